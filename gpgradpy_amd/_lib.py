@@ -1,0 +1,86 @@
+"""ctypes binding of libgpgrad_hip.so (the C ABI declared in include/gpgrad.h).
+
+The HIP library is the product: if it is missing or cannot be loaded this module raises -- there is no
+CPU fallback anywhere in this package.  Build it with `python -c "import __graft_entry__ as g; g.build()"`
+or `make -C gpgradpy_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgpgrad_hip.so")
+
+GPG_KERNEL = {"SqExp": 0, "Ma5f2": 1}
+GPG_WELLCOND = {"base": 0, "precon": 1}
+PROF_CATS = ("assembly", "potrf", "trsm", "gemm_panel", "gemm_trail", "reduce")
+PROF_NCAT = len(PROF_CATS)
+
+# every symbol include/gpgrad.h declares
+ABI_SYMBOLS = (
+    "gpg_create", "gpg_destroy", "gpg_last_error", "gpg_set_data", "gpg_lkd", "gpg_lkd_batch",
+    "gpg_setup_eval", "gpg_predict", "gpg_get_matrix", "gpg_prof_enable", "gpg_prof_read", "gpg_set_panel",
+    "gpg_device_info",
+)
+
+
+class GpgHp(C.Structure):
+    _fields_ = [("theta", C.POINTER(C.c_double)), ("varK_mat", C.c_double), ("var_fval", C.c_double),
+                ("var_fgrad", C.c_double), ("eta", C.c_double), ("wellcond", C.c_int),
+                ("closed_form_varK", C.c_int)]
+
+
+class GpgLkdOut(C.Structure):
+    _fields_ = [("ln_lkd", C.c_double), ("ln_det", C.c_double), ("beta", C.c_double), ("varK", C.c_double),
+                ("rKr", C.c_double), ("info", C.c_int), ("pad_", C.c_int)]
+
+
+class GpgError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library once; raise loudly when it is absent (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GpgError(f"{LIB_PATH} not found: build the HIP extension first "
+                       "(python -c 'import __graft_entry__ as g; g.build()'); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    vp = C.c_void_p
+    lib.gpg_create.argtypes = [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.gpg_create.restype = C.c_int
+    lib.gpg_destroy.argtypes = [vp]
+    lib.gpg_destroy.restype = None
+    lib.gpg_last_error.argtypes = [vp]
+    lib.gpg_last_error.restype = C.c_char_p
+    lib.gpg_set_data.argtypes = [vp, dp, dp, dp]
+    lib.gpg_set_data.restype = C.c_int
+    lib.gpg_lkd.argtypes = [vp, C.POINTER(GpgHp), C.POINTER(GpgLkdOut)]
+    lib.gpg_lkd.restype = C.c_int
+    lib.gpg_lkd_batch.argtypes = [vp, C.c_int, dp, C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(GpgLkdOut)]
+    lib.gpg_lkd_batch.restype = C.c_int
+    lib.gpg_setup_eval.argtypes = [vp, C.POINTER(GpgHp), C.c_double, dp]
+    lib.gpg_setup_eval.restype = C.c_int
+    lib.gpg_predict.argtypes = [vp, C.c_int, dp, C.c_double, dp, dp, dp]
+    lib.gpg_predict.restype = C.c_int
+    lib.gpg_get_matrix.argtypes = [vp, C.POINTER(GpgHp), C.c_int, dp]
+    lib.gpg_get_matrix.restype = C.c_int
+    lib.gpg_prof_enable.argtypes = [vp, C.c_uint]
+    lib.gpg_prof_enable.restype = C.c_int
+    lib.gpg_prof_read.argtypes = [vp, dp, C.POINTER(C.c_longlong), dp]
+    lib.gpg_prof_read.restype = C.c_int
+    lib.gpg_set_panel.argtypes = [vp, C.c_int]
+    lib.gpg_set_panel.restype = C.c_int
+    lib.gpg_device_info.argtypes = [C.c_int, C.c_char_p, C.c_int]
+    lib.gpg_device_info.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def as_dp(arr):
+    return arr.ctypes.data_as(C.POINTER(C.c_double))

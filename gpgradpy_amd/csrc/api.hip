@@ -1,0 +1,369 @@
+// C ABI of libgpgrad_hip.so (see include/gpgrad.h for the contract and the reference citations).
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include "gpg_internal.h"
+
+static thread_local std::string g_create_err;
+
+// ---- profiling helpers ---------------------------------------------------------------------------
+void gpg_prof_begin(gpg_ctx* c, int cat, double work) {
+  c->prof_open = -1;
+  if (!(c->prof_mask & (1u << cat))) return;
+  std::pair<hipEvent_t, hipEvent_t> ev;
+  if (!c->prof_pool.empty()) {
+    ev = c->prof_pool.back();
+    c->prof_pool.pop_back();
+  } else {
+    (void)hipEventCreate(&ev.first);
+    (void)hipEventCreate(&ev.second);
+  }
+  (void)hipEventRecord(ev.first, c->stream);
+  c->prof_pending.push_back(ProfEvent{ev.first, ev.second, cat});
+  c->prof_open = (int)c->prof_pending.size() - 1;
+  c->prof_work[cat] += work;
+}
+
+void gpg_prof_end(gpg_ctx* c) {
+  if (c->prof_open < 0) return;
+  (void)hipEventRecord(c->prof_pending[c->prof_open].e1, c->stream);
+  c->prof_open = -1;
+}
+
+static AsmParams make_params(const gpg_ctx* c, const gpg_hp* hp, int mode) {
+  AsmParams p;
+  memset(&p, 0, sizeof(p));
+  p.n = c->n; p.d = c->d; p.use_grad = c->use_grad; p.kernel = c->kernel;
+  p.N = c->N; p.Npad = c->Npad; p.ld = c->ld;
+  p.precon = hp->wellcond == GPG_WELLCOND_PRECON ? 1 : 0;
+  p.mode = mode;
+  p.varK = hp->varK_mat;
+  p.eta = hp->eta;
+  for (int k = 0; k < c->d; ++k) p.theta[k] = hp->theta[k];
+  return p;
+}
+
+static int check_hp(gpg_ctx* c, const gpg_hp* hp) {
+  if (!c) return -1;
+  if (!hp || !hp->theta) { c->err = "hp / hp->theta is NULL"; return -1; }
+  if (!c->have_data) { c->err = "gpg_set_data has not been called"; return -1; }
+  for (int k = 0; k < c->d; ++k)
+    if (std::isnan(hp->theta[k])) { c->err = "There are nan values in theta"; return -1; }  // Kernel.py:201
+  if (!(hp->varK_mat > 0.0)) { c->err = "varK must be positive"; return -1; }               // Kernel.py:199
+  if (hp->wellcond == GPG_WELLCOND_PRECON && !c->use_grad) {
+    c->err = "wellcond 'precon' requires use_grad (Kernel.py:222)";
+    return -1;
+  }
+  return 0;
+}
+
+static int ensure_scal(gpg_ctx* c, int slots) {
+  if (slots <= c->scal_slots) return 0;
+  if (c->scal) (void)hipFree(c->scal);
+  if (c->info) (void)hipFree(c->info);
+  if (c->h_scal) (void)hipHostFree(c->h_scal);
+  if (c->h_info) (void)hipHostFree(c->h_info);
+  c->scal = nullptr; c->info = nullptr; c->h_scal = nullptr; c->h_info = nullptr; c->scal_slots = 0;
+  GPG_HIP_OK(c, hipMalloc(&c->scal, sizeof(double) * 8 * slots));
+  GPG_HIP_OK(c, hipMalloc(&c->info, sizeof(int) * slots));
+  GPG_HIP_OK(c, hipHostMalloc(&c->h_scal, sizeof(double) * 8 * slots));
+  GPG_HIP_OK(c, hipHostMalloc(&c->h_info, sizeof(int) * slots));
+  c->scal_slots = slots;
+  return 0;
+}
+
+// queue one likelihood evaluation; results land in scal[slot], info[slot]
+static void enqueue_lkd(gpg_ctx* c, const gpg_hp* hp, int slot) {
+  AsmParams p = make_params(c, hp, 0);
+  c->last_precon = p.precon;
+  int* info_save = c->info;
+  c->info = info_save + slot;   // potrf writes through c->info
+  gpg_launch_prep(c, p, hp->var_fval, hp->var_fgrad, 1.0, 0.0, 0.0, 1.0);
+  gpg_launch_assembly(c, p);
+  gpg_cholesky(c);
+  gpg_launch_lkd_reduce(c, slot);
+  c->info = info_save;
+}
+
+static void finish_lkd(const gpg_ctx* c, const gpg_hp* hp, const double* s, int info, gpg_lkd_out* out) {
+  const double nan = std::numeric_limits<double>::quiet_NaN();
+  out->info = info;
+  out->pad_ = 0;
+  if (info != 0) {
+    out->ln_lkd = out->ln_det = out->beta = out->varK = out->rKr = nan;
+    return;
+  }
+  const double N = (double)c->N;
+  out->ln_det = s[0];
+  out->beta = s[1];
+  out->rKr = s[2];
+  if (hp->closed_form_varK) {
+    double vk = s[2] / N;
+    if (!(vk > 1e-32)) vk = 1e-32;                        // CalcLkd.py:151,159
+    out->varK = vk;
+    out->ln_lkd = -(N * log(vk) + s[0]) / 2.0;            // CalcLkd.py:168 (penalty off by default)
+  } else {
+    out->varK = hp->varK_mat;
+    out->ln_lkd = -(s[0] + s[2]) / 2.0;                   // CalcLkd.py:226
+  }
+}
+
+extern "C" {
+
+int gpg_create(gpg_ctx** out, int device, int n_eval, int dim, int use_grad, int kernel) {
+  if (!out) return -1;
+  *out = nullptr;
+  if (n_eval < 1 || dim < 1 || dim > GPG_MAX_DIM) { g_create_err = "n_eval >= 1 and 1 <= dim <= 16 required"; return -1; }
+  if (kernel != GPG_KERNEL_SQEXP && kernel != GPG_KERNEL_MA5F2) { g_create_err = "unknown kernel id"; return -1; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_create_err = "no HIP device visible"; return -2; }
+  if (device < 0 || device >= ndev) { g_create_err = "device index out of range"; return -1; }
+  gpg_ctx* c = new gpg_ctx();
+  c->device = device; c->n = n_eval; c->d = dim; c->use_grad = use_grad ? 1 : 0; c->kernel = kernel;
+  c->N = use_grad ? n_eval * (dim + 1) : n_eval;
+  c->Npad = ((c->N + GPG_TILE - 1) / GPG_TILE) * GPG_TILE;
+  c->R = GPG_RHS_ROWS;
+  c->ld = c->Npad + c->R;
+#define CREATE_OK(call)                                                              \
+  do {                                                                               \
+    hipError_t e_ = (call);                                                          \
+    if (e_ != hipSuccess) {                                                          \
+      g_create_err = std::string(#call) + ": " + hipGetErrorString(e_);              \
+      gpg_destroy(c);                                                                \
+      return -2;                                                                     \
+    }                                                                                \
+  } while (0)
+  CREATE_OK(hipSetDevice(device));
+  CREATE_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  CREATE_OK(hipMalloc(&c->A, sizeof(double) * (size_t)c->ld * c->Npad));
+  CREATE_OK(hipMalloc(&c->Xt, sizeof(double) * (size_t)c->n * c->d));
+  CREATE_OK(hipMalloc(&c->y, sizeof(double) * c->N));
+  CREATE_OK(hipMalloc(&c->noise, sizeof(double) * c->N));
+  CREATE_OK(hipMalloc(&c->dvec, sizeof(double) * c->Npad));
+  CREATE_OK(hipMalloc(&c->invp, sizeof(double) * c->Npad));
+  CREATE_OK(hipMalloc(&c->zvec, sizeof(double) * c->Npad));
+  CREATE_OK(hipMalloc(&c->tmpv, sizeof(double) * c->Npad));
+  CREATE_OK(hipMemset(c->A, 0, sizeof(double) * (size_t)c->ld * c->Npad));
+#undef CREATE_OK
+  if (ensure_scal(c, 64) != 0) { g_create_err = c->err; gpg_destroy(c); return -2; }
+  *out = c;
+  return 0;
+}
+
+void gpg_destroy(gpg_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (auto& pe : c->prof_pending) { (void)hipEventDestroy(pe.e0); (void)hipEventDestroy(pe.e1); }
+  for (auto& ev : c->prof_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+  double* bufs[] = {c->A, c->Xt, c->y, c->noise, c->dvec, c->invp, c->zvec, c->tmpv, c->scal, c->Wt, c->xq_dev,
+                    c->musig, c->dense_tmp};
+  for (double* b : bufs) if (b) (void)hipFree(b);
+  if (c->info) (void)hipFree(c->info);
+  if (c->h_scal) (void)hipHostFree(c->h_scal);
+  if (c->h_info) (void)hipHostFree(c->h_info);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* gpg_last_error(const gpg_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+int gpg_set_data(gpg_ctx* c, const double* x, const double* data_vec, const double* noise_var) {
+  if (!c) return -1;
+  if (!x || !data_vec) { c->err = "x / data_vec is NULL"; return -1; }
+  GPG_HIP_OK(c, hipSetDevice(c->device));
+  std::vector<double> xt((size_t)c->n * c->d);
+  for (int a = 0; a < c->n; ++a)
+    for (int k = 0; k < c->d; ++k) xt[(size_t)k * c->n + a] = x[(size_t)a * c->d + k];
+  GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
+  GPG_HIP_OK(c, hipMemcpy(c->Xt, xt.data(), sizeof(double) * xt.size(), hipMemcpyHostToDevice));
+  GPG_HIP_OK(c, hipMemcpy(c->y, data_vec, sizeof(double) * c->N, hipMemcpyHostToDevice));
+  if (noise_var) GPG_HIP_OK(c, hipMemcpy(c->noise, noise_var, sizeof(double) * c->N, hipMemcpyHostToDevice));
+  else GPG_HIP_OK(c, hipMemset(c->noise, 0, sizeof(double) * c->N));
+  c->have_data = true;
+  c->factor_valid = c->eval_ready = false;
+  return 0;
+}
+
+int gpg_lkd(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out) {
+  int rc = check_hp(c, hp);
+  if (rc) return rc;
+  if (!out) { c->err = "out is NULL"; return -1; }
+  GPG_HIP_OK(c, hipSetDevice(c->device));
+  GPG_HIP_OK(c, hipMemsetAsync(c->info, 0, sizeof(int), c->stream));
+  enqueue_lkd(c, hp, 0);
+  GPG_HIP_OK(c, hipMemcpyAsync(c->h_scal, c->scal, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
+  GPG_HIP_OK(c, hipMemcpyAsync(c->h_info, c->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
+  GPG_HIP_OK(c, hipGetLastError());
+  c->factor_valid = (c->h_info[0] == 0);
+  c->eval_ready = false;
+  finish_lkd(c, hp, c->h_scal, c->h_info[0], out);
+  return out->info;
+}
+
+int gpg_lkd_batch(gpg_ctx* c, int m, const double* hp_rows, int row_len, double eta, int wellcond,
+                  int closed_form_varK, gpg_lkd_out* out) {
+  if (!c) return -1;
+  if (m < 1 || !hp_rows || !out || row_len < c->d + 3) { c->err = "bad batch arguments (row_len >= d + 3)"; return -1; }
+  GPG_HIP_OK(c, hipSetDevice(c->device));
+  int rc = ensure_scal(c, m);
+  if (rc) return rc;
+  std::vector<gpg_hp> hps(m);
+  for (int i = 0; i < m; ++i) {
+    const double* row = hp_rows + (size_t)i * row_len;
+    hps[i].theta = row;
+    hps[i].varK_mat = row[c->d];
+    hps[i].var_fval = row[c->d + 1];
+    hps[i].var_fgrad = row[c->d + 2];
+    hps[i].eta = eta;
+    hps[i].wellcond = wellcond;
+    hps[i].closed_form_varK = closed_form_varK;
+    rc = check_hp(c, &hps[i]);
+    if (rc) return rc;
+  }
+  GPG_HIP_OK(c, hipMemsetAsync(c->info, 0, sizeof(int) * m, c->stream));
+  for (int i = 0; i < m; ++i) enqueue_lkd(c, &hps[i], i);
+  GPG_HIP_OK(c, hipMemcpyAsync(c->h_scal, c->scal, sizeof(double) * 8 * m, hipMemcpyDeviceToHost, c->stream));
+  GPG_HIP_OK(c, hipMemcpyAsync(c->h_info, c->info, sizeof(int) * m, hipMemcpyDeviceToHost, c->stream));
+  GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
+  GPG_HIP_OK(c, hipGetLastError());
+  for (int i = 0; i < m; ++i) finish_lkd(c, &hps[i], c->h_scal + (size_t)8 * i, c->h_info[i], &out[i]);
+  c->factor_valid = c->eval_ready = false;
+  return 0;
+}
+
+int gpg_setup_eval(gpg_ctx* c, const gpg_hp* hp, double beta, double* alpha_out) {
+  int rc = check_hp(c, hp);
+  if (rc) return rc;
+  GPG_HIP_OK(c, hipSetDevice(c->device));
+  c->eval_ready = false;
+  AsmParams p = make_params(c, hp, 0);
+  c->last_precon = p.precon;
+  GPG_HIP_OK(c, hipMemsetAsync(c->info, 0, sizeof(int), c->stream));
+  gpg_launch_prep(c, p, hp->var_fval, hp->var_fgrad, -beta, 1.0, 0.0, 0.0);   // RHS row 0 = (y - V beta) P^-1
+  gpg_launch_assembly(c, p);
+  gpg_cholesky(c);
+  GPG_HIP_OK(c, hipMemcpyAsync(c->h_info, c->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
+  GPG_HIP_OK(c, hipGetLastError());
+  if (c->h_info[0] != 0) { c->factor_valid = false; return c->h_info[0]; }
+  c->factor_valid = true;
+  gpg_backward_solve(c);
+  if (alpha_out) {
+    gpg_launch_alpha(c, c->tmpv);
+    GPG_HIP_OK(c, hipMemcpyAsync(alpha_out, c->tmpv, sizeof(double) * c->N, hipMemcpyDeviceToHost, c->stream));
+  }
+  GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
+  GPG_HIP_OK(c, hipGetLastError());
+  c->eval_ready = true;
+  c->eval_beta = beta;
+  c->eval_params = p;   // theta etc. for the cross kernel
+  c->err.clear();
+  return 0;
+}
+
+int gpg_predict(gpg_ctx* c, int nx, const double* xq, double varK, double* mu, double* sig, double* sig2_raw) {
+  if (!c) return -1;
+  if (!c->eval_ready) { c->err = "gpg_setup_eval must succeed before gpg_predict"; return -1; }
+  if (nx < 1 || !xq || !mu || !sig) { c->err = "bad predict arguments"; return -1; }
+  GPG_HIP_OK(c, hipSetDevice(c->device));
+  const int nxp = ((nx + 63) / 64) * 64;
+  if (nxp > c->xq_cap) {
+    if (c->Wt) (void)hipFree(c->Wt);
+    if (c->xq_dev) (void)hipFree(c->xq_dev);
+    if (c->musig) (void)hipFree(c->musig);
+    c->Wt = c->xq_dev = c->musig = nullptr; c->xq_cap = 0;
+    GPG_HIP_OK(c, hipMalloc(&c->Wt, sizeof(double) * (size_t)nxp * c->Npad));
+    GPG_HIP_OK(c, hipMalloc(&c->xq_dev, sizeof(double) * (size_t)nxp * c->d));
+    GPG_HIP_OK(c, hipMalloc(&c->musig, sizeof(double) * 2 * nxp));
+    c->xq_cap = nxp;
+  }
+  // the allocation may be larger than this call's nxp: kernels index with this call's nxp
+  std::vector<double> xt((size_t)nxp * c->d, 0.0);
+  for (int j = 0; j < nx; ++j)
+    for (int k = 0; k < c->d; ++k) xt[(size_t)k * nxp + j] = xq[(size_t)j * c->d + k];
+  GPG_HIP_OK(c, hipMemcpyAsync(c->xq_dev, xt.data(), sizeof(double) * xt.size(), hipMemcpyHostToDevice, c->stream));
+  GPG_HIP_OK(c, hipMemsetAsync(c->Wt, 0, sizeof(double) * (size_t)nxp * c->Npad, c->stream));
+  AsmParams p = c->eval_params;
+  gpg_launch_cross(c, p, nx, nxp);
+  gpg_launch_predict_reduce(c, nx, nxp, c->eval_beta, varK, 0);
+  gpg_forward_rows(c, c->Wt, nxp, nxp);
+  gpg_launch_predict_reduce(c, nx, nxp, c->eval_beta, varK, 1);
+  std::vector<double> host(2 * (size_t)nxp);
+  GPG_HIP_OK(c, hipMemcpyAsync(host.data(), c->musig, sizeof(double) * 2 * nxp, hipMemcpyDeviceToHost, c->stream));
+  GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
+  GPG_HIP_OK(c, hipGetLastError());
+  const double sigK = sqrt(varK);
+  for (int j = 0; j < nx; ++j) {
+    mu[j] = host[j];
+    double s2 = host[nxp + j];
+    if (sig2_raw) sig2_raw[j] = s2;
+    sig[j] = sqrt(s2 < 0.0 ? 0.0 : s2) * sigK;   // GpEvalModel.py:165-166
+  }
+  return 0;
+}
+
+int gpg_get_matrix(gpg_ctx* c, const gpg_hp* hp, int which, double* out) {
+  if (!c) return -1;
+  if (!out || which < 0 || which > 3) { c->err = "bad get_matrix arguments"; return -1; }
+  GPG_HIP_OK(c, hipSetDevice(c->device));
+  if (!c->dense_tmp) GPG_HIP_OK(c, hipMalloc(&c->dense_tmp, sizeof(double) * (size_t)c->N * c->N));
+  if (which == 3) {
+    if (!c->factor_valid) { c->err = "no valid factor on the device"; return -1; }
+  } else {
+    int rc = check_hp(c, hp);
+    if (rc) return rc;
+    AsmParams p = make_params(c, hp, which == 0 ? 1 : (which == 1 ? 2 : 0));
+    c->last_precon = p.precon;
+    gpg_launch_prep(c, p, hp->var_fval, hp->var_fgrad, 0.0, 0.0, 0.0, 0.0);
+    unsigned save = c->prof_mask; c->prof_mask = 0;
+    gpg_launch_assembly(c, p);
+    c->prof_mask = save;
+    c->factor_valid = c->eval_ready = false;
+  }
+  gpg_launch_extract(c, which);
+  GPG_HIP_OK(c, hipMemcpyAsync(out, c->dense_tmp, sizeof(double) * (size_t)c->N * c->N, hipMemcpyDeviceToHost,
+                               c->stream));
+  GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
+  GPG_HIP_OK(c, hipGetLastError());
+  return 0;
+}
+
+int gpg_prof_enable(gpg_ctx* c, unsigned mask) {
+  if (!c) return -1;
+  c->prof_mask = mask;
+  return 0;
+}
+
+int gpg_prof_read(gpg_ctx* c, double ms[GPG_PROF_NCAT], long long count[GPG_PROF_NCAT], double work[GPG_PROF_NCAT]) {
+  if (!c) return -1;
+  GPG_HIP_OK(c, hipSetDevice(c->device));
+  GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
+  for (int i = 0; i < GPG_PROF_NCAT; ++i) { ms[i] = 0.0; count[i] = 0; work[i] = c->prof_work[i]; c->prof_work[i] = 0.0; }
+  for (auto& pe : c->prof_pending) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, pe.e0, pe.e1) == hipSuccess) { ms[pe.cat] += t; count[pe.cat] += 1; }
+    c->prof_pool.push_back({pe.e0, pe.e1});
+  }
+  c->prof_pending.clear();
+  return 0;
+}
+
+int gpg_set_panel(gpg_ctx* c, int nb_outer) {
+  if (!c) return -1;
+  if (nb_outer < 128 || nb_outer > 1024 || nb_outer % 128) { c->err = "nb_outer must be a multiple of 128 in [128, 1024]"; return -1; }
+  c->nb_outer = nb_outer;
+  return 0;
+}
+
+int gpg_device_info(int device, char* buf, int buflen) {
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return -2;
+  snprintf(buf, buflen, "%s %s CUs=%d clock=%dkHz mem=%.1fGiB", prop.name, prop.gcnArchName, prop.multiProcessorCount,
+           prop.clockRate, prop.totalGlobalMem / 1073741824.0);
+  return 0;
+}
+
+}  // extern "C"

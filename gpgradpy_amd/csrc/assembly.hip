@@ -1,0 +1,264 @@
+// Fused assembly of the gradient-enhanced covariance matrix (gfx950).
+//
+// One pass produces, directly in the form that is factorised,
+//     Kp = varK * (P^-1 (K + diag(noise / varK)) P^-1 + eta I)           (reference Kernel.py:213-236)
+// from the n x d design alone: the [d, n, n] difference tensor of the reference
+// (CommonFun.py:56-84) is recomputed in registers, the diagonal preconditioner and the nugget are
+// applied in-register, and only the lower triangle (column-major) is written.
+// Kernel formulas: KernelSqExp.py:338-408 and KernelMatern5f2.py:369-448; the operation order of those
+// lines is kept (this file is compiled with -ffp-contract=off) so that entries agree with the NumPy
+// reference to the last ulp of exp()/sqrt().
+//
+// Mapping: lane <-> data point a (rows r = I*n + a are contiguous in a, so every store instruction of
+// a wave writes 512 contiguous bytes of one matrix column); each thread walks TB columns b and emits
+// the (d+1)(d+2)/2 block entries of the ordered pair (a, b) that fall in the lower triangle.
+#include "gpg_internal.h"
+
+namespace {
+
+constexpr int kTB = 16;  // columns (points b) per workgroup
+
+__device__ __forceinline__ double kdiag_of(int kernel, int blk, const double* theta) {
+  if (blk == 0) return 1.0;
+  return kernel == GPG_KERNEL_SQEXP ? 2.0 * theta[blk - 1] : theta[blk - 1] * (5.0 / 3.0);
+}
+
+// dvec = diag(Kern) + noise / varK ; invp = 1/sqrt(dvec) (Kernel.py:218,224-226)
+__global__ void prep_diag_kernel(AsmParams P, const double* __restrict__ noise, double var_fval, double var_fgrad,
+                                 double* __restrict__ dvec, double* __restrict__ invp) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= P.Npad) return;
+  if (r >= P.N) { dvec[r] = 1.0; invp[r] = 1.0; return; }
+  int blk = P.use_grad ? r / P.n : 0;
+  double kd = kdiag_of(P.kernel, blk, P.theta);
+  double nz = blk == 0 ? (var_fval >= 0.0 ? var_fval : noise[r]) : (var_fgrad >= 0.0 ? var_fgrad : noise[r]);
+  double dv = kd + nz / P.varK;
+  dvec[r] = dv;
+  invp[r] = P.precon ? 1.0 / sqrt(dv) : 1.0;
+}
+
+// rows [N, ld) of every column: identity padding and the right-hand-side rows
+//   rhs row 0 = (s0 V + t0 y) P^-1, rhs row 1 = (s1 V + t1 y) P^-1, V = [1_n; 0] (GpMeanFun.py:172-191)
+__global__ void prep_rows_kernel(AsmParams P, const double* __restrict__ y, const double* __restrict__ invp,
+                                 double s0, double t0, double s1, double t1, double* __restrict__ A) {
+  int c = blockIdx.x;
+  size_t col = (size_t)c * P.ld;
+  for (int r = P.N + threadIdx.x; r < P.ld; r += blockDim.x) {
+    double v = 0.0;
+    if (r < P.Npad) {
+      v = (r == c) ? 1.0 : 0.0;
+    } else if (c < P.N) {
+      int j = r - P.Npad;
+      double vc = c < P.n ? 1.0 : 0.0;
+      if (j == 0) v = (s0 * vc + t0 * y[c]) * invp[c];
+      else if (j == 1) v = (s1 * vc + t1 * y[c]) * invp[c];
+    }
+    A[col + r] = v;
+  }
+}
+
+template <int KERN, int D>
+__global__ void __launch_bounds__(256) assemble_kernel(AsmParams P, const double* __restrict__ Xt,
+                                                       const double* __restrict__ dvec,
+                                                       const double* __restrict__ invp, double* __restrict__ A) {
+  __shared__ double xb[kTB][D];
+  __shared__ double ipb[kTB][D + 1];
+  const int n = P.n;
+  const int a = blockIdx.x * 256 + threadIdx.x;
+  const int b0 = blockIdx.y * kTB;
+  const int nblk = P.use_grad ? D + 1 : 1;
+  for (int t = threadIdx.x; t < kTB * D; t += 256) {
+    int bb = t / D, k = t % D, b = b0 + bb;
+    xb[bb][k] = b < n ? Xt[(size_t)k * n + b] : 0.0;
+  }
+  for (int t = threadIdx.x; t < kTB * (D + 1); t += 256) {
+    int bb = t / (D + 1), J = t % (D + 1), b = b0 + bb;
+    ipb[bb][J] = (b < n && J < nblk) ? invp[(size_t)J * n + b] : 0.0;
+  }
+  __syncthreads();
+  if (a >= n) return;
+
+  double xa[D], ipa[D + 1], th[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) { xa[k] = Xt[(size_t)k * n + a]; th[k] = P.theta[k]; }
+#pragma unroll
+  for (int I = 0; I <= D; ++I) ipa[I] = I < nblk ? invp[(size_t)I * n + a] : 0.0;
+
+  const int mode = P.mode, precon = P.precon, ld = P.ld;
+  const double varK = P.varK, eta = P.eta;
+  const int bend = min(kTB, n - b0);
+  const double sqrt5 = sqrt(5.0);
+
+  for (int bb = 0; bb < bend; ++bb) {
+    const int b = b0 + bb;
+    double R[D];
+    double E, M1 = 0.0, K00;
+    if (KERN == GPG_KERNEL_SQEXP) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) { R[k] = xa[k] - xb[bb][k]; s -= th[k] * (R[k] * R[k]); }
+      E = exp(s);
+      K00 = E;
+    } else {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) { R[k] = xa[k] - xb[bb][k]; s += th[k] * (R[k] * R[k]); }
+      double nu = sqrt(s);
+      E = exp(-sqrt5 * nu);                       // Abase
+      M1 = ((5.0 / 3.0) * (1.0 + sqrt5 * nu)) * E;  // mat1
+      K00 = (1.0 + sqrt5 * nu + (5.0 / 3.0) * (nu * nu)) * E;
+    }
+    const bool diag_pt = (a == b);
+    const bool low_pt = (a >= b);
+
+    // emit one entry: block (I, J), kernel value v
+    auto emit = [&](int I, int J, double v) {
+      const size_t r = (size_t)I * n + a, c = (size_t)J * n + b;
+      double o;
+      if (mode == 1) {
+        o = v;
+      } else if (diag_pt && I == J) {
+        double dv = dvec[r];
+        if (precon) {
+          double kc = (ipa[I] * dv) * ipa[I];
+          o = varK * (kc + eta);
+          if (mode == 2) { double p = sqrt(dv); o = (p * o) * p; }
+        } else {
+          o = varK * (dv + eta);
+        }
+      } else {
+        if (precon) {
+          o = varK * ((ipa[I] * v) * ipb[bb][J]);
+          if (mode == 2) o = ((1.0 / ipa[I]) * o) * (1.0 / ipb[bb][J]);
+        } else {
+          o = varK * v;
+        }
+      }
+      A[c * ld + r] = o;
+    };
+
+    if (low_pt) emit(0, 0, K00);
+    if (nblk > 1) {
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        double vi0, vii;
+        if (KERN == GPG_KERNEL_SQEXP) {
+          vi0 = ((-2.0 * th[i]) * R[i]) * E;
+          vii = (2.0 * th[i] - (4.0 * (th[i] * th[i])) * (R[i] * R[i])) * E;
+        } else {
+          vi0 = ((-th[i]) * R[i]) * M1;
+          vii = th[i] * M1 - (((25.0 / 3.0) * (th[i] * th[i])) * (R[i] * R[i])) * E;
+        }
+        emit(i + 1, 0, vi0);
+        if (low_pt) emit(i + 1, i + 1, vii);
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+          if (j < i) {  // block row i+1 > block column j+1; the reference's (lo, hi) = (j, i) ordering
+            double vij;
+            if (KERN == GPG_KERNEL_SQEXP) vij = ((-4.0 * th[j]) * th[i]) * ((R[j] * R[i]) * E);
+            else vij = (((((-(25.0 / 3.0)) * th[j]) * th[i]) * R[j]) * R[i]) * E;
+            emit(i + 1, j + 1, vij);
+          }
+        }
+      }
+    }
+  }
+}
+
+// Cross matrix for the posterior (GpEvalModel.py:133-139): Wt[j, c] = Kyx[c, j] / p_c, c = I*n + a,
+// stored as RHS rows (query index j contiguous).
+template <int KERN, int D>
+__global__ void __launch_bounds__(256) cross_kernel(AsmParams P, const double* __restrict__ Xt,
+                                                    const double* __restrict__ Xq, int nx, int nxp,
+                                                    const double* __restrict__ invp, double* __restrict__ Wt) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int j = (int)(t % nxp);
+  const long long a_ll = t / nxp;
+  if (a_ll >= P.n) return;
+  const int a = (int)a_ll, n = P.n;
+  const int nblk = P.use_grad ? D + 1 : 1;
+  double R[D];
+  double E, M1 = 0.0, K00;
+  const double sqrt5 = sqrt(5.0);
+  if (j < nx) {
+    if (KERN == GPG_KERNEL_SQEXP) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) { R[k] = Xt[(size_t)k * n + a] - Xq[(size_t)k * nxp + j]; s -= P.theta[k] * (R[k] * R[k]); }
+      E = exp(s);
+      K00 = E;
+    } else {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) { R[k] = Xt[(size_t)k * n + a] - Xq[(size_t)k * nxp + j]; s += P.theta[k] * (R[k] * R[k]); }
+      double nu = sqrt(s);
+      E = exp(-sqrt5 * nu);
+      M1 = ((5.0 / 3.0) * (1.0 + sqrt5 * nu)) * E;
+      K00 = (1.0 + sqrt5 * nu + (5.0 / 3.0) * (nu * nu)) * E;
+    }
+  }
+  for (int I = 0; I < nblk; ++I) {
+    const size_t c = (size_t)I * n + a;
+    double v = 0.0;
+    if (j < nx) {
+      if (I == 0) v = K00;
+      else if (KERN == GPG_KERNEL_SQEXP) v = ((-2.0 * P.theta[I - 1]) * R[I - 1]) * E;
+      else v = ((-P.theta[I - 1]) * R[I - 1]) * M1;
+      v *= invp[c];
+    }
+    Wt[c * nxp + j] = v;
+  }
+}
+
+template <int KERN>
+void launch_assemble_d(gpg_ctx* c, const AsmParams& p) {
+  dim3 grid((p.n + 255) / 256, (p.n + kTB - 1) / kTB);
+#define CASE_D(DD)                                                                                  \
+  case DD:                                                                                          \
+    hipLaunchKernelGGL((assemble_kernel<KERN, DD>), grid, dim3(256), 0, c->stream, p, c->Xt, c->dvec, \
+                       c->invp, c->A);                                                              \
+    break;
+  switch (p.d) {
+    CASE_D(1) CASE_D(2) CASE_D(3) CASE_D(4) CASE_D(5) CASE_D(6) CASE_D(7) CASE_D(8)
+    CASE_D(9) CASE_D(10) CASE_D(11) CASE_D(12) CASE_D(13) CASE_D(14) CASE_D(15) CASE_D(16)
+  }
+#undef CASE_D
+}
+
+template <int KERN>
+void launch_cross_d(gpg_ctx* c, const AsmParams& p, int nx, int nxp) {
+  long long total = (long long)p.n * nxp;
+  dim3 grid((unsigned)((total + 255) / 256));
+#define CASE_D(DD)                                                                                   \
+  case DD:                                                                                           \
+    hipLaunchKernelGGL((cross_kernel<KERN, DD>), grid, dim3(256), 0, c->stream, p, c->Xt, c->xq_dev, nx, \
+                       nxp, c->invp, c->Wt);                                                         \
+    break;
+  switch (p.d) {
+    CASE_D(1) CASE_D(2) CASE_D(3) CASE_D(4) CASE_D(5) CASE_D(6) CASE_D(7) CASE_D(8)
+    CASE_D(9) CASE_D(10) CASE_D(11) CASE_D(12) CASE_D(13) CASE_D(14) CASE_D(15) CASE_D(16)
+  }
+#undef CASE_D
+}
+
+}  // namespace
+
+void gpg_launch_prep(gpg_ctx* c, const AsmParams& p, double var_fval, double var_fgrad, double s0, double t0,
+                     double s1, double t1) {
+  hipLaunchKernelGGL(prep_diag_kernel, dim3((p.Npad + 255) / 256), dim3(256), 0, c->stream, p, c->noise, var_fval,
+                     var_fgrad, c->dvec, c->invp);
+  hipLaunchKernelGGL(prep_rows_kernel, dim3(p.Npad), dim3(256), 0, c->stream, p, c->y, c->invp, s0, t0, s1, t1, c->A);
+}
+
+void gpg_launch_assembly(gpg_ctx* c, const AsmParams& p) {
+  double bytes = 8.0 * (double)p.N * ((double)p.N + 1.0) / 2.0;
+  gpg_prof_begin(c, GPG_PROF_ASSEMBLY, bytes);
+  if (p.kernel == GPG_KERNEL_SQEXP) launch_assemble_d<GPG_KERNEL_SQEXP>(c, p);
+  else launch_assemble_d<GPG_KERNEL_MA5F2>(c, p);
+  gpg_prof_end(c);
+}
+
+void gpg_launch_cross(gpg_ctx* c, const AsmParams& p, int nx, int nxp) {
+  if (p.kernel == GPG_KERNEL_SQEXP) launch_cross_d<GPG_KERNEL_SQEXP>(c, p, nx, nxp);
+  else launch_cross_d<GPG_KERNEL_MA5F2>(c, p, nx, nxp);
+}

@@ -1,0 +1,94 @@
+// Internal declarations shared by the HIP translation units of libgpgrad_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include "../../include/gpgrad.h"
+
+#define GPG_MAX_DIM 16
+#define GPG_TILE 128      // padding / GEMM tile granularity
+#define GPG_NBI 64        // inner (diagonal block) width of the panel factorisation
+#define GPG_RHS_ROWS 128  // right-hand-side rows appended below the matrix (ride along the Cholesky)
+
+// Arguments of the fused assembly kernels (passed by value -> SGPRs / kernarg segment).
+struct AsmParams {
+  int n, d, use_grad, kernel;
+  int N, Npad, ld;
+  int precon;      // 1: write varK*(P^-1 Kw P^-1 + eta I); 0: varK*(Kw + eta I)
+  int mode;        // 0: matrix to factorise, 1: raw Kern, 2: Kcov (P Kp P for precon)
+  double varK, eta;
+  double theta[GPG_MAX_DIM];
+};
+
+struct ProfEvent { hipEvent_t e0, e1; int cat; };
+
+struct gpg_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int n = 0, d = 0, use_grad = 0, kernel = 0;
+  int N = 0, Npad = 0, R = GPG_RHS_ROWS, ld = 0;
+  int nb_outer = 256;
+  // device buffers
+  double* A = nullptr;       // [ld x Npad] column-major; lower triangle + RHS rows
+  double* Xt = nullptr;      // [d x n]   (coordinate-major copy of x for coalesced loads)
+  double* y = nullptr;       // [N]
+  double* noise = nullptr;   // [N] known noise variances (zeros if none)
+  double* dvec = nullptr;    // [Npad] diag(Kern) + noise / varK
+  double* invp = nullptr;    // [Npad] 1/sqrt(dvec) (precon) or 1
+  double* zvec = nullptr;    // [Npad] L^-T L^-1 P^-1 (y - V beta)  (= p * alpha)
+  double* tmpv = nullptr;    // [Npad] scratch for the backward solve
+  double* scal = nullptr;    // device scalars of the reductions
+  int* info = nullptr;       // device: first failing pivot (0 = none)
+  double* Wt = nullptr;      // prediction RHS rows [wt_rows x Npad]
+  int wt_rows = 0;
+  double* xq_dev = nullptr;  // [d x nxp]
+  double* musig = nullptr;   // [2 x nxp]
+  int xq_cap = 0;
+  double* dense_tmp = nullptr;  // [N x N] materialisation buffer (on request)
+  // pinned host staging
+  double* h_scal = nullptr;
+  int* h_info = nullptr;
+  // state
+  bool have_data = false;
+  bool factor_valid = false;   // A holds L of the last setup_eval
+  bool eval_ready = false;
+  double eval_beta = 0.0;
+  int last_precon = 0;         // wellcond of the matrix currently in A
+  int scal_slots = 0;
+  AsmParams eval_params;       // hyperparameters of the factor kept for gpg_predict
+  // profiling
+  unsigned prof_mask = 0;
+  std::vector<ProfEvent> prof_pending;
+  int prof_open = -1;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
+  double prof_work[GPG_PROF_NCAT] = {0, 0, 0, 0, 0, 0};
+  std::string err;
+};
+
+#define GPG_SCAL_COUNT 16
+
+// ---- launchers (each enqueues on ctx->stream; none synchronises) ---------------------------------
+void gpg_launch_prep(gpg_ctx* c, const AsmParams& p, double var_fval, double var_fgrad,
+                     double s0, double t0, double s1, double t1);
+void gpg_launch_assembly(gpg_ctx* c, const AsmParams& p);
+void gpg_launch_cross(gpg_ctx* c, const AsmParams& p, int nx, int nxp);   // Wt <- P^-1 Kyx (transposed)
+void gpg_cholesky(gpg_ctx* c);                                           // blocked right-looking, in place
+void gpg_forward_rows(gpg_ctx* c, double* W, int ldw, int rows);         // W <- W L^-T (rows = RHS rows)
+void gpg_launch_lkd_reduce(gpg_ctx* c, int slot);                        // writes scal[slot*8 ..]
+void gpg_backward_solve(gpg_ctx* c);                                     // zvec <- L^-T (RHS row 0)
+void gpg_launch_alpha(gpg_ctx* c, double* alpha_dev);                    // alpha = zvec * invp
+void gpg_launch_predict_reduce(gpg_ctx* c, int nx, int nxp, double beta, double varK, int phase);
+void gpg_launch_extract(gpg_ctx* c, int which);                          // dense_tmp <- sym / P L
+
+// profiling helpers
+void gpg_prof_begin(gpg_ctx* c, int cat, double work);
+void gpg_prof_end(gpg_ctx* c);
+
+#define GPG_HIP_OK(c, call)                                                              \
+  do {                                                                                   \
+    hipError_t e_ = (call);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      (c)->err = std::string(#call) + ": " + hipGetErrorString(e_);                      \
+      return -2;                                                                         \
+    }                                                                                    \
+  } while (0)

@@ -1,0 +1,601 @@
+"""Host-side mirror of the reference's `GaussianProcess` facade for the likelihood hot path.
+
+Same method names, argument meaning, return shapes and error behaviour as the reference
+(gpgradpy/src/GaussianProcess.py, kernel/Kernel.py, optz/CalcLkd.py, eval/GpEvalModel.py; file:line
+citations below are relative to gpgradpy/src/), but every O(N^2)/O(N^3) step runs in the HIP library
+behind include/gpgrad.h.  What the path does not cover raises NotImplementedError -- there is no
+NumPy/SciPy fallback for any part of the computation.
+"""
+import copy
+import ctypes as C
+import time
+
+import numpy as np
+
+from . import _lib
+from .hpara import HparaOptzInfo, HparaOptzVal, LkdInfo
+
+
+class GaussianProcess:
+    # ---- options read by the hot path (reference GaussianProcess.py:27-113) -------------------------
+    optz_log_hp_theta = True
+    optz_log_hp_var = True
+    optz_log_hp_kernel = True
+    lkd_use_adj_mtd = True
+    lkd_optz_start_mtd = 'hp_best'
+    lkd_hp_best_n_eval = 40
+    lkd_varK_pnlt_use = False
+    lkd_varK_pnlt_lb_var = 0.1
+    lkd_varK_pnlt_c1 = 1.0
+    lkd_varK_pnlt_c2 = 10.0
+    hp_theta_init = 1e-2
+    hp_varK_init = 1.0
+    hp_var_fval_init = 0.0
+    hp_var_fgrad_init = 0.0
+    wellcond_mtd_avail = ['base', 'precon', 'rescale_origin', 'rescale_eta_vary', 'dflt_vmin', 'dflt_vmax']
+    cond_eta_set_mtd = 'Kbase_eta'
+    cond_eta_is_const = True
+    cond_eta_dflt = 1e-8
+    cond_max_target = 1e10
+    cond_max = 1e10
+    cond_max_abs = 1e16
+
+    b_optz_hp_kernel = True
+    b_use_data_scl = False
+    b_has_noisy_data = None
+    b_optz_var_fval = None
+    b_optz_var_fgrad = None
+    bvec_use_grad = None
+    hp_vals = None
+    _time_chofac = 0
+    _last_hp_vec = None
+
+    kernel_types = ('SqExp', 'Ma5f2')
+
+    def __init__(self, dim, use_grad, kernel_type='SqExp', wellcond_mtd='precon', mean_fun_type='poly_ord_0',
+                 path_data_surr='baye_data_surr', surr_name='obj_', device=0):
+        # reference GaussianProcess.py:138-190
+        assert isinstance(dim, int), 'dim must be an integer'
+        assert isinstance(use_grad, bool), 'use_grad must be of type bool'
+        assert isinstance(kernel_type, str), 'kernel_type must be of type str'
+        self.dim = dim
+        self.use_grad = use_grad
+        self.set_wellcond_mtd(wellcond_mtd)
+        self.path_data_surr = path_data_surr
+        self.surr_name = surr_name
+        if kernel_type == 'RatQu':
+            raise NotImplementedError("kernel 'RatQu' is outside the accelerated path (SURVEY.md 8f4)")
+        if kernel_type not in self.kernel_types:
+            raise Exception('Kernel type is not available')                       # Kernel.py:108-109
+        self.kernel_type = kernel_type
+        self.hp_kernel_default = None                                           # KernelSqExp.py:577, KernelMatern5f2.py:651
+        self.kernel_has_hp = False
+        self.hp_kernel = None
+        if mean_fun_type != 'poly_ord_0':
+            raise Exception(f'mean_fun_type = {mean_fun_type} not available')     # GpMeanFun.py:203-204
+        self.mean_fun_type = mean_fun_type
+        self.n_beta_coeff = 1
+        self.beta_var_npara = 1
+        self.device = int(device)
+        self._lib = _lib.load()
+        self._ctx = None
+        self._ctx_shape = None
+        self.KernEta_chofac = None
+        self.invKernEta_fdiff = None
+
+    def __del__(self):
+        try:
+            if getattr(self, '_ctx', None):
+                self._lib.gpg_destroy(self._ctx)
+                self._ctx = None
+        except Exception:
+            pass
+
+    # ---- small host pieces ---------------------------------------------------------------------------
+    def set_wellcond_mtd(self, wellcond_mtd):
+        # reference GaussianProcess.py:192-217
+        assert wellcond_mtd in self.wellcond_mtd_avail, \
+            f'Requested method not available, wellcond_mtd : {wellcond_mtd}'
+        if not self.use_grad:
+            wellcond_mtd = 'base'
+        if wellcond_mtd not in ('base', 'precon'):
+            raise NotImplementedError(f"wellcond_mtd '{wellcond_mtd}' (data rescaling) is outside the accelerated path")
+        self.wellcond_mtd = wellcond_mtd
+        self.b_use_cond_cstr = wellcond_mtd != 'precon'
+        self.b_use_data_scl = False
+
+    def theta2gamma(self, theta):
+        # KernelSqExp.py:580-583 / KernelMatern5f2.py:654-657
+        return np.sqrt(2 * theta) if self.kernel_type == 'SqExp' else np.sqrt((5.0 / 3.0) * theta)
+
+    def gamma2theta(self, gamma):
+        return 0.5 * gamma ** 2 if self.kernel_type == 'SqExp' else (3.0 / 5.0) * gamma ** 2
+
+    def calc_nugget_Kbase(self, n_eval, cond_max=None):
+        # GpWellCond.py:109-114
+        if cond_max is None:
+            cond_max = self.cond_max_target
+        return n_eval / (cond_max - 1)
+
+    def calc_nugget(self, n_eval):
+        # GpWellCond.py:116-154
+        if self.cond_eta_set_mtd == 'dflt_eta':
+            return self.cond_eta_dflt, self.cond_eta_dflt
+        eta_Kbase = self.calc_nugget_Kbase(n_eval)
+        if not self.use_grad:
+            return eta_Kbase, np.nan
+        if n_eval == 1:
+            return eta_Kbase, eta_Kbase
+        if self.wellcond_mtd == 'precon':
+            dim = self.dim
+            if self.kernel_type == 'SqExp':
+                ub = 0.5 * (n_eval - 1) * (1 + np.sqrt(1 + 4 * dim)) * np.exp(-(1 + 2 * dim - np.sqrt(1 + 4 * dim)) / (4 * dim))
+            else:
+                al = (np.sqrt(3 * dim) - 1 + np.sqrt(15 * dim + 2 * np.sqrt(3 * dim) + 1)) / (2 * (3 * dim + np.sqrt(3 * dim)))
+                ub = (n_eval - 1) * (1 + (dim + np.sqrt(3 * dim)) * al + dim * (1 + np.sqrt(3 * dim)) * al ** 2) \
+                    * np.exp(-np.sqrt(3 * dim) * al)
+            return eta_Kbase, (1 + ub) / (self.cond_max_target - 1)
+        if self.cond_eta_set_mtd == 'Kbase_eta':
+            return eta_Kbase, eta_Kbase
+        if self.cond_eta_set_mtd == 'Kbase_eta_w_dim':
+            return eta_Kbase, eta_Kbase * (self.dim + 1)
+        raise Exception(f'Uknown method for cond_eta_set_mtd = {self.cond_eta_set_mtd}')
+
+    @staticmethod
+    def make_data_vec(fval, fgrad=None):
+        # CommonFun.py:151-173
+        if fgrad is None:
+            return np.atleast_1d(fval)
+        return np.hstack((fval, fgrad.reshape(fgrad.size, order='f')))
+
+    def make_hp_class(self, beta=None, theta=None, kernel=None, varK=None, var_fval=None, var_fgrad=None):
+        return HparaOptzVal(beta, theta, kernel, varK, var_fval, var_fgrad)     # GpHpara.py:28-31
+
+    def set_custom_hp(self, beta=None, theta=None, kernel=None, varK=None, var_fval=None, var_fgrad=None):
+        if varK is not None:
+            assert varK > 0, f'varK must be positive but it is {varK}'            # GpHpara.py:105-116
+        self.hp_vals = self.make_hp_class(beta, theta, kernel, varK, var_fval, var_fgrad)
+
+    def set_hp_optz_info(self, has_theta, has_kernel=False, has_varK=False, has_var_fval=False, has_var_fgrad=False):
+        # GpHparaOptz.py:44-138
+        n_hp = has_theta * self.dim + has_kernel + has_varK + has_var_fval + has_var_fgrad
+        bvec = np.zeros(n_hp, dtype=bool)
+        cnt = 0
+        empty = np.array([], dtype=int)
+        idx_theta = idx_kernel = idx_varK = idx_var_fval = idx_var_fgrad = empty
+        if has_theta:
+            idx_theta = np.arange(cnt, cnt + self.dim, dtype=int)
+            cnt += self.dim
+            if self.optz_log_hp_theta:
+                bvec[idx_theta] = 1
+        if has_kernel:
+            assert self.kernel_has_hp, 'Kernel must have hyperaparamters if b_optz_hp_kernel is set to True'
+        if has_varK:
+            idx_varK = cnt
+            cnt += 1
+            if self.optz_log_hp_var:
+                bvec[idx_varK] = 1
+        if has_var_fval:
+            assert self.known_eps_fval is False, 'var_fval should not be a hyperparameter if known_eps_fval is True'
+            idx_var_fval = cnt
+            cnt += 1
+            if self.optz_log_hp_var:
+                bvec[idx_var_fval] = 1
+        if has_var_fgrad:
+            assert self.known_eps_fgrad is False, 'var_fgrad should not be a hyperparameter if known_eps_fgrad is True'
+            idx_var_fgrad = cnt
+            cnt += 1
+            if self.optz_log_hp_var:
+                bvec[idx_var_fgrad] = 1
+        return HparaOptzInfo(n_hp=n_hp, has_theta=has_theta, idx_theta=idx_theta, has_kernel=has_kernel,
+                             idx_kernel=idx_kernel, has_varK=has_varK, idx_varK=idx_varK,
+                             has_var_fval=has_var_fval, idx_var_fval=idx_var_fval, has_var_fgrad=has_var_fgrad,
+                             idx_var_fgrad=idx_var_fgrad, bvec_log_optz=bvec)
+
+    def setup_hp_idx4optz(self):
+        # GpHparaOptz.py:187-196
+        self.hp_info_optz_lkd = self.set_hp_optz_info(True, self.b_optz_hp_kernel and self.kernel_has_hp,
+                                                      self.b_has_noisy_data, self.b_optz_var_fval,
+                                                      self.b_optz_var_fgrad)
+
+    def hp_vec2dataclass(self, hp_optz_info, hp_vec):
+        # GpHpara.py:56-103
+        v = np.copy(hp_vec)
+        b = hp_optz_info.bvec_log_optz
+        v[b] = 10 ** (v[b])
+        theta = v[hp_optz_info.idx_theta] if hp_optz_info.has_theta else None
+        varK = var_fval = var_fgrad = None
+        if hp_optz_info.has_varK:
+            assert self.b_has_noisy_data
+            varK = v[hp_optz_info.idx_varK]
+        if hp_optz_info.has_var_fval:
+            assert self.b_optz_var_fval
+            var_fval = v[hp_optz_info.idx_var_fval]
+        if hp_optz_info.has_var_fgrad:
+            assert self.b_optz_var_fgrad
+            var_fgrad = v[hp_optz_info.idx_var_fgrad]
+        return self.make_hp_class(None, theta, None, varK, var_fval, var_fgrad)
+
+    # ---- data ingest ---------------------------------------------------------------------------------
+    def set_data(self, x_eval, fval, std_fval, grad=None, std_grad=None, bvec_use_grad=None):
+        # reference GaussianProcess.py:219-363
+        n_eval = fval.size
+        if self.use_grad:
+            if bvec_use_grad is not None:
+                assert bvec_use_grad.size == n_eval, \
+                    f'Length of bvec_use_grad is {bvec_use_grad.size} but it should be n_eval = {n_eval}'
+                if not np.all(bvec_use_grad):
+                    raise NotImplementedError('partial gradients (bvec_use_grad mask) are outside the accelerated path')
+                bvec_use_grad = None
+            n_grad = n_eval
+        else:
+            assert bvec_use_grad is None, 'bvec_use_grad must be None if grads are not used for the GP'
+            n_grad = 0
+        self.n_eval, self.n_grad = n_eval, n_grad
+        self.n_data = n_eval + n_grad * self.dim
+        fval = np.atleast_1d(fval).ravel()
+        assert x_eval.ndim == 2, f'x_eval must be a 2 array but x_eval.ndim = {x_eval.ndim}'
+        assert n_eval == fval.size, 'No. of points do not match with x_eval and fval'
+        assert x_eval.shape == (n_eval, self.dim), 'Shape of x_eval does not match (n_eval, dim)'
+        if (std_fval is None) or np.any(np.isnan(std_fval)):
+            self.known_eps_fval = False
+        else:
+            self.known_eps_fval = True
+            std_fval = np.atleast_1d(std_fval).ravel()
+            assert n_eval == std_fval.size, f'Size of std_fval is {std_fval.size} while it should be {n_eval}'
+        if grad is None:
+            assert self.use_grad is False, 'No grad info provided but use_grad was set to True'
+            self.has_grad_info = False
+            self.known_eps_fgrad = False
+        else:
+            assert self.use_grad, 'Grad info provided but use_grad was set to False'
+            self.has_grad_info = True
+            assert grad.ndim == 2, f'grad must be a 2 array but grad.ndim = {grad.ndim}'
+            assert grad.shape == (n_grad, self.dim), 'Shape of grad does not match x_eval'
+            if (std_grad is None) or np.any(np.isnan(std_grad)):
+                self.known_eps_fgrad = False
+            else:
+                self.known_eps_fgrad = True
+                assert std_grad.ndim == 2, f'std_grad must be a 2 array but std_grad.ndim = {std_grad.ndim}'
+                assert grad.shape == std_grad.shape, 'Shape of grad does not match std_grad'
+        self._x_eval_in = x_eval
+        self._fval_in = fval
+        self._std_fval_in = std_fval if self.known_eps_fval else None
+        self._grad_in = grad
+        self._std_grad_in = std_grad if self.known_eps_fgrad else None
+        self.bvec_use_grad = None
+        if self.known_eps_fval:
+            self.b_optz_var_fval = False
+            self.b_fval_zero = bool(np.max(std_fval) < 1e-10)
+        else:
+            self.b_optz_var_fval = True
+            self.b_fval_zero = False
+        if self.use_grad is False:
+            self.b_optz_var_fgrad = False
+            self.b_fgrad_zero = True
+        elif self.known_eps_fgrad:
+            self.b_optz_var_fgrad = False
+            self.b_fgrad_zero = bool(np.max(std_grad) < 1e-10)
+        else:
+            self.b_optz_var_fgrad = True
+            self.b_fgrad_zero = False
+        self.b_has_noisy_data = not (self.b_fval_zero and self.b_fgrad_zero)
+        self._eta_Kbase, self._eta_Kgrad = self.calc_nugget(self.n_eval)
+        self._etaK = self._eta_Kgrad if self.use_grad else self._eta_Kbase
+        self.setup_hp_idx4optz()
+        self.Rtensor_init = None        # the [d, n, n] tensor (GaussianProcess.py:363) is never materialised
+        self.KernEta_chofac = None
+        self.invKernEta_fdiff = None
+        self._eval_ready = False
+        self._push_data()
+
+    def _err(self):
+        return self._lib.gpg_last_error(self._ctx).decode()
+
+    def _push_data(self):
+        shape = (self.n_eval, self.dim, bool(self.use_grad), self.kernel_type)
+        if self._ctx is None or self._ctx_shape != shape:
+            if self._ctx is not None:
+                self._lib.gpg_destroy(self._ctx)
+                self._ctx = None
+            ctx = C.c_void_p()
+            rc = self._lib.gpg_create(C.byref(ctx), self.device, self.n_eval, self.dim, int(self.use_grad),
+                                      _lib.GPG_KERNEL[self.kernel_type])
+            if rc != 0:
+                raise _lib.GpgError(f'gpg_create failed ({rc}): {self._lib.gpg_last_error(None).decode()}')
+            self._ctx, self._ctx_shape = ctx, shape
+        x = np.ascontiguousarray(self._x_eval_in, dtype=np.float64)
+        y = np.ascontiguousarray(self.make_data_vec(self._fval_in, self._grad_in if self.use_grad else None),
+                                 dtype=np.float64)
+        noise = np.zeros(self.n_data)
+        if self.b_has_noisy_data:                                                 # Kernel.py:324-353
+            if self.known_eps_fval:
+                noise[:self.n_eval] = self._std_fval_in ** 2
+            if self.use_grad and self.known_eps_fgrad:
+                noise[self.n_eval:] = (self._std_grad_in ** 2).reshape(self._std_grad_in.size, order='f')
+        self._noise_known = noise
+        rc = self._lib.gpg_set_data(self._ctx, _lib.as_dp(x), _lib.as_dp(y), _lib.as_dp(noise))
+        if rc != 0:
+            raise _lib.GpgError(f'gpg_set_data failed ({rc}): {self._err()}')
+        self._data_vec = y
+
+    def get_scl_x_w_dist(self):
+        return self._x_eval_in, self.Rtensor_init                                # GaussianProcess.py:399-404
+
+    def get_scl_eval_data(self):
+        return self._fval_in, self._std_fval_in, self._grad_in, self._std_grad_in   # GaussianProcess.py:423-433
+
+    def calc_noise_vec(self, hp_vals):
+        # Kernel.py:309-357 (host copy; the device builds the same vector from var_fval / var_fgrad)
+        if self.b_fval_zero and self.b_fgrad_zero:
+            return np.zeros(self.n_data)
+        out = np.zeros(self.n_data)
+        if self.known_eps_fval:
+            assert hp_vals.var_fval is None
+            out[:self.n_eval] = self._std_fval_in ** 2
+        else:
+            out[:self.n_eval] = hp_vals.var_fval
+        if self.use_grad:
+            if self.known_eps_fgrad:
+                assert hp_vals.var_fgrad is None
+                out[self.n_eval:] = (self._std_grad_in ** 2).reshape(self._std_grad_in.size, order='f')
+            else:
+                out[self.n_eval:] = hp_vals.var_fgrad
+        return out
+
+    # ---- C-ABI argument packing ------------------------------------------------------------------------
+    def _make_hp(self, hp_vals, varK_mat, closed_form):
+        theta = np.ascontiguousarray(hp_vals.theta, dtype=np.float64)
+        assert theta.size == self.dim, 'theta must have dim entries'
+        assert np.sum(np.isnan(theta)) == 0, f'There are nan values theta = {theta}'     # Kernel.py:201
+        hp = _lib.GpgHp()
+        hp.theta = _lib.as_dp(theta)
+        hp.varK_mat = float(varK_mat)
+        hp.var_fval = -1.0 if (self.known_eps_fval or not self.b_has_noisy_data) else float(hp_vals.var_fval)
+        if not self.use_grad:
+            hp.var_fgrad = -1.0
+        else:
+            hp.var_fgrad = -1.0 if (self.known_eps_fgrad or not self.b_has_noisy_data) else float(hp_vals.var_fgrad)
+        hp.eta = float(self._etaK)
+        hp.wellcond = _lib.GPG_WELLCOND[self.wellcond_mtd]
+        hp.closed_form_varK = int(closed_form)
+        if not self.cond_eta_is_const:
+            raise NotImplementedError('cond_eta_is_const=False (row-sum nugget) is outside the accelerated path')
+        return hp, theta   # keep theta alive
+
+    # ---- kernel + factorisation (compat entry points; the hot path does not materialise N x N arrays) ----
+    def calc_Kern_w_chofac(self, Rtensor, hp_vals, noise_vec=None, calc_chofac=True, calc_cond=False,
+                           materialize=False):
+        # Kernel.py:128-138
+        assert self.b_has_noisy_data is False, 'This function should not be called if there is noisy data'
+        return self.calc_all_K_w_chofac(Rtensor, hp_vals, noise_vec, calc_chofac, calc_cond, varK=1,
+                                        materialize=materialize)
+
+    def calc_all_K_w_chofac(self, Rtensor, hp_vals, noise_vec=None, calc_chofac=True, calc_cond=False,
+                            varK=None, b_normlz_w_varK=False, materialize=False):
+        """Kernel.py:140-307.  Returns the reference's 7-tuple (Kern, Kcor, Kcov, Kcov_chofac, condK, etaK,
+        idx_etaK_argmax).  Kcov_chofac is the SciPy-compatible (P L, True) pair downloaded from the device
+        (lower factor for both well-conditioning methods).  Kern / Kcov are downloaded only when
+        materialize=True; Kcor is never formed (None)."""
+        if noise_vec is not None:
+            raise NotImplementedError('a caller-supplied noise_vec is outside the accelerated path')
+        if calc_cond:
+            raise NotImplementedError('calc_cond=True (dense condition number) is outside the accelerated path')
+        if varK is None:
+            assert hp_vals.varK is not None, f'varK is not provided and hp_vals.varK is None, hp_vals = {hp_vals}'
+            varK = hp_vals.varK
+        if b_normlz_w_varK:
+            varK = 1.0
+        else:
+            assert varK > 0, f'varK must be positive but varK = {varK}'
+        hp, keep = self._make_hp(hp_vals, varK, closed_form=not self.b_has_noisy_data)
+        N = self.n_data
+        Kern = Kcov = None
+        if materialize:
+            Kern = np.empty((N, N))
+            Kcov = np.empty((N, N))
+            for which, out in ((0, Kern), (1, Kcov)):
+                rc = self._lib.gpg_get_matrix(self._ctx, C.byref(hp), which, _lib.as_dp(out))
+                if rc != 0:
+                    raise _lib.GpgError(f'gpg_get_matrix failed ({rc}): {self._err()}')
+        chofac = None
+        t0 = time.time()
+        if calc_chofac:
+            out = _lib.GpgLkdOut()
+            rc = self._lib.gpg_lkd(self._ctx, C.byref(hp), C.byref(out))
+            if rc < 0:
+                raise _lib.GpgError(f'gpg_lkd failed ({rc}): {self._err()}')
+            if rc == 0:
+                fac = np.empty((N, N))
+                rc2 = self._lib.gpg_get_matrix(self._ctx, None, 3, _lib.as_dp(fac))
+                if rc2 != 0:
+                    raise _lib.GpgError(f'gpg_get_matrix failed ({rc2}): {self._err()}')
+                chofac = (fac, True)
+            else:
+                print(f'Failure of the Cholesky decomposition, first non-positive pivot = {rc}')   # Kernel.py:255
+        self._time_chofac += time.time() - t0
+        self._eval_ready = False
+        return Kern, None, Kcov, chofac, None, self._etaK, None
+
+    # ---- likelihood ------------------------------------------------------------------------------------
+    def calc_lkd_all(self, hp_vals, calc_lkd=True, calc_cond=False, calc_grad=False, lkd_use_adj_mtd=None):
+        """One marginal-log-likelihood evaluation -- reference CalcLkd.py:270-346 (value path)."""
+        if calc_grad:
+            raise NotImplementedError('calc_grad=True (likelihood gradient) is not on the accelerated path yet (SURVEY.md 8f1)')
+        if calc_cond:
+            raise NotImplementedError('calc_cond=True is outside the accelerated path (SURVEY.md 8f4)')
+        if self.lkd_varK_pnlt_use:
+            raise NotImplementedError('lkd_varK_pnlt_use=True is outside the accelerated path')
+        noisy = self.b_has_noisy_data
+        if noisy:
+            assert hp_vals.varK is not None, f'varK is not provided and hp_vals.varK is None, hp_vals = {hp_vals}'
+            varK_mat = hp_vals.varK
+            assert varK_mat > 0, f'varK must be positive but varK = {varK_mat}'
+        else:
+            varK_mat = 1.0                                                           # Kernel.py:137-138
+        hp, keep = self._make_hp(hp_vals, varK_mat, closed_form=not noisy)
+        out = _lib.GpgLkdOut()
+        t0 = time.time()
+        rc = self._lib.gpg_lkd(self._ctx, C.byref(hp), C.byref(out))
+        self._time_chofac += time.time() - t0
+        self._eval_ready = False
+        if rc < 0:
+            raise _lib.GpgError(f'gpg_lkd failed ({rc}): {self._err()}')
+        if rc > 0:
+            # CalcLkd.py:308-311 / 330-333: the reference reports the SVD condition number here; not computed
+            return LkdInfo(cond=np.nan), False
+        info = LkdInfo(hp_beta=np.array([out.beta]), hp_varK=None if noisy else out.varK,
+                       ln_det_Kmat=out.ln_det if calc_lkd or not noisy else None,
+                       ln_lkd=out.ln_lkd if calc_lkd else None,
+                       data_vec=self._data_vec if noisy else None, cond=None)
+        return info, True
+
+    def _rows_from_hp_x0(self, hp_x0):
+        """Decode optimiser rows (GpHpara.py:56-103) into the C ABI's [theta(d), varK_mat, var_fval, var_fgrad]."""
+        info = self.hp_info_optz_lkd
+        hp_x0 = np.atleast_2d(np.asarray(hp_x0, dtype=np.float64))
+        assert hp_x0.shape[1] == info.n_hp, f'hp rows must have n_hp = {info.n_hp} entries'
+        v = hp_x0.copy()
+        v[:, info.bvec_log_optz] = 10.0 ** v[:, info.bvec_log_optz]
+        m, d = v.shape[0], self.dim
+        rows = np.empty((m, d + 3))
+        rows[:, :d] = v[:, info.idx_theta]
+        rows[:, d] = v[:, info.idx_varK] if info.has_varK else 1.0
+        rows[:, d + 1] = v[:, info.idx_var_fval] if info.has_var_fval else -1.0
+        rows[:, d + 2] = v[:, info.idx_var_fgrad] if info.has_var_fgrad else -1.0
+        return rows
+
+    def calc_lkd_batch(self, hp_x0, return_all=False):
+        """ln_lkd of every restart row on this device, queued back-to-back -- the loop body of
+        GpHparaX0.py:39-45.  Failed factorisations give NaN (GpHparaX0.py:34,43-45)."""
+        rows = np.ascontiguousarray(self._rows_from_hp_x0(hp_x0))
+        m = rows.shape[0]
+        if not self.cond_eta_is_const:
+            raise NotImplementedError('cond_eta_is_const=False is outside the accelerated path')
+        outs = (_lib.GpgLkdOut * m)()
+        t0 = time.time()
+        rc = self._lib.gpg_lkd_batch(self._ctx, m, _lib.as_dp(rows), rows.shape[1], float(self._etaK),
+                                     _lib.GPG_WELLCOND[self.wellcond_mtd], int(not self.b_has_noisy_data), outs)
+        self._time_chofac += time.time() - t0
+        self._eval_ready = False
+        if rc != 0:
+            raise _lib.GpgError(f'gpg_lkd_batch failed ({rc}): {self._err()}')
+        ln = np.array([o.ln_lkd if o.info == 0 else np.nan for o in outs])
+        if return_all:
+            return ln, outs
+        return ln
+
+    def select_hp_best(self, hp_x0):
+        """hp_best selection of GpHparaX0.py:33-59 for explicit start rows: the row of highest ln_lkd."""
+        ln = self.calc_lkd_batch(hp_x0)
+        idx = int(np.nanargmax(ln))
+        return np.atleast_2d(hp_x0)[idx][None, :], ln, idx
+
+    def optz_closed_form_hp(self, hp_vals):
+        # GpHparaOptz.py:220-230
+        lkd_info, b_chofac_good = self.calc_lkd_all(hp_vals, calc_lkd=False, calc_cond=False, calc_grad=False)
+        hp_vals.beta = lkd_info.hp_beta
+        if self.b_has_noisy_data is False:
+            hp_vals.varK = lkd_info.hp_varK
+        return hp_vals
+
+    # ---- posterior -------------------------------------------------------------------------------------
+    def set_hpara(self, method2set_hp, i_optz, hp_vals=None, calc_cond=False):
+        # GaussianProcess.py:365-395
+        assert type(method2set_hp) is str, 'method2set_hp must be a string'
+        if method2set_hp in ('stored', 'optz'):
+            raise NotImplementedError(f"set_hpara('{method2set_hp}') drives the optimiser / history and is outside the accelerated path")
+        elif method2set_hp == 'current':
+            assert i_optz > 0
+            assert self.hp_vals is not None, 'Cannot use current hp_vals if they have not been set yet'
+        elif method2set_hp == 'set':
+            assert hp_vals is not None, 'If method2set_hp == "set", then the class hp_vals must be provided'
+            self.hp_vals = hp_vals
+        else:
+            raise Exception(f'Unknown method to set GP hp: method2set_hp = {method2set_hp}')
+        self.setup_eval_model(calc_cond=calc_cond)
+
+    def setup_eval_model(self, calc_cond=False):
+        """GpEvalModel.py:17-57: factor kept on the device, alpha = K^-1 (y - V beta) returned to the host."""
+        if calc_cond:
+            raise NotImplementedError('calc_cond=True is outside the accelerated path')
+        self._hp_vals_model_setup = copy.copy(self.hp_vals)
+        hp, keep = self._make_hp(self.hp_vals, 1.0, closed_form=not self.b_has_noisy_data)   # b_normlz_w_varK=True
+        beta = float(np.ravel(self.hp_vals.beta)[0])
+        alpha = np.empty(self.n_data)
+        t0 = time.time()
+        rc = self._lib.gpg_setup_eval(self._ctx, C.byref(hp), beta, _lib.as_dp(alpha))
+        self._time_chofac += time.time() - t0
+        if rc < 0:
+            raise _lib.GpgError(f'gpg_setup_eval failed ({rc}): {self._err()}')
+        self.data_vec = self._data_vec
+        self.Kern = self.KernEta = None
+        self.condK = None
+        self.etaK_eval = self._etaK
+        if rc > 0:
+            self.KernEta_chofac = None
+            self.invKernEta_fdiff = None
+            self._eval_ready = False
+        else:
+            self.KernEta_chofac = 'device'      # the factor lives in HBM; gpg_get_matrix(which=3) downloads it
+            self.invKernEta_fdiff = alpha
+            self._eval_ready = True
+
+    def eval_model(self, x2model_in, calc_grad=False, calc_hess=False, squeeze_nx=False):
+        """GpEvalModel.py:59-198 for calc_grad=False: returns (mu, sig, None, None, None, None)."""
+        assert self.KernEta_chofac is not None, 'To evaluate the surr the Cholesky decomposition is required'
+        if calc_grad or calc_hess:
+            raise NotImplementedError('posterior derivatives are not on the accelerated path yet (SURVEY.md 8f3)')
+        if x2model_in.ndim == 1:
+            x2model = x2model_in[None, :]
+        elif x2model_in.ndim == 2:
+            x2model = x2model_in
+        else:
+            raise Exception(f'x2model_in should be a 2d array but it has shape {x2model_in.shape}')
+        nx = x2model.shape[0]
+        if squeeze_nx:
+            assert nx == 1, 'If squeeze_nx is True, then x_acq must only have one point'
+        if (self.hp_vals == self._hp_vals_model_setup) is False:
+            raise Exception('Cannot change hp_vals between calling setup_eval_model() and eval_model()')
+        if not self._eval_ready:
+            raise Exception('setup_eval_model() must be called again: the device factor was overwritten by a likelihood evaluation')
+        xq = np.ascontiguousarray(x2model, dtype=np.float64)
+        mu, sig, s2 = np.empty(nx), np.empty(nx), np.empty(nx)
+        rc = self._lib.gpg_predict(self._ctx, nx, _lib.as_dp(xq), float(self.hp_vals.varK), _lib.as_dp(mu),
+                                   _lib.as_dp(sig), _lib.as_dp(s2))
+        if rc != 0:
+            raise _lib.GpgError(f'gpg_predict failed ({rc}): {self._err()}')
+        assert np.min(s2) >= 0, \
+            f'The variance of the surr should be non-negative but min(sig2_wo_sigK) = {np.min(s2)}'   # GpEvalModel.py:163
+        if squeeze_nx:
+            return mu[0], sig[0], None, None, None, None
+        return mu, sig, None, None, None, None
+
+    # ---- instrumentation -------------------------------------------------------------------------------
+    def prof_enable(self, cats):
+        mask = 0
+        for c in cats:
+            mask |= 1 << _lib.PROF_CATS.index(c)
+        self._lib.gpg_prof_enable(self._ctx, mask)
+
+    def prof_read(self):
+        ms = (C.c_double * _lib.PROF_NCAT)()
+        cnt = (C.c_longlong * _lib.PROF_NCAT)()
+        work = (C.c_double * _lib.PROF_NCAT)()
+        rc = self._lib.gpg_prof_read(self._ctx, ms, cnt, work)
+        if rc != 0:
+            raise _lib.GpgError(f'gpg_prof_read failed ({rc}): {self._err()}')
+        return {c: dict(ms=ms[i], count=cnt[i], work=work[i]) for i, c in enumerate(_lib.PROF_CATS)}
+
+    def set_panel(self, nb_outer):
+        rc = self._lib.gpg_set_panel(self._ctx, int(nb_outer))
+        if rc != 0:
+            raise _lib.GpgError(f'gpg_set_panel failed ({rc}): {self._err()}')
+
+    def download_chofac(self):
+        """(P L, True) of the factor currently on the device (Kernel.py:252) as a SciPy cho_factor pair."""
+        fac = np.empty((self.n_data, self.n_data))
+        rc = self._lib.gpg_get_matrix(self._ctx, None, 3, _lib.as_dp(fac))
+        if rc != 0:
+            raise _lib.GpgError(f'gpg_get_matrix failed ({rc}): {self._err()}')
+        return fac, True

@@ -1,0 +1,143 @@
+/* gpgrad.h -- C ABI of the MI355X-native gradient-enhanced GP likelihood hot path.
+ *
+ * This is the drop-in boundary: every entry point replaces one step of the reference
+ * (marchildon/gpgradpy @ v2; citations are file:line in that tree).  Plain pointers and sizes only;
+ * the caller owns every host buffer, the library owns every device allocation.
+ *
+ * Return convention (all int-returning functions):
+ *    0   success
+ *   >0   LAPACK-style info: 1-based index of the first non-positive pivot met by the Cholesky
+ *        factorisation -> the caller treats it like the `except` branch of Kernel.py:253-264
+ *        (Kcov_chofac = None, b_chofac_good = False)
+ *   <0   argument / HIP runtime error; text via gpg_last_error()
+ *
+ * Threading: one context = one device + one HIP stream, not re-entrant (the reference object is not
+ * thread-safe either: memoised `_last_hp_vec`, mutable `_time_chofac`).
+ *
+ * Matrix layout: derivative-major blocks (KernelSqExp.py:381-408, CommonFun.py:151-173): row
+ * r = blk * n + a, blk 0 = function value, blk i+1 = d/dx_i at point a.  Device storage is
+ * column-major, lower triangle, padded to a multiple of 128.
+ */
+#ifndef GPGRAD_H
+#define GPGRAD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gpg_ctx gpg_ctx;
+
+enum { GPG_KERNEL_SQEXP = 0, GPG_KERNEL_MA5F2 = 1 };
+enum { GPG_WELLCOND_BASE = 0, GPG_WELLCOND_PRECON = 1 };
+
+/* Hyperparameters + regularisation of ONE evaluation.
+ * Mirrors HparaOptzVal (GpHpara.py:12-19) plus the scalars calc_all_K_w_chofac reads from the object
+ * (Kernel.py:186-236: theta, varK, noise, self._etaK, self.wellcond_mtd). */
+typedef struct {
+  const double* theta; /* [d] > 0                                                              */
+  double varK_mat;     /* varK the matrix is built with: 1 for noise-free data and for          */
+                       /* b_normlz_w_varK (Kernel.py:137-138,196-197), hp_vals.varK otherwise   */
+  double var_fval;     /* >= 0: noise variance of every function value (unknown-noise case,     */
+                       /*       Kernel.py:348); < 0: use the per-row vector given to set_data   */
+  double var_fgrad;    /* same for every gradient entry (Kernel.py:355)                         */
+  double eta;          /* nugget etaK (GpWellCond.py:116-154, Kernel.py:229-236)                */
+  int wellcond;        /* GPG_WELLCOND_PRECON (Kernel.py:220-266) or _BASE (Kernel.py:268-302)  */
+  int closed_form_varK;/* 1: noise-free path, varK = max(1e-32, r'K^-1 r / N) (CalcLkd.py:159); */
+                       /* 0: noisy path, ln_lkd = -(ln_det + r'K^-1 r)/2 (CalcLkd.py:226)       */
+} gpg_hp;
+
+/* Result of one likelihood evaluation = the scalar fields of LkdInfo (CalcLkd.py:14-26). */
+typedef struct {
+  double ln_lkd;  /* marginal log-likelihood, without the N ln(2 pi) constant (CalcLkd.py:168,226) */
+  double ln_det;  /* 2 sum log diag(P L)                               (CalcLkd.py:165,225)       */
+  double beta;    /* GLS constant mean                                  (GpMeanFun.py:103-107)     */
+  double varK;    /* closed-form varK, or varK_mat on the noisy path    (CalcLkd.py:159)           */
+  double rKr;     /* r' Kcov^-1 r with r = y - V beta                   (CalcLkd.py:154,221)       */
+  int info;       /* 0, or first non-positive pivot (1-based)                                      */
+  int pad_;
+} gpg_lkd_out;
+
+/* Lifetime --------------------------------------------------------------------------------------- */
+
+/* Replaces GaussianProcess.__init__ + the shape part of set_data (GaussianProcess.py:138-190,
+ * 244-262).  n_eval points of dimension dim; use_grad != 0 -> N = n_eval * (dim + 1) rows.
+ * Allocates the (N_pad + 128) x N_pad fp64 workspace once.  dim <= 16. */
+int gpg_create(gpg_ctx** out, int device, int n_eval, int dim, int use_grad, int kernel);
+void gpg_destroy(gpg_ctx* ctx);
+const char* gpg_last_error(const gpg_ctx* ctx); /* ctx may be NULL: error of the last failed create */
+
+/* Replaces the data ingest of set_data (GaussianProcess.py:296-302,363) and make_data_vec
+ * (CommonFun.py:151-173).  x [n_eval, dim] row-major; data_vec [N] = [f, d1 f(all pts), ...];
+ * noise_var [N] = known noise variances in the same ordering (Kernel.py:343-353) or NULL (zeros).
+ * The [d, n, n] Rtensor of the reference is never materialised. */
+int gpg_set_data(gpg_ctx* ctx, const double* x, const double* data_vec, const double* noise_var);
+
+/* Likelihood ------------------------------------------------------------------------------------- */
+
+/* Replaces CalcLkd.calc_lkd_all(hp, calc_lkd=True, calc_cond=False, calc_grad=False)
+ * (CalcLkd.py:270-346): assembly + noise + preconditioner + nugget (Kernel.py:213-237), Cholesky
+ * (Kernel.py:251), GLS mean (GpMeanFun.py:69-122), alpha-free evaluation of r'K^-1 r and ln det
+ * (CalcLkd.py:149-181 / 185-251).  Returns out->info as well. */
+int gpg_lkd(gpg_ctx* ctx, const gpg_hp* hp, gpg_lkd_out* out);
+
+/* Replaces the serial restart loop of GpHparaX0.select_hp_optz_x0 (GpHparaX0.py:33-59) on ONE
+ * device: m hyperparameter rows, hp_rows [m, row_len] with row = [theta(d), varK_mat, var_fval,
+ * var_fgrad] already decoded from log10 (GpHpara.py:56-103); eta / wellcond / closed_form_varK are
+ * shared.  out [m].  Rows whose factorisation fails get info > 0 and NaN ln_lkd (GpHparaX0.py:34,
+ * 43-45).  Returns 0 unless an argument / runtime error occurred.  All m evaluations are queued on
+ * the stream back-to-back and synchronised once. */
+int gpg_lkd_batch(gpg_ctx* ctx, int m, const double* hp_rows, int row_len, double eta, int wellcond,
+                  int closed_form_varK, gpg_lkd_out* out);
+
+/* Posterior -------------------------------------------------------------------------------------- */
+
+/* Replaces GpEvalModel.setup_eval_model (GpEvalModel.py:17-57): factorises the matrix for hp (the
+ * caller passes varK_mat = 1, noise undivided: the b_normlz_w_varK quirk of Kernel.py:196-197,218)
+ * and keeps the factor plus alpha = Kcov^-1 (y - V beta) on the device.  alpha_out [N] may be NULL. */
+int gpg_setup_eval(gpg_ctx* ctx, const gpg_hp* hp, double beta, double* alpha_out);
+
+/* Replaces GpEvalModel.eval_model(x, calc_grad=False) (GpEvalModel.py:59-198): cross-kernel
+ * (GpEvalModel.py:133-139), K^-1 Kyx (GpEvalModel.py:154), mu = beta + Kyx' alpha (:168),
+ * sig = sqrt(max(0, 1 - diag(Kxy K^-1 Kyx))) * sqrt(varK) (:162-166).  xq [nx, dim] row-major.
+ * sig2_raw [nx] (may be NULL) receives the unclipped 1 - diag(...) that the reference asserts to be
+ * non-negative (GpEvalModel.py:163). */
+int gpg_predict(gpg_ctx* ctx, int nx, const double* xq, double varK, double* mu, double* sig,
+                double* sig2_raw);
+
+/* Materialisation on request (the 7-tuple of Kernel.py:307 carries N x N arrays; the fast path never
+ * copies them).  out is [N, N] column-major == row-major (symmetric) for which = 0..2:
+ *   0 Kern (Kernel.py:213-216), 1 Kcov (Kernel.py:237 / 277), 2 the matrix that is factorised
+ *   (Kcov_precon, Kernel.py:236; equals Kcov for wellcond = base);
+ *   3 the Cholesky factor kept by the last gpg_setup_eval / gpg_lkd call, as the lower-triangular
+ *     P L of Kernel.py:252 (row-major [N, N], zeros above the diagonal) usable with
+ *     scipy.linalg.cho_solve((out, True), b). */
+int gpg_get_matrix(gpg_ctx* ctx, const gpg_hp* hp, int which, double* out);
+
+/* Instrumentation (replaces the wall-clock accumulator _time_chofac, Kernel.py:247,304-305) ------- */
+
+enum {
+  GPG_PROF_ASSEMBLY = 0,   /* fused kernel build: algorithmic bytes 8 N (N+1) / 2                   */
+  GPG_PROF_POTRF = 1,      /* diagonal-block factorisations                                         */
+  GPG_PROF_TRSM = 2,       /* panel triangular solves                                               */
+  GPG_PROF_GEMM_PANEL = 3, /* updates inside a panel                                                */
+  GPG_PROF_GEMM_TRAIL = 4, /* trailing syrk/gemm update on fp64 MFMA: algorithmic flops             */
+  GPG_PROF_REDUCE = 5,     /* log-det / GLS reductions                                              */
+  GPG_PROF_NCAT = 6
+};
+/* mask: bit c enables HIP-event timing of category c launches on the context's stream. */
+int gpg_prof_enable(gpg_ctx* ctx, unsigned mask);
+/* Synchronises, then returns per category: ms[c] summed event time, count[c] launches,
+ * work[c] algorithmic units (bytes for ASSEMBLY, flops otherwise) since the last call; resets. */
+int gpg_prof_read(gpg_ctx* ctx, double ms[GPG_PROF_NCAT], long long count[GPG_PROF_NCAT],
+                  double work[GPG_PROF_NCAT]);
+
+/* Tuning knobs (defaults are the measured best): outer panel width (multiple of 128 in [128, 1024]). */
+int gpg_set_panel(gpg_ctx* ctx, int nb_outer);
+
+/* Library / device facts for logs: writes "gfx950 MI355X ..." style text. */
+int gpg_device_info(int device, char* buf, int buflen);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPGRAD_H */

@@ -1,0 +1,123 @@
+"""CPU: the C-ABI library loads and exports every symbol include/gpgrad.h declares (no compute calls),
+the host-side logic mirrors the reference's bookkeeping, and the product fails loudly without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR, ROOT
+import gpgradpy_amd
+from gpgradpy_amd import _lib
+from gpgradpy_amd.multistart import shard_rows
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "gpgrad.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(gpg_[a-z_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    syms = _header_symbols()
+    assert set(syms) == set(_lib.ABI_SYMBOLS)
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/gpgrad.h but not exported"
+
+
+def test_struct_layout_matches_header():
+    assert ctypes.sizeof(_lib.GpgLkdOut) == 5 * 8 + 2 * 4
+    assert ctypes.sizeof(_lib.GpgHp) == 8 + 4 * 8 + 2 * 4
+
+
+def _no_gpu():
+    import torch
+    return not torch.cuda.is_available()
+
+
+@pytest.mark.skipif(not _no_gpu(), reason="only meaningful on a machine without a GPU")
+def test_product_path_fails_loudly_without_gpu():
+    GP = gpgradpy_amd.GaussianProcess(2, True, 'SqExp', 'precon')
+    x = np.random.default_rng(0).uniform(-1, 1, (5, 2))
+    with pytest.raises(_lib.GpgError):
+        GP.set_data(x, x[:, 0], np.zeros(5), x, np.zeros((5, 2)))
+
+
+def _gp_host_only(dim, kernel, n, noise):
+    """Run set_data up to the device push (which raises on a CPU-only box) to inspect the host state."""
+    GP = gpgradpy_amd.GaussianProcess(dim, True, kernel, 'precon')
+    rng = np.random.default_rng(1)
+    x = rng.uniform(-1, 1, (n, dim))
+    f, g = x[:, 0] ** 2, rng.standard_normal((n, dim))
+    if noise == 'none':
+        sf, sg = np.zeros(n), np.zeros((n, dim))
+    elif noise == 'known':
+        sf, sg = np.full(n, 1e-2), np.full((n, dim), 1e-1)
+    else:
+        sf, sg = None, None
+    try:
+        GP.set_data(x, f, sf, g, sg)
+    except _lib.GpgError:
+        pass
+    return GP
+
+
+@pytest.mark.parametrize("noise,n_hp", [("none", 3), ("known", 4), ("unknown", 6)])
+def test_hp_index_map(noise, n_hp):
+    """SURVEY.md 8a15 probe (d=3, Ma5f2): n_hp = 3 / 4 / 6, all entries log10 by default."""
+    GP = _gp_host_only(3, 'Ma5f2', 6, noise)
+    info = GP.hp_info_optz_lkd
+    assert info.n_hp == n_hp and info.bvec_log_optz.all()
+    row = np.linspace(-2, -1, n_hp)
+    hp = GP.hp_vec2dataclass(info, row)
+    np.testing.assert_allclose(hp.theta, 10.0 ** row[:3])
+    rows = GP._rows_from_hp_x0(row[None, :])
+    np.testing.assert_allclose(rows[0, :3], 10.0 ** row[:3])
+    if noise == 'none':
+        assert hp.varK is None and rows[0, 3] == 1.0 and rows[0, 4] == -1.0 and rows[0, 5] == -1.0
+    elif noise == 'known':
+        assert np.isclose(hp.varK, 10.0 ** row[3]) and rows[0, 4] == -1.0
+    else:
+        assert np.isclose(hp.var_fval, 10.0 ** row[4]) and np.isclose(rows[0, 5], 10.0 ** row[5])
+
+
+def test_nugget_table_matches_reference():
+    rows = np.load(os.path.join(GOLDEN_DIR, "nugget_table.npz"))["rows"]
+    for k, n, d, eb, eg in rows:
+        GP = gpgradpy_amd.GaussianProcess(int(d), True, 'SqExp' if k == 0 else 'Ma5f2', 'precon')
+        b, g = GP.calc_nugget(int(n))
+        assert np.isclose(b, eb, rtol=1e-15) and np.isclose(g, eg, rtol=1e-14)
+
+
+def test_out_of_scope_features_raise():
+    with pytest.raises(NotImplementedError):
+        gpgradpy_amd.GaussianProcess(2, True, 'RatQu')
+    with pytest.raises(NotImplementedError):
+        gpgradpy_amd.GaussianProcess(2, True, 'SqExp', 'rescale_origin')
+    with pytest.raises(AssertionError):
+        gpgradpy_amd.GaussianProcess(2, True, 'SqExp', 'req_vmin')      # rejected like GaussianProcess.py:194
+    GP = _gp_host_only(2, 'SqExp', 4, 'none')
+    hp = GP.make_hp_class(theta=np.array([0.5, 0.5]))
+    with pytest.raises(NotImplementedError):
+        GP.calc_lkd_all(hp, calc_grad=True)
+    with pytest.raises(NotImplementedError):
+        GP.calc_lkd_all(hp, calc_cond=True)
+
+
+def test_data_vec_layout():
+    f = np.array([1.0, 2.0])
+    g = np.array([[3.0, 5.0], [4.0, 6.0]])
+    np.testing.assert_array_equal(gpgradpy_amd.GaussianProcess.make_data_vec(f, g), [1, 2, 3, 4, 5, 6])
+
+
+def test_shard_rows_partition():
+    for m in (1, 7, 64, 65):
+        for w in (1, 2, 3, 8):
+            spans = [shard_rows(m, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == m
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert shard_rows(64, 8, 3) == (24, 32)     # BASELINE cfg4: 8 rows per GPU in rank order

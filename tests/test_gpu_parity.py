@@ -1,0 +1,238 @@
+"""GPU (MI355X): the HIP path, called through the C ABI, against (1) the golden vectors captured from
+the reference, (2) the NumPy oracle on seeded inputs, (3) size-independent properties at BASELINE sizes."""
+import os
+
+import numpy as np
+import pytest
+from scipy.linalg import cho_solve
+
+from conftest import GOLDEN_DIR, case_id, golden_case_paths, load_case
+import tolerances as tol
+
+pytestmark = pytest.mark.gpu
+
+CASES = golden_case_paths()
+
+
+def _gp_from_case(c):
+    import gpgradpy_amd
+    GP = gpgradpy_amd.GaussianProcess(c["d"], c["use_grad"], c["kernel"], c["wellcond"] if c["use_grad"] else "base")
+    if c["use_grad"]:
+        GP.set_data(c["x"], c["f"], c["std_f"], c["g"], c["std_g"])
+    else:
+        GP.set_data(c["x"], c["f"], c["std_f"])
+    if "chofail" in c["name"]:
+        GP._etaK = c["etaK"]
+        GP._eta_Kgrad = c["etaK"]
+    return GP
+
+
+def _hp_from_case(GP, c):
+    noisy = c["b_has_noisy_data"]
+    vf = None if np.isnan(c["var_fval"]) else c["var_fval"]
+    vg = None if np.isnan(c["var_fgrad"]) else c["var_fgrad"]
+    return GP.make_hp_class(theta=c["theta"], varK=c["varK_in"] if noisy else None, var_fval=vf, var_fgrad=vg)
+
+
+@pytest.mark.parametrize("path", CASES, ids=case_id)
+def test_golden_case(path):
+    c = load_case(path)
+    GP = _gp_from_case(c)
+    assert GP.n_data == c["n_data"]
+    assert np.isclose(GP._etaK, c["etaK"], rtol=1e-14)
+    assert GP.b_has_noisy_data == c["b_has_noisy_data"]
+    hp = _hp_from_case(GP, c)
+    info, ok = GP.calc_lkd_all(hp)
+    assert ok == c["b_chofac_good"]
+    if not ok:
+        assert info.ln_lkd is None
+        return
+    noisy = c["b_has_noisy_data"]
+    tol.check_scalars(info.hp_beta[0], info.hp_varK, info.ln_det_Kmat, info.ln_lkd, c, GP.n_data, noisy)
+
+    # assembled matrices and the factor (reference Kernel.py:213-252)
+    if "Kern" in c:
+        if noisy:
+            Kern, _, Kcov, chofac, _, etaK, _ = GP.calc_all_K_w_chofac(None, hp, materialize=True)
+        else:
+            Kern, _, Kcov, chofac, _, etaK, _ = GP.calc_Kern_w_chofac(None, hp, materialize=True)
+        np.testing.assert_allclose(Kern, c["Kern"], rtol=tol.KERN_RTOL, atol=tol.KERN_ATOL)
+        np.testing.assert_allclose(Kcov, c["Kcov"], rtol=tol.KERN_RTOL, atol=tol.KERN_ATOL)
+        L = chofac[0]
+        assert chofac[1] is True and np.allclose(np.triu(L, 1), 0.0)
+        Kc = c["Kcov"]
+        assert np.linalg.norm(L @ L.T - Kc) <= 1e-14 * np.linalg.norm(Kc) * GP.n_data
+        np.testing.assert_allclose(np.abs(np.diag(L)), np.abs(c["chofac_diag"]), rtol=1e-6)
+
+    # posterior (reference GpEvalModel.py:17-198)
+    hp2 = GP.optz_closed_form_hp(hp)
+    np.testing.assert_allclose(hp2.varK, c["varK_model"], rtol=tol.VARK_RTOL)
+    GP.set_hpara('set', 0, hp_vals=hp2)
+    alpha = GP.invKernEta_fdiff
+    assert np.linalg.norm(alpha - c["alpha"]) <= tol.ALPHA_NORMWISE * np.linalg.norm(c["alpha"])
+    mu, sig = GP.eval_model(c["xq"])[:2]
+    np.testing.assert_allclose(mu, c["mu"], rtol=tol.MU_RTOL, atol=tol.MU_ATOL_SCALE * max(1.0, np.abs(c["mu"]).max()))
+    np.testing.assert_allclose(sig, c["sig"], rtol=tol.SIG_RTOL, atol=tol.SIG_ATOL_SCALE * np.sqrt(hp2.varK))
+    # squeeze_nx contract
+    m1, s1 = GP.eval_model(c["xq"][0], squeeze_nx=True)[:2]
+    assert np.isclose(m1, mu[0]) and np.isclose(s1, sig[0])
+
+
+def test_alpha_residual_against_reference_matrix():
+    """||Kcov alpha - r|| / (||Kcov|| ||alpha||) <= 1e-13 with Kcov from the golden fixture."""
+    c = load_case(os.path.join(GOLDEN_DIR, "SqExp_none_n17_d4.npz"))
+    GP = _gp_from_case(c)
+    hp = GP.optz_closed_form_hp(_hp_from_case(GP, c))
+    GP.set_hpara('set', 0, hp_vals=hp)
+    y = GP.make_data_vec(c["f"], c["g"])
+    r = y.copy()
+    r[:c["n"]] -= hp.beta[0]
+    Kcov = c["Kcov"]
+    res = np.linalg.norm(Kcov @ GP.invKernEta_fdiff - r) / (np.linalg.norm(Kcov, 2) * np.linalg.norm(GP.invKernEta_fdiff))
+    assert res <= tol.ALPHA_RESIDUAL
+    fac = GP.download_chofac()
+    np.testing.assert_allclose(cho_solve(fac, r), GP.invKernEta_fdiff, rtol=1e-6, atol=1e-6 * np.abs(GP.invKernEta_fdiff).max())
+
+
+@pytest.mark.parametrize("name,noisy,kernel", [("multistart_SqExp_n64_d4", False, "SqExp"),
+                                               ("multistart_Ma5f2_noisy_n40_d6", True, "Ma5f2")])
+def test_multistart_tables(name, noisy, kernel):
+    import gpgradpy_amd
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    X, f, g = z["x"], z["f"], z["g"]
+    n, d = X.shape
+    GP = gpgradpy_amd.GaussianProcess(d, True, kernel, 'precon')
+    if noisy:
+        GP.set_data(X, f, z["std_f"], g, z["std_g"])
+    else:
+        GP.set_data(X, f, np.zeros(n), g, np.zeros((n, d)))
+    assert GP.hp_info_optz_lkd.n_hp == int(z["n_hp"])
+    hp_best, ln, idx = GP.select_hp_best(z["hp_x0"])
+    np.testing.assert_allclose(ln, z["ln_lkd_all"], rtol=tol.LN_LKD_RTOL)
+    assert idx == int(z["idx_max"])
+    np.testing.assert_array_equal(hp_best[0], z["hp_x0"][idx])
+    # batch == one-at-a-time
+    for i in (0, idx, len(ln) - 1):
+        info, ok = GP.calc_lkd_all(GP.hp_vec2dataclass(GP.hp_info_optz_lkd, z["hp_x0"][i]))
+        assert ok and np.isclose(info.ln_lkd, ln[i], rtol=1e-12)
+    # the multi-rank selection path with no process group = single rank
+    hb, ln2, idx2 = gpgradpy_amd.select_best_restart(z["hp_x0"], GP.calc_lkd_batch)
+    assert idx2 == idx and np.allclose(ln2, ln, rtol=1e-12, equal_nan=True)
+
+
+@pytest.mark.parametrize("kernel,noise,n,d,panel", [("SqExp", "none", 300, 8, 256), ("Ma5f2", "known", 260, 7, 128),
+                                                    ("SqExp", "unknown", 500, 4, 256), ("Ma5f2", "none", 150, 16, 512)])
+def test_against_oracle_multi_panel(kernel, noise, n, d, panel):
+    """Sizes spanning several outer panels, ragged tiles and every kernel template; oracle finishes in seconds."""
+    import gpgradpy_amd
+    from oracle import gp_oracle as orc
+    rng = np.random.default_rng(n + d)
+    X, f, g = orc.synthetic_design(n, d, seed=n)
+    std_f = std_g = None
+    vf = vg = None
+    varK = None
+    if noise == "none":
+        std_f, std_g = np.zeros(n), np.zeros((n, d))
+    elif noise == "known":
+        std_f, std_g = np.full(n, 1e-2), np.full((n, d), 1e-1)
+        varK = 2.5
+    else:
+        vf, vg, varK = 1e-4, 1e-2, 0.7
+    theta = 10.0 ** rng.uniform(-2.5, -0.5, d)
+    GP = gpgradpy_amd.GaussianProcess(d, True, kernel, 'precon')
+    GP.set_data(X, f, std_f, g, std_g)
+    GP.set_panel(panel)
+    hp = GP.make_hp_class(theta=theta, varK=varK, var_fval=vf, var_fgrad=vg)
+    info, ok = GP.calc_lkd_all(hp)
+    y = orc.make_data_vec(f, g)
+    nv = orc.calc_noise_vec(n, d, True, std_f, std_g, vf, vg)
+    noisy = noise != "none"
+    r = orc.calc_lkd(X, y, theta, kernel, True, "precon", GP._etaK, nv, noisy, varK=varK)
+    assert ok and r.ok
+    ref = dict(hp_beta=r.hp_beta, hp_varK=r.hp_varK, ln_det_Kmat=r.ln_det_Kmat, ln_lkd=r.ln_lkd)
+    tol.check_scalars(info.hp_beta[0], info.hp_varK, info.ln_det_Kmat, info.ln_lkd, ref, y.size, noisy)
+    # posterior
+    hp2 = GP.optz_closed_form_hp(hp)
+    GP.set_hpara('set', 0, hp_vals=hp2)
+    m = orc.setup_eval_model(X, y, theta, kernel, True, "precon", GP._etaK, nv, r.hp_beta, hp2.varK)
+    assert np.linalg.norm(GP.invKernEta_fdiff - m.alpha) <= tol.ALPHA_NORMWISE * np.linalg.norm(m.alpha)
+    xq = rng.uniform(-2, 2, (70, d))          # > 64 query points: two RHS tiles
+    mu, sig = GP.eval_model(xq)[:2]
+    mu_o, sig_o = orc.eval_model(m, xq)
+    np.testing.assert_allclose(mu, mu_o, rtol=tol.MU_RTOL, atol=tol.MU_ATOL_SCALE * max(1.0, np.abs(mu_o).max()))
+    np.testing.assert_allclose(sig, sig_o, rtol=tol.SIG_RTOL, atol=tol.SIG_ATOL_SCALE * np.sqrt(hp2.varK))
+
+
+def test_gradient_free_base():
+    """BASELINE cfg1 shape (gradient-free SqExp, n=200, d=2): wellcond coerced to 'base'."""
+    import gpgradpy_amd
+    from oracle import gp_oracle as orc
+    X, f, g = orc.synthetic_design(200, 2, seed=0)
+    GP = gpgradpy_amd.GaussianProcess(2, False, 'SqExp', 'precon')
+    assert GP.wellcond_mtd == 'base'
+    GP.set_data(X, f, np.zeros(200))
+    theta = np.array([0.5, 0.5])
+    info, ok = GP.calc_lkd_all(GP.make_hp_class(theta=theta))
+    r = orc.calc_lkd(X, f, theta, "SqExp", False, "base", GP._etaK, np.zeros(200), False)
+    assert ok and r.ok
+    ref = dict(hp_beta=r.hp_beta, hp_varK=r.hp_varK, ln_det_Kmat=r.ln_det_Kmat, ln_lkd=r.ln_lkd)
+    tol.check_scalars(info.hp_beta[0], info.hp_varK, info.ln_det_Kmat, info.ln_lkd, ref, 200, False)
+
+
+def test_edge_cases():
+    import gpgradpy_amd
+    # single data point (n_eval == 1 nugget branch, GpWellCond.py:125-126)
+    GP = gpgradpy_amd.GaussianProcess(2, True, 'SqExp', 'precon')
+    GP.set_data(np.array([[0.3, -0.2]]), np.array([1.5]), np.zeros(1), np.array([[0.1, 0.2]]), np.zeros((1, 2)))
+    info, ok = GP.calc_lkd_all(GP.make_hp_class(theta=np.array([0.5, 2.0])))
+    assert ok and np.isclose(info.hp_beta[0], 1.5, rtol=1e-12)
+    # NaN theta is rejected as in Kernel.py:201
+    with pytest.raises(AssertionError):
+        GP.calc_lkd_all(GP.make_hp_class(theta=np.array([np.nan, 1.0])))
+    # eval_model before setup -> assertion of GpEvalModel.py:91
+    with pytest.raises(AssertionError):
+        GP.eval_model(np.zeros((1, 2)))
+    # re-using the object with a different shape re-creates the device context
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-1, 1, (9, 2))
+    GP.set_data(x, x[:, 0], np.zeros(9), x, np.zeros((9, 2)))
+    assert GP.n_data == 27 and GP.calc_lkd_all(GP.make_hp_class(theta=np.array([0.5, 2.0])))[1]
+
+
+def test_full_size_properties():
+    """BASELINE cfg3 size (n=2000, d=8, N=18000): size-independent checks.
+    (1) theta -> large decouples the points: Kcor = I exactly, so ln_det, beta and varK are analytic;
+    (2) a batch of restarts equals the one-at-a-time evaluations bit for bit;
+    (3) permuting the data points leaves ln_lkd unchanged to rounding * kappa."""
+    import gpgradpy_amd
+    from oracle import gp_oracle as orc
+    n, d = 2000, 8
+    X, f, g = orc.synthetic_design(n, d, seed=0)
+    GP = gpgradpy_amd.GaussianProcess(d, True, 'SqExp', 'precon')
+    GP.set_data(X, f, np.zeros(n), g, np.zeros((n, d)))
+    N = n * (d + 1)
+    theta_big = np.full(d, 1e6)
+    info, ok = GP.calc_lkd_all(GP.make_hp_class(theta=theta_big))
+    assert ok
+    eta = GP._etaK
+    ln_det_exact = N * np.log1p(eta) + n * np.sum(np.log(2 * theta_big))
+    assert abs(info.ln_det_Kmat - ln_det_exact) <= 1e-9 * N
+    assert np.isclose(info.hp_beta[0], f.mean(), rtol=1e-12)
+    y = orc.make_data_vec(f, g)
+    r = y.copy()
+    r[:n] -= f.mean()
+    p2 = np.concatenate((np.ones(n), np.repeat(2 * theta_big, n)))
+    varK_exact = np.sum(r * r / p2) / (1 + eta) / N
+    assert np.isclose(info.hp_varK, varK_exact, rtol=1e-11)
+
+    hp_x0 = np.random.default_rng(1).uniform(-2.5, -0.5, (3, d))
+    ln = GP.calc_lkd_batch(hp_x0)
+    assert np.all(np.isfinite(ln))
+    one = GP.calc_lkd_all(GP.hp_vec2dataclass(GP.hp_info_optz_lkd, hp_x0[1]))[0].ln_lkd
+    assert one == ln[1]
+
+    perm = np.random.default_rng(2).permutation(n)
+    GP2 = gpgradpy_amd.GaussianProcess(d, True, 'SqExp', 'precon')
+    GP2.set_data(X[perm], f[perm], np.zeros(n), g[perm], np.zeros((n, d)))
+    ln_p = GP2.calc_lkd_batch(hp_x0[1:2])
+    assert np.isclose(ln_p[0], ln[1], rtol=tol.LN_LKD_RTOL)
