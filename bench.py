@@ -97,6 +97,7 @@ def main():
     ap.add_argument("--n", type=int, default=2000)
     ap.add_argument("--d", type=int, default=8)
     ap.add_argument("--panel", type=int, default=0, help="outer panel width override")
+    ap.add_argument("--lookahead", type=int, default=-1, help="1/0 force the two-stream look-ahead on/off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-all", action="store_true", help="time every kernel category (adds event overhead)")
     args = ap.parse_args()
@@ -127,6 +128,8 @@ def main():
     GP.set_data(X, f, np.zeros(n), g, np.zeros((n, d)))          # resident in HBM before the timed region
     if args.panel:
         GP.set_panel(args.panel)
+    if args.lookahead >= 0:
+        GP.set_lookahead(args.lookahead)
 
     # rank r owns rows [8r, 8r+8) of the 64-row table (BASELINE cfg4), cycled when steps > 8
     def rows_for(k):

@@ -18,7 +18,7 @@ PROF_NCAT = len(PROF_CATS)
 # every symbol include/gpgrad.h declares
 ABI_SYMBOLS = (
     "gpg_create", "gpg_destroy", "gpg_last_error", "gpg_set_data", "gpg_lkd", "gpg_lkd_batch",
-    "gpg_setup_eval", "gpg_predict", "gpg_get_matrix", "gpg_prof_enable", "gpg_prof_read", "gpg_set_panel",
+    "gpg_setup_eval", "gpg_predict", "gpg_get_matrix", "gpg_prof_enable", "gpg_prof_read", "gpg_set_panel", "gpg_set_lookahead",
     "gpg_device_info",
 )
 
@@ -76,6 +76,8 @@ def load():
     lib.gpg_prof_read.restype = C.c_int
     lib.gpg_set_panel.argtypes = [vp, C.c_int]
     lib.gpg_set_panel.restype = C.c_int
+    lib.gpg_set_lookahead.argtypes = [vp, C.c_int]
+    lib.gpg_set_lookahead.restype = C.c_int
     lib.gpg_device_info.argtypes = [C.c_int, C.c_char_p, C.c_int]
     lib.gpg_device_info.restype = C.c_int
     _lib = lib

@@ -135,7 +135,12 @@ int gpg_create(gpg_ctx** out, int device, int n_eval, int dim, int use_grad, int
     }                                                                                \
   } while (0)
   CREATE_OK(hipSetDevice(device));
-  CREATE_OK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  {
+    int prio_lo = 0, prio_hi = 0;
+    CREATE_OK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));   // numerically lowest = highest priority
+    CREATE_OK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_lo));
+    CREATE_OK(hipStreamCreateWithPriority(&c->stream_upd, hipStreamNonBlocking, prio_hi));
+  }
   CREATE_OK(hipMalloc(&c->A, sizeof(double) * (size_t)c->ld * c->Npad));
   CREATE_OK(hipMalloc(&c->Xt, sizeof(double) * (size_t)c->n * c->d));
   CREATE_OK(hipMalloc(&c->y, sizeof(double) * c->N));
@@ -144,6 +149,7 @@ int gpg_create(gpg_ctx** out, int device, int n_eval, int dim, int use_grad, int
   CREATE_OK(hipMalloc(&c->invp, sizeof(double) * c->Npad));
   CREATE_OK(hipMalloc(&c->zvec, sizeof(double) * c->Npad));
   CREATE_OK(hipMalloc(&c->tmpv, sizeof(double) * c->Npad));
+  CREATE_OK(hipMalloc(&c->dinv, sizeof(double) * c->Npad));
   CREATE_OK(hipMemset(c->A, 0, sizeof(double) * (size_t)c->ld * c->Npad));
 #undef CREATE_OK
   if (ensure_scal(c, 64) != 0) { g_create_err = c->err; gpg_destroy(c); return -2; }
@@ -155,14 +161,18 @@ void gpg_destroy(gpg_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->stream_upd) (void)hipStreamSynchronize(c->stream_upd);
   for (auto& pe : c->prof_pending) { (void)hipEventDestroy(pe.e0); (void)hipEventDestroy(pe.e1); }
   for (auto& ev : c->prof_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-  double* bufs[] = {c->A, c->Xt, c->y, c->noise, c->dvec, c->invp, c->zvec, c->tmpv, c->scal, c->Wt, c->xq_dev,
+  double* bufs[] = {c->A, c->Xt, c->y, c->noise, c->dvec, c->invp, c->zvec, c->tmpv, c->dinv, c->scal, c->Wt, c->xq_dev,
                     c->musig, c->dense_tmp};
   for (double* b : bufs) if (b) (void)hipFree(b);
   if (c->info) (void)hipFree(c->info);
   if (c->h_scal) (void)hipHostFree(c->h_scal);
   if (c->h_info) (void)hipHostFree(c->h_info);
+  for (auto e : c->ev_panel) (void)hipEventDestroy(e);
+  for (auto e : c->ev_upd) (void)hipEventDestroy(e);
+  if (c->stream_upd) (void)hipStreamDestroy(c->stream_upd);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -348,6 +358,12 @@ int gpg_prof_read(gpg_ctx* c, double ms[GPG_PROF_NCAT], long long count[GPG_PROF
     c->prof_pool.push_back({pe.e0, pe.e1});
   }
   c->prof_pending.clear();
+  return 0;
+}
+
+int gpg_set_lookahead(gpg_ctx* c, int on) {
+  if (!c) return -1;
+  c->lookahead = on ? 1 : 0;
   return 0;
 }
 

@@ -31,7 +31,8 @@ __device__ __forceinline__ double readlane_d(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
-__global__ void __launch_bounds__(64) potrf64_kernel(double* __restrict__ A, int ld, int j0, int N, int* __restrict__ info) {
+__global__ void __launch_bounds__(64) potrf64_kernel(double* __restrict__ A, int ld, int j0, int N, int* __restrict__ info,
+                                                      double* __restrict__ dinv) {
   __shared__ __attribute__((aligned(16))) double St[64][64];   // St[k][i] = L[i][k]
   const int i = threadIdx.x;
   double* blk = A + (size_t)j0 + (size_t)j0 * ld;
@@ -54,6 +55,7 @@ __global__ void __launch_bounds__(64) potrf64_kernel(double* __restrict__ A, int
       const double dj = sqrt(ajj);
       const double inv = 1.0 / dj;
       a[c] = (i == 16 * s + c) ? dj : a[c] * inv;
+      if (i == 0) dinv[j0 + 16 * s + c] = inv;   // reciprocal pivots for the panel solves
 #pragma unroll
       for (int k2 = c + 1; k2 < 16; ++k2) a[k2] -= a[c] * readlane_d(a[c], 16 * s + k2);
     }
@@ -68,38 +70,81 @@ __global__ void __launch_bounds__(64) potrf64_kernel(double* __restrict__ A, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// trsm64: X <- X L^-T for the `rows` rows below a factorised 64 x 64 diagonal block (X is rows x 64).
-// Lane <-> row; L^T is staged in LDS and read with wave-uniform (broadcast) addresses.
+// trsm64: X <- X L^-T for `rows` rows against a factorised 64 x 64 diagonal block (X is rows x 64).
+// Four lanes share one matrix row: lane (rr = lane >> 2, q = lane & 3) keeps the 16 columns k = 4m + q
+// of row rr in registers.  Column step j: the owner lane scales x_j by the reciprocal pivot, the quad
+// broadcasts it with one DPP quad_perm per dword, and every lane updates its remaining columns with
+// L[k][j] read from an LDS image laid out per (j, q) so that a lane's values are contiguous (b128
+// reads, the four q-slices 144 B apart: conflict-free).  544 FMAs per lane instead of 2016 for a
+// lane-per-row sweep; a wave covers 16 rows (4 columns x 128 contiguous bytes per global access).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) trsm64_kernel(const double* __restrict__ Lblk, int ldl, double* __restrict__ X,
-                                                     int ldx, int rows) {
-  __shared__ __attribute__((aligned(16))) double Lt[64][64];  // Lt[j][k] = L[k][j]
-  __shared__ double invd[64];
+template <int Q>
+__device__ __forceinline__ double quad_bcast(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, Q * 0x55, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, Q * 0x55, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+__global__ void __launch_bounds__(256) trsm64_kernel(const double* __restrict__ Lblk, int ldl,
+                                                     const double* __restrict__ dinv, double* __restrict__ X, int ldx,
+                                                     int rows) {
+  __shared__ __attribute__((aligned(16))) double Ls[64][4][18];   // Ls[j][q][m] = L[4m + q][j]
+  __shared__ double sdinv[64];
   for (int t = threadIdx.x; t < 64 * 64; t += 256) {
-    int j = t >> 6, k = t & 63;
-    Lt[j][k] = Lblk[k + (size_t)j * ldl];
+    const int j = t >> 6, k = t & 63;
+    Ls[j][k & 3][k >> 2] = Lblk[k + (size_t)j * ldl];
   }
-  if (threadIdx.x < 64) invd[threadIdx.x] = 1.0 / Lblk[threadIdx.x + (size_t)threadIdx.x * ldl];
+  if (threadIdx.x < 64) sdinv[threadIdx.x] = dinv[threadIdx.x];
   __syncthreads();
-  const int r = blockIdx.x * 256 + threadIdx.x;
-  if (r >= rows) return;
-  double x[64];
+  const int q = threadIdx.x & 3;
+  int r = blockIdx.x * 64 + (threadIdx.x >> 2);
+  const bool active = r < rows;
+  r = active ? r : rows - 1;
+  double* Xr = X + r + (size_t)q * ldx;
+  double x[16];
 #pragma unroll
-  for (int j = 0; j < 64; ++j) x[j] = X[r + (size_t)j * ldx];
+  for (int m = 0; m < 16; ++m) x[m] = Xr[(size_t)(4 * m) * ldx];
+  // software pipeline: the L values of step j+1 are read from LDS while step j computes; the
+  // sched_barrier keeps the compiler from hoisting every read to the top (register blow-up).
+  double lv[2][16];
 #pragma unroll
-  for (int j = 0; j < 64; ++j) {
-    x[j] *= invd[j];
-#pragma unroll
-    for (int k = j + 1; k < 64; ++k) x[k] -= x[j] * Lt[j][k];
+  for (int m = 0; m < 16; ++m) lv[0][m] = Ls[0][q][m];
+#define GPG_TRSM_STEP(QJ)                                                                   \
+  {                                                                                         \
+    constexpr int cur = QJ & 1, nxt = cur ^ 1;                                               \
+    const int j = 4 * mj + QJ;                                                              \
+    const int jn = j + 1 < 64 ? j + 1 : 63;                                                 \
+    const int m0n = (j + 1) >> 2;                                                           \
+    _Pragma("unroll") for (int m = 0; m < 16; ++m) if (m >= m0n) lv[nxt][m] = Ls[jn][q][m]; \
+    const double xs = x[mj] * sdinv[j];                                                     \
+    x[mj] = (q == QJ) ? xs : x[mj];                                                         \
+    const double xj = quad_bcast<QJ>(x[mj]);                                                \
+    if (QJ < 3) {                                                                           \
+      const double t = x[mj] - xj * lv[cur][mj];                                            \
+      x[mj] = (q > QJ) ? t : x[mj];                                                         \
+    }                                                                                       \
+    _Pragma("unroll") for (int m = mj + 1; m < 16; ++m) x[m] -= xj * lv[cur][m];            \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
   }
 #pragma unroll
-  for (int j = 0; j < 64; ++j) X[r + (size_t)j * ldx] = x[j];
+  for (int mj = 0; mj < 16; ++mj) {
+    GPG_TRSM_STEP(0)
+    GPG_TRSM_STEP(1)
+    GPG_TRSM_STEP(2)
+    GPG_TRSM_STEP(3)
+  }
+#undef GPG_TRSM_STEP
+  if (active) {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) Xr[(size_t)(4 * m) * ldx] = x[m];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
 // gemm_nt_minus<BM, BN>:  C[M x Nc] -= A[M x K] * B[Nc x K]^T   (all column-major)
-//   M multiple of 64, Nc multiple of BN, K multiple of 16.  lower != 0: C's origin lies on the matrix
-//   diagonal and tiles entirely above it are skipped.
+//   M multiple of 64, Nc multiple of BN, K multiple of 8.  lower != 0: C's origin lies on the matrix
+//   diagonal and tiles entirely above it are skipped; tiles with m0 < skipM and n0 < skipN are skipped too.
 // 4 waves as 2 x 2; each wave owns (BM/2) x (BN/2) of C as 16x16 MFMA blocks.  The MFMA "A" operand
 // is fed from the C-column side and the "B" operand from the C-row side, so that lane&15 indexes C's
 // row: every accumulator load/store instruction touches 4 columns x 128 contiguous bytes.
@@ -107,7 +152,7 @@ __global__ void __launch_bounds__(256) trsm64_kernel(const double* __restrict__ 
 template <int BM, int BN>
 __global__ void __launch_bounds__(256, 2)
 gemm_nt_minus_kernel(double* __restrict__ C, int ldc, const double* __restrict__ A, int lda,
-                     const double* __restrict__ B, int ldb, int M, int Nc, int K, int lower) {
+                     const double* __restrict__ B, int ldb, int M, int Nc, int K, int lower, int skipM, int skipN) {
   constexpr int KB = 8;
   constexpr int SA = BM + 16, SB = BN + 16;   // row strides: +128 B keeps ds_read_b64 conflict-free
   constexpr int MI = BM / 32, NI = BN / 32;   // 16x16 blocks per wave
@@ -117,6 +162,7 @@ gemm_nt_minus_kernel(double* __restrict__ C, int ldc, const double* __restrict__
 
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   if (lower && m0 + BM <= n0) return;
+  if (m0 < skipM && n0 < skipN) return;   // region owned by the look-ahead stream
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w & 1, wn = w >> 1;
@@ -209,52 +255,117 @@ gemm_nt_minus_kernel(double* __restrict__ C, int ldc, const double* __restrict__
 
 template <int BM, int BN>
 void launch_gemm(gpg_ctx* c, double* C, int ldc, const double* A, int lda, const double* B, int ldb, int M, int Nc,
-                 int K, int lower) {
+                 int K, int lower, int skipM = 0, int skipN = 0) {
   if (M <= 0 || Nc <= 0 || K <= 0) return;
   dim3 grid((M + BM - 1) / BM, Nc / BN);
   hipLaunchKernelGGL((gemm_nt_minus_kernel<BM, BN>), grid, dim3(256), 0, c->stream, C, ldc, A, lda, B, ldb, M, Nc, K,
-                     lower);
+                     lower, skipM, skipN);
 }
 
 }  // namespace
 
 // Factorise the Npad x Npad matrix held in c->A; rows [Npad, ld) are right-hand-side rows.
-void gpg_cholesky(gpg_ctx* c) {
-  const int ld = c->ld, Npad = c->Npad, NB = c->nb_outer;
+//
+// Per panel p (columns [k0, k1), width nb_outer):
+//   D_p  factor the nb x nb diagonal block               (potrf64 + small trsm/gemm; latency-bound, tiny)
+//   B_p  solve the rows below it: 64-column trsm sweeps + MFMA updates inside the panel
+//   U_p  trailing update C -= A_panel A_panel^T on fp64 MFMA
+// Look-ahead: D_(p+1) only needs the next diagonal block updated, so a second (high-priority) stream
+// applies panel p to that block and factors it while the main stream runs the big U_p (which skips
+// that block).  The serial pivot chain of potrf is thereby hidden behind the trailing update.
+//   main stream : [wait D_p] B_p, U_p (minus next diag block), [wait D_(p+1)] B_(p+1), ...
+//   diag stream : [wait B_p] update next diag block with panel p, D_(p+1)
+static void factor_diag_block(gpg_ctx* c, int k0, int k1) {
+  const int ld = c->ld;
   double* A = c->A;
-  for (int k0 = 0; k0 < Npad; k0 += NB) {
-    const int nbw = (Npad - k0) < NB ? (Npad - k0) : NB;
-    const int k1 = k0 + nbw;
-    for (int j0 = k0; j0 < k1; j0 += GPG_NBI) {
-      const int j1 = j0 + GPG_NBI;
-      gpg_prof_begin(c, GPG_PROF_POTRF, 64.0 * 64.0 * 64.0 / 3.0);
-      hipLaunchKernelGGL(potrf64_kernel, dim3(1), dim3(64), 0, c->stream, A, ld, j0, c->N, c->info);
-      gpg_prof_end(c);
-      const int rows = ld - j1;
-      if (rows > 0) {
-        gpg_prof_begin(c, GPG_PROF_TRSM, (double)rows * 64.0 * 64.0);
-        hipLaunchKernelGGL(trsm64_kernel, dim3((rows + 255) / 256), dim3(256), 0, c->stream,
-                           A + (size_t)j0 + (size_t)j0 * ld, ld, A + (size_t)j1 + (size_t)j0 * ld, ld, rows);
-        gpg_prof_end(c);
-      }
-      const int ncols = k1 - j1;
-      if (ncols > 0) {
-        gpg_prof_begin(c, GPG_PROF_GEMM_PANEL, 2.0 * (double)rows * ncols * 64.0);
-        launch_gemm<128, 64>(c, A + (size_t)j1 + (size_t)j1 * ld, ld, A + (size_t)j1 + (size_t)j0 * ld, ld,
-                             A + (size_t)j1 + (size_t)j0 * ld, ld, rows, ncols, GPG_NBI, 1);
-        gpg_prof_end(c);
-      }
-    }
-    if (k1 < Npad) {
-      const int M = ld - k1, Nc = Npad - k1;
-      // algorithmic flops of this launch: lower triangle of the Nt x Nt trailing block, K = nbw
-      const double nt = (double)(Npad - k1);
-      gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, nt * (nt + 1.0) * (double)nbw);
-      launch_gemm<128, 128>(c, A + (size_t)k1 + (size_t)k1 * ld, ld, A + (size_t)k1 + (size_t)k0 * ld, ld,
-                            A + (size_t)k1 + (size_t)k0 * ld, ld, M, Nc, nbw, 1);
+  for (int j0 = k0; j0 < k1; j0 += GPG_NBI) {
+    const int j1 = j0 + GPG_NBI;
+    gpg_prof_begin(c, GPG_PROF_POTRF, 64.0 * 64.0 * 64.0 / 3.0);
+    hipLaunchKernelGGL(potrf64_kernel, dim3(1), dim3(64), 0, c->stream, A, ld, j0, c->N, c->info, c->dinv);
+    gpg_prof_end(c);
+    const int rows = k1 - j1;
+    if (rows > 0) {
+      gpg_prof_begin(c, GPG_PROF_POTRF, (double)rows * 64.0 * 64.0);
+      hipLaunchKernelGGL(trsm64_kernel, dim3((rows + 63) / 64), dim3(256), 0, c->stream, A + (size_t)j0 + (size_t)j0 * ld,
+                         ld, c->dinv + j0, A + (size_t)j1 + (size_t)j0 * ld, ld, rows);
+      launch_gemm<128, 64>(c, A + (size_t)j1 + (size_t)j1 * ld, ld, A + (size_t)j1 + (size_t)j0 * ld, ld,
+                           A + (size_t)j1 + (size_t)j0 * ld, ld, rows, rows, GPG_NBI, 1);
       gpg_prof_end(c);
     }
   }
+}
+
+static void solve_below_block(gpg_ctx* c, int k0, int k1) {
+  const int ld = c->ld;
+  double* A = c->A;
+  const int rows = ld - k1;
+  if (rows <= 0) return;
+  for (int j0 = k0; j0 < k1; j0 += GPG_NBI) {
+    const int j1 = j0 + GPG_NBI;
+    gpg_prof_begin(c, GPG_PROF_TRSM, (double)rows * 64.0 * 64.0);
+    hipLaunchKernelGGL(trsm64_kernel, dim3((rows + 63) / 64), dim3(256), 0, c->stream, A + (size_t)j0 + (size_t)j0 * ld, ld,
+                       c->dinv + j0, A + (size_t)k1 + (size_t)j0 * ld, ld, rows);
+    gpg_prof_end(c);
+    const int ncols = k1 - j1;
+    if (ncols > 0) {   // X[:, j1:k1] -= X[:, j0:j1] L[j1:k1, j0:j1]^T
+      gpg_prof_begin(c, GPG_PROF_GEMM_PANEL, 2.0 * (double)rows * ncols * 64.0);
+      launch_gemm<128, 64>(c, A + (size_t)k1 + (size_t)j1 * ld, ld, A + (size_t)k1 + (size_t)j0 * ld, ld,
+                           A + (size_t)j1 + (size_t)j0 * ld, ld, rows, ncols, GPG_NBI, 0);
+      gpg_prof_end(c);
+    }
+  }
+}
+
+void gpg_cholesky(gpg_ctx* c) {
+  const int ld = c->ld, Npad = c->Npad, NB = c->nb_outer;
+  double* A = c->A;
+  hipStream_t sM = c->stream, sD = c->lookahead ? c->stream_upd : c->stream;
+  const bool two = (sD != sM);
+  const int npanel = (Npad + NB - 1) / NB;
+  while ((int)c->ev_panel.size() < npanel + 1) {
+    hipEvent_t e1, e2;
+    (void)hipEventCreateWithFlags(&e1, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&e2, hipEventDisableTiming);
+    c->ev_panel.push_back(e1);   // ev_panel[p]: diagonal block p factorised (diag stream)
+    c->ev_upd.push_back(e2);     // ev_upd[p]  : rows below panel p solved (main stream)
+  }
+  // D_0 follows the assembly on the main stream
+  c->stream = sM;
+  factor_diag_block(c, 0, NB < Npad ? NB : Npad);
+  for (int k0 = 0, p = 0; k0 < Npad; k0 += NB, ++p) {
+    const int nbw = (Npad - k0) < NB ? (Npad - k0) : NB;
+    const int k1 = k0 + nbw;
+    c->stream = sM;
+    if (two && p > 0) (void)hipStreamWaitEvent(sM, c->ev_panel[p], 0);
+    solve_below_block(c, k0, k1);                                   // B_p (also carries the RHS rows)
+    if (k1 >= Npad) break;
+    const int k2 = (k1 + NB < Npad) ? k1 + NB : Npad;               // next diagonal block = [k1, k2)
+    const double* Ap = A + (size_t)k0 * ld;
+    const double w = (double)(k2 - k1), nt = (double)(Npad - k1);
+    if (two) {
+      (void)hipEventRecord(c->ev_upd[p], sM);
+      // diag stream: next diagonal block -= panel rows [k1,k2) (panel p), then D_(p+1)
+      c->stream = sD;
+      (void)hipStreamWaitEvent(sD, c->ev_upd[p], 0);
+      gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, w * (w + 1.0) * (double)nbw);
+      launch_gemm<128, 128>(c, A + (size_t)k1 + (size_t)k1 * ld, ld, Ap + k1, ld, Ap + k1, ld, k2 - k1, k2 - k1, nbw, 1);
+      gpg_prof_end(c);
+      factor_diag_block(c, k1, k2);
+      (void)hipEventRecord(c->ev_panel[p + 1], sD);
+      // main stream: the rest of the trailing update
+      c->stream = sM;
+      gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, (nt * (nt + 1.0) - w * (w + 1.0)) * (double)nbw);
+      launch_gemm<128, 128>(c, A + (size_t)k1 + (size_t)k1 * ld, ld, Ap + k1, ld, Ap + k1, ld, ld - k1, Npad - k1, nbw, 1,
+                            k2 - k1, k2 - k1);
+      gpg_prof_end(c);
+    } else {
+      gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, nt * (nt + 1.0) * (double)nbw);
+      launch_gemm<128, 128>(c, A + (size_t)k1 + (size_t)k1 * ld, ld, Ap + k1, ld, Ap + k1, ld, ld - k1, Npad - k1, nbw, 1);
+      gpg_prof_end(c);
+      factor_diag_block(c, k1, k2);
+    }
+  }
+  c->stream = sM;
 }
 
 // W (rows x Npad, leading dimension ldw, "RHS rows" layout) <- W L^-T using the factor in c->A.
@@ -266,8 +377,8 @@ void gpg_forward_rows(gpg_ctx* c, double* W, int ldw, int rows) {
     const int k1 = k0 + nbw;
     for (int j0 = k0; j0 < k1; j0 += GPG_NBI) {
       const int j1 = j0 + GPG_NBI;
-      hipLaunchKernelGGL(trsm64_kernel, dim3((rows + 255) / 256), dim3(256), 0, c->stream,
-                         A + (size_t)j0 + (size_t)j0 * ld, ld, W + (size_t)j0 * ldw, ldw, rows);
+      hipLaunchKernelGGL(trsm64_kernel, dim3((rows + 63) / 64), dim3(256), 0, c->stream,
+                         A + (size_t)j0 + (size_t)j0 * ld, ld, c->dinv + j0, W + (size_t)j0 * ldw, ldw, rows);
       const int ncols = k1 - j1;
       if (ncols > 0)
         launch_gemm<128, 64>(c, W + (size_t)j1 * ldw, ldw, W + (size_t)j0 * ldw, ldw,

@@ -24,7 +24,10 @@ struct ProfEvent { hipEvent_t e0, e1; int cat; };
 
 struct gpg_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;      // main stream
+  hipStream_t stream_upd = nullptr;  // high-priority stream: look-ahead factorisation of the next diagonal block
+  int lookahead = 1;
+  std::vector<hipEvent_t> ev_panel, ev_upd;
   int n = 0, d = 0, use_grad = 0, kernel = 0;
   int N = 0, Npad = 0, R = GPG_RHS_ROWS, ld = 0;
   int nb_outer = 256;
@@ -37,6 +40,7 @@ struct gpg_ctx {
   double* invp = nullptr;    // [Npad] 1/sqrt(dvec) (precon) or 1
   double* zvec = nullptr;    // [Npad] L^-T L^-1 P^-1 (y - V beta)  (= p * alpha)
   double* tmpv = nullptr;    // [Npad] scratch for the backward solve
+  double* dinv = nullptr;    // [Npad] reciprocal pivots 1 / L_jj of the factor in A
   double* scal = nullptr;    // device scalars of the reductions
   int* info = nullptr;       // device: first failing pivot (0 = none)
   double* Wt = nullptr;      // prediction RHS rows [wt_rows x Npad]

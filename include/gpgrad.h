@@ -133,6 +133,9 @@ int gpg_prof_read(gpg_ctx* ctx, double ms[GPG_PROF_NCAT], long long count[GPG_PR
 
 /* Tuning knobs (defaults are the measured best): outer panel width (multiple of 128 in [128, 1024]). */
 int gpg_set_panel(gpg_ctx* ctx, int nb_outer);
+/* 1 (default): two-stream look-ahead Cholesky (next panel factorised under the trailing update);
+ * 0: single stream. */
+int gpg_set_lookahead(gpg_ctx* ctx, int on);
 
 /* Library / device facts for logs: writes "gfx950 MI355X ..." style text. */
 int gpg_device_info(int device, char* buf, int buflen);
