@@ -170,6 +170,7 @@ void gpg_destroy(gpg_ctx* c) {
   if (c->info) (void)hipFree(c->info);
   if (c->h_scal) (void)hipHostFree(c->h_scal);
   if (c->h_info) (void)hipHostFree(c->h_info);
+  for (auto& kv : c->tilemaps) if (kv.second.dev) (void)hipFree(kv.second.dev);
   for (auto e : c->ev_panel) (void)hipEventDestroy(e);
   for (auto e : c->ev_upd) (void)hipEventDestroy(e);
   if (c->stream_upd) (void)hipStreamDestroy(c->stream_upd);
@@ -363,7 +364,8 @@ int gpg_prof_read(gpg_ctx* c, double ms[GPG_PROF_NCAT], long long count[GPG_PROF
 
 int gpg_set_lookahead(gpg_ctx* c, int on) {
   if (!c) return -1;
-  c->lookahead = on ? 1 : 0;
+  c->lookahead = (on & 1) ? 1 : 0;
+  c->gemm_impl = (on & 2) ? 0 : 1;   // bit 1: fall back to the register-staged 128x128 kernel (A/B runs)
   return 0;
 }
 

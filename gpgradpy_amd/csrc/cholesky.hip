@@ -152,7 +152,8 @@ __global__ void __launch_bounds__(256) trsm64_kernel(const double* __restrict__ 
 template <int BM, int BN>
 __global__ void __launch_bounds__(256, 2)
 gemm_nt_minus_kernel(double* __restrict__ C, int ldc, const double* __restrict__ A, int lda,
-                     const double* __restrict__ B, int ldb, int M, int Nc, int K, int lower, int skipM, int skipN) {
+                     const double* __restrict__ B, int ldb, int M, int Nc, int K, int lower, int skipM, int skipN,
+                     const int* __restrict__ tilemap, int ntiles) {
   constexpr int KB = 8;
   constexpr int SA = BM + 16, SB = BN + 16;   // row strides: +128 B keeps ds_read_b64 conflict-free
   constexpr int MI = BM / 32, NI = BN / 32;   // 16x16 blocks per wave
@@ -160,9 +161,23 @@ gemm_nt_minus_kernel(double* __restrict__ C, int ldc, const double* __restrict__
   __shared__ __attribute__((aligned(16))) double sA[2][KB][SA];
   __shared__ __attribute__((aligned(16))) double sB[2][KB][SB];
 
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  if (lower && m0 + BM <= n0) return;
-  if (m0 < skipM && n0 < skipN) return;   // region owned by the look-ahead stream
+  int m0, n0;
+  if (tilemap) {
+    // 1-D grid over a precomputed list of live tiles in super-tile-major order.  Workgroups b and b + 8
+    // share an XCD (round-robin dispatch), so each XCD is handed one contiguous chunk of the list: the
+    // tiles resident on an XCD at any time share panel slices, which then hit in that XCD's L2.
+    const int nwg = ntiles, b = blockIdx.x;
+    const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    const int t = tilemap[v];
+    m0 = (t & 0xffff) * BM;
+    n0 = (t >> 16) * BN;
+  } else {
+    m0 = blockIdx.x * BM;
+    n0 = blockIdx.y * BN;
+    if (lower && m0 + BM <= n0) return;
+    if (m0 < skipM && n0 < skipN) return;   // region owned by the look-ahead stream
+  }
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w & 1, wn = w >> 1;
@@ -253,13 +268,190 @@ gemm_nt_minus_kernel(double* __restrict__ C, int ldc, const double* __restrict__
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// gemm_dma_kernel: the 128 x 128 tile update  C -= A B^T  with the panel streamed by LDS-DMA.
+// Same tile / wave / MFMA mapping as gemm_nt_minus_kernel<128,128>, but the k-chunks (8 deep) are
+// written straight into a 4-stage LDS ring with global_load_lds_dwordx4: one wave-instruction moves one
+// 1 KiB k-row of the A or B slice (rows are contiguous in the column-major panel and padded by 128 B in
+// LDS, so each row is exactly one lane-linear DMA).  Three chunks stay in flight across the single raw
+// s_barrier per chunk (counted vmcnt, never __syncthreads(), which would drain the DMAs); no staging
+// VGPRs, no ds_write.  The sign of the update is folded into the A fragment (one v_xor per fragment).
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+
+__global__ void __launch_bounds__(256, 2)
+gemm_dma_kernel(double* __restrict__ C, int ldc, const double* __restrict__ A, int lda, const double* __restrict__ B,
+                int ldb, int M, int Nc, int K, int lower, int skipM, int skipN, const int* __restrict__ tilemap,
+                int ntiles) {
+  constexpr int BM = 128, BN = 128, KB = 8, S = 4;
+  constexpr int ROW = 144;                 // doubles per LDS k-row (128 + 16 pad: conflict-free ds_read_b64)
+  constexpr int STAGE = 2 * KB * ROW;      // A rows then B rows
+  __shared__ __attribute__((aligned(16))) double smem[S * STAGE];
+
+  int m0, n0;
+  if (tilemap) {
+    const int nwg = ntiles, b = blockIdx.x;
+    const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    const int t = tilemap[v];
+    m0 = (t & 0xffff) * BM;
+    n0 = (t >> 16) * BN;
+  } else {
+    m0 = blockIdx.x * BM;
+    n0 = blockIdx.y * BN;
+    if (lower && m0 + BM <= n0) return;
+    if (m0 < skipM && n0 < skipN) return;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w & 1, wn = w >> 1;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const bool wave_active = (m0 + wm * 64) < M;
+
+  d4 acc[4][4] = {};
+  double* Cw = C + (size_t)(m0 + wm * 64 + l15) + (size_t)(n0 + wn * 64 + l4) * ldc;
+#ifndef GPG_ABLATE_CLOAD
+  if (wave_active) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[ni][mi][r] = Cw[mi * 16 + (size_t)(ni * 16 + 4 * r) * ldc];
+  }
+#endif
+
+  // per-lane DMA sources: this wave moves k-rows w and w + 4 of every chunk, for A and for B
+  int rowa = m0 + 2 * lane;
+  rowa = rowa < M ? rowa : M - 2;          // ragged last row tile: clamp (those rows are never stored)
+#ifdef GPG_ABLATE_SAMEPANEL
+  const double* ga = A + 2 * lane + (size_t)w * lda;   // diagnostic: every tile streams the same (L2-resident) slices
+  const double* gb = B + 2 * lane + (size_t)w * ldb;
+#else
+  const double* ga = A + rowa + (size_t)w * lda;
+  const double* gb = B + n0 + 2 * lane + (size_t)w * ldb;
+#endif
+  const size_t a4 = (size_t)4 * lda, b4 = (size_t)4 * ldb, aK = (size_t)KB * lda, bK = (size_t)KB * ldb;
+  double* const sbase = smem;
+
+#ifdef GPG_ABLATE_DMA
+#define GPG_DMA_ISSUE(stage) {}
+#else
+#define GPG_DMA_ISSUE(stage)                                                                              \
+  {                                                                                                       \
+    double* sa = sbase + (stage) * STAGE + w * ROW;                                                        \
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)ga, (lds_ptr_t)sa, 16, 0, 0);                              \
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(ga + a4), (lds_ptr_t)(sa + 4 * ROW), 16, 0, 0);          \
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)gb, (lds_ptr_t)(sa + KB * ROW), 16, 0, 0);                 \
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(gb + b4), (lds_ptr_t)(sa + (KB + 4) * ROW), 16, 0, 0);    \
+    ga += aK;                                                                                             \
+    gb += bK;                                                                                             \
+  }
+#endif
+#define GPG_DMA_COMPUTE(stage)                                                                            \
+  {                                                                                                       \
+    const double* pa = sbase + (stage) * STAGE + l4 * ROW + wm * 64 + l15;                                 \
+    const double* pb = sbase + (stage) * STAGE + (KB + l4) * ROW + wn * 64 + l15;                          \
+    _Pragma("unroll") for (int kk = 0; kk < KB; kk += 4) {                                                 \
+      double fm[4], fn[4];                                                                                \
+      _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) fm[mi] = -pa[kk * ROW + mi * 16];                    \
+      _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) fn[ni] = pb[kk * ROW + ni * 16];                     \
+      _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                     \
+        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                   \
+          acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fn[ni], fm[mi], acc[ni][mi], 0, 0, 0);        \
+    }                                                                                                     \
+  }
+
+  const int nchunk = K / KB;
+  // prologue: S-1 chunks in flight
+#pragma unroll
+  for (int st = 0; st < S - 1; ++st)
+    if (st < nchunk) GPG_DMA_ISSUE(st)
+  if (nchunk >= S - 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  int stage = 0;
+  for (int i = 0; i < nchunk; ++i) {
+    const bool more = (i + S - 1) < nchunk;
+    if (more) {
+      int st = stage + S - 1;
+      st = st >= S ? st - S : st;
+      GPG_DMA_ISSUE(st)
+    }
+    GPG_DMA_COMPUTE(stage)
+    // chunk i+1 must have landed before anybody reads it; chunks i+2, i+3 may stay in flight
+    if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    stage = stage + 1 == S ? 0 : stage + 1;
+  }
+#undef GPG_DMA_ISSUE
+#undef GPG_DMA_COMPUTE
+
+  if (wave_active) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cw[mi * 16 + (size_t)(ni * 16 + 4 * r) * ldc] = acc[ni][mi][r];
+  }
+}
+
 template <int BM, int BN>
 void launch_gemm(gpg_ctx* c, double* C, int ldc, const double* A, int lda, const double* B, int ldb, int M, int Nc,
                  int K, int lower, int skipM = 0, int skipN = 0) {
   if (M <= 0 || Nc <= 0 || K <= 0) return;
   dim3 grid((M + BM - 1) / BM, Nc / BN);
+  if (BM == 128 && BN == 128 && c->gemm_impl == 1) {
+    hipLaunchKernelGGL(gemm_dma_kernel, grid, dim3(256), 0, c->stream, C, ldc, A, lda, B, ldb, M, Nc, K, lower, skipM,
+                       skipN, (const int*)nullptr, 0);
+    return;
+  }
   hipLaunchKernelGGL((gemm_nt_minus_kernel<BM, BN>), grid, dim3(256), 0, c->stream, C, ldc, A, lda, B, ldb, M, Nc, K,
-                     lower, skipM, skipN);
+                     lower, skipM, skipN, (const int*)nullptr, 0);
+}
+
+// Live-tile list of a lower-trapezoid update (Mt x Nt tiles of 128, tiles above the diagonal and the
+// skipT x skipT leading block dropped), ordered by 4 x 4 super-tiles.  Built once per shape and kept on
+// the device for the lifetime of the context.
+const TileMap& get_tilemap(gpg_ctx* c, int Mt, int Nt, int skipT) {
+  const unsigned long long key = ((unsigned long long)Mt << 40) | ((unsigned long long)Nt << 16) | (unsigned)skipT;
+  auto it = c->tilemaps.find(key);
+  if (it != c->tilemaps.end()) return it->second;
+  constexpr int S = 4;
+  std::vector<int> list;
+  list.reserve((size_t)Mt * Nt / 2 + Mt);
+  for (int sj = 0; sj * S < Nt; ++sj)
+    for (int si = sj; si * S < Mt; ++si)
+      for (int ti = si * S; ti < (si + 1) * S && ti < Mt; ++ti)
+        for (int tj = sj * S; tj < (sj + 1) * S && tj < Nt; ++tj) {
+          if (tj > ti) continue;                       // above the diagonal
+          if (ti < skipT && tj < skipT) continue;      // owned by the look-ahead stream
+          list.push_back(ti | (tj << 16));
+        }
+  TileMap tm;
+  tm.n = (int)list.size();
+  tm.dev = nullptr;
+  if (tm.n > 0) {
+    (void)hipMalloc(&tm.dev, sizeof(int) * list.size());
+    (void)hipMemcpy(tm.dev, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice);
+  }
+  return c->tilemaps.emplace(key, tm).first->second;
+}
+
+void launch_gemm_trailing(gpg_ctx* c, double* C, int ldc, const double* A, int lda, const double* B, int ldb, int M,
+                          int Nc, int K, int skip) {
+  const TileMap& tm = get_tilemap(c, (M + 127) / 128, Nc / 128, skip / 128);
+  if (tm.n <= 0) return;
+  if (c->gemm_impl == 1) {
+    hipLaunchKernelGGL(gemm_dma_kernel, dim3(tm.n), dim3(256), 0, c->stream, C, ldc, A, lda, B, ldb, M, Nc, K, 1, 0, 0,
+                       (const int*)tm.dev, tm.n);
+    return;
+  }
+  hipLaunchKernelGGL((gemm_nt_minus_kernel<128, 128>), dim3(tm.n), dim3(256), 0, c->stream, C, ldc, A, lda, B, ldb, M, Nc,
+                     K, 1, 0, 0, (const int*)tm.dev, tm.n);
 }
 
 }  // namespace
@@ -347,7 +539,7 @@ void gpg_cholesky(gpg_ctx* c) {
       // diag stream: next diagonal block -= panel rows [k1,k2) (panel p), then D_(p+1)
       c->stream = sD;
       (void)hipStreamWaitEvent(sD, c->ev_upd[p], 0);
-      gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, w * (w + 1.0) * (double)nbw);
+      gpg_prof_begin(c, GPG_PROF_POTRF, w * (w + 1.0) * (double)nbw);
       launch_gemm<128, 128>(c, A + (size_t)k1 + (size_t)k1 * ld, ld, Ap + k1, ld, Ap + k1, ld, k2 - k1, k2 - k1, nbw, 1);
       gpg_prof_end(c);
       factor_diag_block(c, k1, k2);
@@ -355,12 +547,12 @@ void gpg_cholesky(gpg_ctx* c) {
       // main stream: the rest of the trailing update
       c->stream = sM;
       gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, (nt * (nt + 1.0) - w * (w + 1.0)) * (double)nbw);
-      launch_gemm<128, 128>(c, A + (size_t)k1 + (size_t)k1 * ld, ld, Ap + k1, ld, Ap + k1, ld, ld - k1, Npad - k1, nbw, 1,
-                            k2 - k1, k2 - k1);
+      launch_gemm_trailing(c, A + (size_t)k1 + (size_t)k1 * ld, ld, Ap + k1, ld, Ap + k1, ld, ld - k1, Npad - k1, nbw,
+                           k2 - k1);
       gpg_prof_end(c);
     } else {
       gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, nt * (nt + 1.0) * (double)nbw);
-      launch_gemm<128, 128>(c, A + (size_t)k1 + (size_t)k1 * ld, ld, Ap + k1, ld, Ap + k1, ld, ld - k1, Npad - k1, nbw, 1);
+      launch_gemm_trailing(c, A + (size_t)k1 + (size_t)k1 * ld, ld, Ap + k1, ld, Ap + k1, ld, ld - k1, Npad - k1, nbw, 0);
       gpg_prof_end(c);
       factor_diag_block(c, k1, k2);
     }

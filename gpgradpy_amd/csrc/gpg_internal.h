@@ -1,6 +1,7 @@
 // Internal declarations shared by the HIP translation units of libgpgrad_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <map>
 #include <string>
 #include <vector>
 #include "../../include/gpgrad.h"
@@ -20,6 +21,8 @@ struct AsmParams {
   double theta[GPG_MAX_DIM];
 };
 
+struct TileMap { int* dev; int n; };
+
 struct ProfEvent { hipEvent_t e0, e1; int cat; };
 
 struct gpg_ctx {
@@ -27,7 +30,9 @@ struct gpg_ctx {
   hipStream_t stream = nullptr;      // main stream
   hipStream_t stream_upd = nullptr;  // high-priority stream: look-ahead factorisation of the next diagonal block
   int lookahead = 1;
+  int gemm_impl = 1;                 // 1: LDS-DMA ring kernel for the 128x128 updates, 0: register-staged kernel
   std::vector<hipEvent_t> ev_panel, ev_upd;
+  std::map<unsigned long long, TileMap> tilemaps;   // live-tile lists of the trailing updates, per shape
   int n = 0, d = 0, use_grad = 0, kernel = 0;
   int N = 0, Npad = 0, R = GPG_RHS_ROWS, ld = 0;
   int nb_outer = 256;

@@ -593,7 +593,7 @@ class GaussianProcess:
             raise _lib.GpgError(f'gpg_set_panel failed ({rc}): {self._err()}')
 
     def set_lookahead(self, on):
-        self._lib.gpg_set_lookahead(self._ctx, int(bool(on)))
+        self._lib.gpg_set_lookahead(self._ctx, int(on))
 
     def download_chofac(self):
         """(P L, True) of the factor currently on the device (Kernel.py:252) as a SciPy cho_factor pair."""
