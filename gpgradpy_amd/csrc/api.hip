@@ -366,6 +366,7 @@ int gpg_set_lookahead(gpg_ctx* c, int on) {
   if (!c) return -1;
   c->lookahead = (on & 1) ? 1 : 0;
   c->gemm_impl = (on & 2) ? 0 : 1;   // bit 1: fall back to the register-staged 128x128 kernel (A/B runs)
+  c->gemm_stagger = (on & 4) ? 1 : 0; // bit 2: first-round de-phasing of the trailing-update workgroups (measured: no gain)
   return 0;
 }
 

@@ -269,6 +269,123 @@ gemm_nt_minus_kernel(double* __restrict__ C, int ldc, const double* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// gemm_reg_kernel: 128 x 128 tile update  C -= A B^T, register-staged double buffering with the prefetch
+// pinned ahead of the MFMAs.  Per 8-deep k-chunk a thread issues four 16-byte global loads (two of the
+// A slice, two of the B slice) BEFORE the chunk's 32 MFMAs and parks them in LDS after them; plain loads
+// cost their issuing wave a few cycles each (an LDS-DMA costs ~380: measured with in-kernel stamps), so
+// the MFMA waves never stall on the memory pipe.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2)
+gemm_reg_kernel(double* __restrict__ C, int ldc, const double* __restrict__ A, int lda, const double* __restrict__ B,
+                int ldb, int M, int Nc, int K, int lower, int skipM, int skipN, const int* __restrict__ tilemap,
+                int ntiles) {
+  constexpr int BM = 128, BN = 128, KB = 8;
+  constexpr int ROW = 144;
+  constexpr int STAGE = 2 * KB * ROW;
+  __shared__ __attribute__((aligned(16))) double smem[2 * STAGE];
+
+  int m0, n0;
+  if (tilemap) {
+    const int nwg = ntiles, b = blockIdx.x;
+    const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    const int t = tilemap[v];
+    m0 = (t & 0xffff) * BM;
+    n0 = (t >> 16) * BN;
+  } else {
+    m0 = blockIdx.x * BM;
+    n0 = blockIdx.y * BN;
+    if (lower && m0 + BM <= n0) return;
+    if (m0 < skipM && n0 < skipN) return;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w & 1, wn = w >> 1;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const bool wave_active = (m0 + wm * 64) < M;
+
+  d4 acc[4][4] = {};
+  double* Cw = C + (size_t)(m0 + wm * 64 + l15) + (size_t)(n0 + wn * 64 + l4) * ldc;
+  if (wave_active) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[ni][mi][r] = Cw[mi * 16 + (size_t)(ni * 16 + 4 * r) * ldc];
+  }
+
+  // this thread moves rows (2 lane, 2 lane + 1) of k-rows w and w + 4, for A and for B
+  int rowa = m0 + 2 * lane;
+  rowa = rowa < M ? rowa : M - 2;
+  const double* ga = A + rowa + (size_t)w * lda;
+  const double* gb = B + n0 + 2 * lane + (size_t)w * ldb;
+  const size_t a4 = (size_t)4 * lda, b4 = (size_t)4 * ldb, aK = (size_t)KB * lda, bK = (size_t)KB * ldb;
+  double* const sw = smem + w * ROW + 2 * lane;      // + stage * STAGE ; A rows at 0, B rows at KB * ROW
+  const double* const pa0 = smem + l4 * ROW + wm * 64 + l15;
+  const double* const pb0 = smem + (KB + l4) * ROW + wn * 64 + l15;
+
+  double2 ra0, ra1, rb0, rb1;
+#define GPG_REG_LOAD()                                              \
+  ra0 = *reinterpret_cast<const double2*>(ga);                      \
+  ra1 = *reinterpret_cast<const double2*>(ga + a4);                 \
+  rb0 = *reinterpret_cast<const double2*>(gb);                      \
+  rb1 = *reinterpret_cast<const double2*>(gb + b4);                 \
+  ga += aK;                                                         \
+  gb += bK;
+#define GPG_REG_STORE(stage)                                        \
+  {                                                                 \
+    double* d = sw + (stage) * STAGE;                                \
+    double2 n0v, n1v;                                               \
+    n0v.x = -ra0.x; n0v.y = -ra0.y; n1v.x = -ra1.x; n1v.y = -ra1.y; \
+    *reinterpret_cast<double2*>(d) = n0v;                           \
+    *reinterpret_cast<double2*>(d + 4 * ROW) = n1v;                 \
+    *reinterpret_cast<double2*>(d + KB * ROW) = rb0;                \
+    *reinterpret_cast<double2*>(d + (KB + 4) * ROW) = rb1;          \
+  }
+#define GPG_REG_COMPUTE(stage)                                                                        \
+  {                                                                                                   \
+    const double* pa = pa0 + (stage) * STAGE;                                                          \
+    const double* pb = pb0 + (stage) * STAGE;                                                          \
+    _Pragma("unroll") for (int kk = 0; kk < KB; kk += 4) {                                             \
+      double fm[4], fn[4];                                                                            \
+      _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) fm[mi] = pa[kk * ROW + mi * 16];                 \
+      _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) fn[ni] = pb[kk * ROW + ni * 16];                 \
+      _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                 \
+        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                               \
+          acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fn[ni], fm[mi], acc[ni][mi], 0, 0, 0);    \
+    }                                                                                                 \
+  }
+
+  const int nchunk = K / KB;
+  GPG_REG_LOAD()
+  GPG_REG_STORE(0)
+  __syncthreads();
+  int stage = 0;
+  for (int i = 0; i + 1 < nchunk; ++i) {
+    GPG_REG_LOAD()                           // next chunk: issued before the MFMAs ...
+    __builtin_amdgcn_sched_barrier(0);       // ... and kept there (hipcc otherwise sinks the loads below them)
+    GPG_REG_COMPUTE(stage)
+    __builtin_amdgcn_sched_barrier(0);
+    GPG_REG_STORE(stage ^ 1)
+    __syncthreads();
+    stage ^= 1;
+  }
+  GPG_REG_COMPUTE(stage)
+#undef GPG_REG_LOAD
+#undef GPG_REG_STORE
+#undef GPG_REG_COMPUTE
+
+  if (wave_active) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cw[mi * 16 + (size_t)(ni * 16 + 4 * r) * ldc] = acc[ni][mi][r];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // gemm_dma_kernel: the 128 x 128 tile update  C -= A B^T  with the panel streamed by LDS-DMA.
 // Same tile / wave / MFMA mapping as gemm_nt_minus_kernel<128,128>, but the k-chunks (8 deep) are
 // written straight into a 4-stage LDS ring with global_load_lds_dwordx4: one wave-instruction moves one
@@ -280,10 +397,17 @@ gemm_nt_minus_kernel(double* __restrict__ C, int ldc, const double* __restrict__
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
+#ifdef GPG_STAMP   // diagnostic build of tools/gemm_probe.hip only: per-wave cycle shares of the loop phases
+__device__ unsigned long long* g_stamp_buf;
+#define GPG_T(var) unsigned long long var; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0);
+#else
+#define GPG_T(var)
+#endif
+
 __global__ void __launch_bounds__(256, 2)
 gemm_dma_kernel(double* __restrict__ C, int ldc, const double* __restrict__ A, int lda, const double* __restrict__ B,
                 int ldb, int M, int Nc, int K, int lower, int skipM, int skipN, const int* __restrict__ tilemap,
-                int ntiles) {
+                int ntiles, int stagger_ticks) {
   constexpr int BM = 128, BN = 128, KB = 8, S = 4;
   constexpr int ROW = 144;                 // doubles per LDS k-row (128 + 16 pad: conflict-free ds_read_b64)
   constexpr int STAGE = 2 * KB * ROW;      // A rows then B rows
@@ -307,6 +431,18 @@ gemm_dma_kernel(double* __restrict__ C, int ldc, const double* __restrict__ A, i
   const int wm = w & 1, wn = w >> 1;
   const int l15 = lane & 15, l4 = lane >> 4;
   const bool wave_active = (m0 + wm * 64) < M;
+
+  // De-phase the first round.  All 512 co-resident workgroups of a launch would otherwise load their C
+  // tiles, stream and store in lockstep: HBM sees 64 MB bursts and both workgroups of a CU leave the MFMA
+  // pipe idle together.  Workgroup j of an XCD (b >> 3; j < 32 is the first on its CU, 32 <= j < 64 the
+  // second, by the observed round-robin placement) waits a fraction of one tile time before starting, so
+  // that the pair on a CU runs half a tile apart and the CUs are spread over the other half.
+  if (stagger_ticks > 0 && (blockIdx.x >> 3) < 64) {
+    const int j = blockIdx.x >> 3;
+    const unsigned wait_ticks = (unsigned)(((j & 31) * (stagger_ticks >> 1)) >> 5) + (j >= 32 ? (stagger_ticks >> 1) : 0);
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while ((unsigned)(__builtin_amdgcn_s_memrealtime() - t0) < wait_ticks) __builtin_amdgcn_s_sleep(32);
+  }
 
   d4 acc[4][4] = {};
   double* Cw = C + (size_t)(m0 + wm * 64 + l15) + (size_t)(n0 + wn * 64 + l4) * ldc;
@@ -334,6 +470,13 @@ gemm_dma_kernel(double* __restrict__ C, int ldc, const double* __restrict__ A, i
   const size_t a4 = (size_t)4 * lda, b4 = (size_t)4 * ldb, aK = (size_t)KB * lda, bK = (size_t)KB * ldb;
   double* const sbase = smem;
 
+#ifdef GPG_ABLATE_DMAB   // diagnostic: stream only the A slice (half the panel bytes)
+#define GPG_DMA_B_HALF
+#else
+#define GPG_DMA_B_HALF                                                                                    \
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)gb, (lds_ptr_t)(sa + KB * ROW), 16, 0, 0);                 \
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(gb + b4), (lds_ptr_t)(sa + (KB + 4) * ROW), 16, 0, 0);
+#endif
 #ifdef GPG_ABLATE_DMA
 #define GPG_DMA_ISSUE(stage) {}
 #else
@@ -342,8 +485,7 @@ gemm_dma_kernel(double* __restrict__ C, int ldc, const double* __restrict__ A, i
     double* sa = sbase + (stage) * STAGE + w * ROW;                                                        \
     __builtin_amdgcn_global_load_lds((glb_ptr_t)ga, (lds_ptr_t)sa, 16, 0, 0);                              \
     __builtin_amdgcn_global_load_lds((glb_ptr_t)(ga + a4), (lds_ptr_t)(sa + 4 * ROW), 16, 0, 0);          \
-    __builtin_amdgcn_global_load_lds((glb_ptr_t)gb, (lds_ptr_t)(sa + KB * ROW), 16, 0, 0);                 \
-    __builtin_amdgcn_global_load_lds((glb_ptr_t)(gb + b4), (lds_ptr_t)(sa + (KB + 4) * ROW), 16, 0, 0);    \
+    GPG_DMA_B_HALF                                                                                        \
     ga += aK;                                                                                             \
     gb += bK;                                                                                             \
   }
@@ -367,25 +509,49 @@ gemm_dma_kernel(double* __restrict__ C, int ldc, const double* __restrict__ A, i
 #pragma unroll
   for (int st = 0; st < S - 1; ++st)
     if (st < nchunk) GPG_DMA_ISSUE(st)
-  if (nchunk >= S - 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#ifdef GPG_ABLATE_DMAB
+#define GPG_VMCNT_STEADY "s_waitcnt vmcnt(4)"
+#else
+#define GPG_VMCNT_STEADY "s_waitcnt vmcnt(8)"
+#endif
+  if (nchunk >= S - 1) asm volatile(GPG_VMCNT_STEADY ::: "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
   int stage = 0;
+#ifdef GPG_STAMP
+  unsigned long long t_issue = 0, t_comp = 0, t_wait = 0, t_bar = 0;
+  const unsigned long long tc0 = __builtin_amdgcn_s_memtime(), tr0 = __builtin_amdgcn_s_memrealtime();
+#endif
   for (int i = 0; i < nchunk; ++i) {
     const bool more = (i + S - 1) < nchunk;
+    GPG_T(s0)
     if (more) {
       int st = stage + S - 1;
       st = st >= S ? st - S : st;
       GPG_DMA_ISSUE(st)
     }
+    GPG_T(s1)
     GPG_DMA_COMPUTE(stage)
+    GPG_T(s2)
     // chunk i+1 must have landed before anybody reads it; chunks i+2, i+3 may stay in flight
-    if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    if (more) asm volatile(GPG_VMCNT_STEADY ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    GPG_T(s3)
     __builtin_amdgcn_s_barrier();
+    GPG_T(s4)
+#ifdef GPG_STAMP
+    t_issue += s1 - s0; t_comp += s2 - s1; t_wait += s3 - s2; t_bar += s4 - s3;
+#endif
     stage = stage + 1 == S ? 0 : stage + 1;
   }
+#ifdef GPG_STAMP
+  if (lane == 0 && blockIdx.x < 4096 && g_stamp_buf != nullptr) {
+    unsigned long long* o = g_stamp_buf + ((size_t)blockIdx.x * 4 + w) * 4;
+    const unsigned long long tc1 = __builtin_amdgcn_s_memtime(), tr1 = __builtin_amdgcn_s_memrealtime();
+    o[0] = t_issue; o[1] = t_comp; o[2] = tc1 - tc0; o[3] = tr1 - tr0;
+  }
+#endif
 #undef GPG_DMA_ISSUE
 #undef GPG_DMA_COMPUTE
 
@@ -404,9 +570,14 @@ void launch_gemm(gpg_ctx* c, double* C, int ldc, const double* A, int lda, const
                  int K, int lower, int skipM = 0, int skipN = 0) {
   if (M <= 0 || Nc <= 0 || K <= 0) return;
   dim3 grid((M + BM - 1) / BM, Nc / BN);
+  if (BM == 128 && BN == 128 && c->gemm_impl == 2) {
+    hipLaunchKernelGGL(gemm_reg_kernel, grid, dim3(256), 0, c->stream, C, ldc, A, lda, B, ldb, M, Nc, K, lower, skipM,
+                       skipN, (const int*)nullptr, 0);
+    return;
+  }
   if (BM == 128 && BN == 128 && c->gemm_impl == 1) {
     hipLaunchKernelGGL(gemm_dma_kernel, grid, dim3(256), 0, c->stream, C, ldc, A, lda, B, ldb, M, Nc, K, lower, skipM,
-                       skipN, (const int*)nullptr, 0);
+                       skipN, (const int*)nullptr, 0, 0);
     return;
   }
   hipLaunchKernelGGL((gemm_nt_minus_kernel<BM, BN>), grid, dim3(256), 0, c->stream, C, ldc, A, lda, B, ldb, M, Nc, K,
@@ -445,9 +616,17 @@ void launch_gemm_trailing(gpg_ctx* c, double* C, int ldc, const double* A, int l
                           int Nc, int K, int skip) {
   const TileMap& tm = get_tilemap(c, (M + 127) / 128, Nc / 128, skip / 128);
   if (tm.n <= 0) return;
-  if (c->gemm_impl == 1) {
-    hipLaunchKernelGGL(gemm_dma_kernel, dim3(tm.n), dim3(256), 0, c->stream, C, ldc, A, lda, B, ldb, M, Nc, K, 1, 0, 0,
+  if (c->gemm_impl == 2) {
+    hipLaunchKernelGGL(gemm_reg_kernel, dim3(tm.n), dim3(256), 0, c->stream, C, ldc, A, lda, B, ldb, M, Nc, K, 1, 0, 0,
                        (const int*)tm.dev, tm.n);
+    return;
+  }
+  if (c->gemm_impl == 1) {
+    // one tile takes ~ K / 256 * 55 us when two workgroups share a CU (100 MHz ticks); only worth it when
+    // the launch runs for several rounds of 512 workgroups
+    const int stagger = (c->gemm_stagger && tm.n >= 4 * 512) ? (int)(5500.0 * K / 256.0) : 0;
+    hipLaunchKernelGGL(gemm_dma_kernel, dim3(tm.n), dim3(256), 0, c->stream, C, ldc, A, lda, B, ldb, M, Nc, K, 1, 0, 0,
+                       (const int*)tm.dev, tm.n, stagger);
     return;
   }
   hipLaunchKernelGGL((gemm_nt_minus_kernel<128, 128>), dim3(tm.n), dim3(256), 0, c->stream, C, ldc, A, lda, B, ldb, M, Nc,

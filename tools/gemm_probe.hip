@@ -9,6 +9,7 @@ int main(int argc, char** argv) {
   int Nt = argc > 1 ? atoi(argv[1]) : 16384, K = argc > 2 ? atoi(argv[2]) : 256, impl = argc > 3 ? atoi(argv[3]) : 1;
   gpg_ctx c;
   c.gemm_impl = impl;
+  c.gemm_stagger = 0;
   hipStreamCreate(&c.stream);
   int ld = Nt + 128;
   double *C, *P;
@@ -20,6 +21,19 @@ int main(int argc, char** argv) {
   hipMemcpy(P, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice);
   hipMemset(C, 0, sizeof(double) * (size_t)ld * Nt);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  {
+    int nb = -1;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_dma_kernel, 256, 0);
+    hipFuncAttributes fa; hipFuncGetAttributes(&fa, (const void*)gemm_dma_kernel);
+    printf("gemm_dma_kernel: occupancy API %d blocks/CU, regs %d, static LDS %zu B\n", nb, fa.numRegs, fa.sharedSizeBytes);
+  }
+#ifdef GPG_STAMP
+  unsigned long long* dbuf = nullptr;
+  if (hipMalloc(&dbuf, 4096 * 16 * 8) != hipSuccess || dbuf == nullptr) { printf("stamp buffer alloc failed\n"); return 1; }
+  hipMemset(dbuf, 0, 4096 * 16 * 8);
+  if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &dbuf, sizeof(dbuf)) != hipSuccess) { printf("symbol copy failed\n"); return 1; }
+  hipDeviceSynchronize();
+#endif
   for (int rep = 0; rep < 3; ++rep) launch_gemm_trailing(&c, C, ld, P, ld, P, ld, ld, Nt, K, 0);
   hipStreamSynchronize(c.stream);
   const int reps = 10;
@@ -29,6 +43,19 @@ int main(int argc, char** argv) {
   hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   double fl = (double)Nt * (Nt + 1.0) * K * reps;
+#ifdef GPG_STAMP
+  {
+    hipMemset(dbuf, 0, 4096 * 16 * 8);
+    launch_gemm_trailing(&c, C, ld, P, ld, P, ld, ld, Nt, K, 0);
+    hipStreamSynchronize(c.stream);
+    std::vector<unsigned long long> hb(4096 * 16);
+    hipMemcpy(hb.data(), dbuf, hb.size() * 8, hipMemcpyDeviceToHost);
+    double sum[4] = {0, 0, 0, 0}; int nw = 0;
+    for (int b = 0; b < 4096; ++b) for (int w = 0; w < 4; ++w) { const unsigned long long* o = &hb[(b * 4 + w) * 4]; if (o[1] == 0) continue; ++nw; for (int q = 0; q < 4; ++q) sum[q] += (double)o[q]; }
+    printf("stamps over %d waves: issue %.0f + compute %.0f cycles per chunk; main loop %.0f cycles = %.2f us per tile -> held clock %.3f GHz\n", nw,
+           sum[0] / nw / (K / 8), sum[1] / nw / (K / 8), sum[2] / nw, sum[3] / nw * 0.01, (sum[2] / nw) / (sum[3] / nw * 10.0));
+  }
+#endif
   printf("Nt=%d K=%d impl=%d: %.3f ms/launch, %.2f TFLOP/s (algorithmic, lower triangle)\n", Nt, K, impl, ms / reps, fl / ms * 1e-9);
   return 0;
 }
