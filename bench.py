@@ -96,7 +96,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n", type=int, default=2000)
     ap.add_argument("--d", type=int, default=8)
-    ap.add_argument("--panel", type=int, default=0, help="outer panel width override")
+    ap.add_argument("--panel", type=int, default=0, help="panel width override")
+    ap.add_argument("--super", type=int, default=0, dest="superp", help="super-panel width override")
     ap.add_argument("--lookahead", type=int, default=-1, help="1/0 force the two-stream look-ahead on/off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-all", action="store_true", help="time every kernel category (adds event overhead)")
@@ -126,8 +127,8 @@ def main():
     N = n * (d + 1)
     GP = gpgradpy_amd.GaussianProcess(d, True, "SqExp", "precon", device=local_rank)
     GP.set_data(X, f, np.zeros(n), g, np.zeros((n, d)))          # resident in HBM before the timed region
-    if args.panel:
-        GP.set_panel(args.panel)
+    if args.panel or args.superp:
+        GP.set_panel(args.panel or 256, args.superp)
     if args.lookahead >= 0:
         GP.set_lookahead(args.lookahead)
 

@@ -372,8 +372,13 @@ int gpg_set_lookahead(gpg_ctx* c, int on) {
 
 int gpg_set_panel(gpg_ctx* c, int nb_outer) {
   if (!c) return -1;
-  if (nb_outer < 128 || nb_outer > 1024 || nb_outer % 128) { c->err = "nb_outer must be a multiple of 128 in [128, 1024]"; return -1; }
-  c->nb_outer = nb_outer;
+  // nb_outer = panel + 65536 * super-panel (super-panel 0 keeps the current one)
+  const int nb = nb_outer & 0xffff, sb = nb_outer >> 16;
+  if (nb < 128 || nb > 1024 || nb % 128) { c->err = "panel width must be a multiple of 128 in [128, 1024]"; return -1; }
+  if (sb != 0 && (sb < nb || sb % nb || sb > 8192)) { c->err = "super-panel width must be a multiple of the panel width, <= 8192"; return -1; }
+  c->nb_outer = nb;
+  if (sb) c->nb_super = sb;
+  if (c->nb_super < nb || c->nb_super % nb) c->nb_super = nb;
   return 0;
 }
 

@@ -52,8 +52,8 @@ __global__ void __launch_bounds__(64) potrf64_kernel(double* __restrict__ A, int
     for (int c = 0; c < 16; ++c) {
       const double ajj = readlane_d(a[c], 16 * s + c);
       bad = (bad == 0 && !(ajj > 0.0)) ? 16 * s + c + 1 : bad;   // first non-positive / NaN pivot (LAPACK info)
-      const double dj = sqrt(ajj);
-      const double inv = 1.0 / dj;
+      const double inv = rsqrt(ajj);     // reciprocal pivot first: one short dependent chain per column
+      const double dj = ajj * inv;        // sqrt(ajj) to ~1 ulp
       a[c] = (i == 16 * s + c) ? dj : a[c] * inv;
       if (i == 0) dinv[j0 + 16 * s + c] = inv;   // reciprocal pivots for the panel solves
 #pragma unroll
@@ -659,8 +659,8 @@ static void factor_diag_block(gpg_ctx* c, int k0, int k1) {
       gpg_prof_begin(c, GPG_PROF_POTRF, (double)rows * 64.0 * 64.0);
       hipLaunchKernelGGL(trsm64_kernel, dim3((rows + 63) / 64), dim3(256), 0, c->stream, A + (size_t)j0 + (size_t)j0 * ld,
                          ld, c->dinv + j0, A + (size_t)j1 + (size_t)j0 * ld, ld, rows);
-      launch_gemm<128, 64>(c, A + (size_t)j1 + (size_t)j1 * ld, ld, A + (size_t)j1 + (size_t)j0 * ld, ld,
-                           A + (size_t)j1 + (size_t)j0 * ld, ld, rows, rows, GPG_NBI, 1);
+      launch_gemm<64, 64>(c, A + (size_t)j1 + (size_t)j1 * ld, ld, A + (size_t)j1 + (size_t)j0 * ld, ld,
+                          A + (size_t)j1 + (size_t)j0 * ld, ld, rows, rows, GPG_NBI, 1);
       gpg_prof_end(c);
     }
   }
@@ -689,6 +689,7 @@ static void solve_below_block(gpg_ctx* c, int k0, int k1) {
 
 void gpg_cholesky(gpg_ctx* c) {
   const int ld = c->ld, Npad = c->Npad, NB = c->nb_outer;
+  const int SB = (c->nb_super / NB > 0 ? c->nb_super / NB : 1) * NB;   // super-panel = whole number of panels
   double* A = c->A;
   hipStream_t sM = c->stream, sD = c->lookahead ? c->stream_upd : c->stream;
   const bool two = (sD != sM);
@@ -703,37 +704,50 @@ void gpg_cholesky(gpg_ctx* c) {
   // D_0 follows the assembly on the main stream
   c->stream = sM;
   factor_diag_block(c, 0, NB < Npad ? NB : Npad);
-  for (int k0 = 0, p = 0; k0 < Npad; k0 += NB, ++p) {
-    const int nbw = (Npad - k0) < NB ? (Npad - k0) : NB;
-    const int k1 = k0 + nbw;
-    c->stream = sM;
-    if (two && p > 0) (void)hipStreamWaitEvent(sM, c->ev_panel[p], 0);
-    solve_below_block(c, k0, k1);                                   // B_p (also carries the RHS rows)
-    if (k1 >= Npad) break;
-    const int k2 = (k1 + NB < Npad) ? k1 + NB : Npad;               // next diagonal block = [k1, k2)
-    const double* Ap = A + (size_t)k0 * ld;
-    const double w = (double)(k2 - k1), nt = (double)(Npad - k1);
-    if (two) {
-      (void)hipEventRecord(c->ev_upd[p], sM);
-      // diag stream: next diagonal block -= panel rows [k1,k2) (panel p), then D_(p+1)
-      c->stream = sD;
-      (void)hipStreamWaitEvent(sD, c->ev_upd[p], 0);
-      gpg_prof_begin(c, GPG_PROF_POTRF, w * (w + 1.0) * (double)nbw);
-      launch_gemm<128, 128>(c, A + (size_t)k1 + (size_t)k1 * ld, ld, Ap + k1, ld, Ap + k1, ld, k2 - k1, k2 - k1, nbw, 1);
-      gpg_prof_end(c);
-      factor_diag_block(c, k1, k2);
-      (void)hipEventRecord(c->ev_panel[p + 1], sD);
-      // main stream: the rest of the trailing update
+  int p = 0;
+  for (int s0 = 0; s0 < Npad; s0 += SB) {
+    const int s1 = (s0 + SB < Npad) ? s0 + SB : Npad;             // super-panel = columns [s0, s1)
+    for (int k0 = s0; k0 < s1; k0 += NB, ++p) {
+      const int k1 = (k0 + NB < s1) ? k0 + NB : s1;                // panel p = columns [k0, k1)
       c->stream = sM;
-      gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, (nt * (nt + 1.0) - w * (w + 1.0)) * (double)nbw);
-      launch_gemm_trailing(c, A + (size_t)k1 + (size_t)k1 * ld, ld, Ap + k1, ld, Ap + k1, ld, ld - k1, Npad - k1, nbw,
-                           k2 - k1);
-      gpg_prof_end(c);
-    } else {
-      gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, nt * (nt + 1.0) * (double)nbw);
-      launch_gemm_trailing(c, A + (size_t)k1 + (size_t)k1 * ld, ld, Ap + k1, ld, Ap + k1, ld, ld - k1, Npad - k1, nbw, 0);
-      gpg_prof_end(c);
-      factor_diag_block(c, k1, k2);
+      if (two && p > 0) (void)hipStreamWaitEvent(sM, c->ev_panel[p], 0);
+      solve_below_block(c, k0, k1);                                 // B_p (also carries the RHS rows)
+      if (k1 >= Npad) break;
+      const int k2 = (k1 + NB < Npad) ? k1 + NB : Npad;             // next diagonal block = [k1, k2)
+      // Two-level blocking: inside a super-panel the update with panel p only reaches the remaining
+      // columns of the super-panel (K = panel width); everything right of the super-panel is updated
+      // once per super-panel with K = super-panel width, which divides the C read+write traffic of the
+      // far region by SB / NB.
+      const bool far = (k1 == s1);
+      const int kc0 = far ? s0 : k0;                                // first column of the A operand
+      const int K = k1 - kc0;
+      const int cend = far ? Npad : s1;                             // update columns [k1, cend)
+      const double* Ap = A + (size_t)kc0 * ld;
+      const double w = (double)(k2 - k1), wc = (double)(cend - k1), nt = (double)(Npad - k1);
+      const double flops_all = 2.0 * (double)K * (wc * nt - wc * (wc - 1.0) / 2.0);   // lower trapezoid
+      const double flops_diag = w * (w + 1.0) * (double)K;
+      if (two) {
+        (void)hipEventRecord(c->ev_upd[p], sM);
+        // diag stream: next diagonal block -= its rows of the A operand, then D_(p+1)
+        c->stream = sD;
+        (void)hipStreamWaitEvent(sD, c->ev_upd[p], 0);
+        gpg_prof_begin(c, GPG_PROF_POTRF, flops_diag);
+        launch_gemm<64, 64>(c, A + (size_t)k1 + (size_t)k1 * ld, ld, Ap + k1, ld, Ap + k1, ld, k2 - k1, k2 - k1, K, 1);
+        gpg_prof_end(c);
+        factor_diag_block(c, k1, k2);
+        (void)hipEventRecord(c->ev_panel[p + 1], sD);
+        // main stream: the rest of the update
+        c->stream = sM;
+        gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, flops_all - flops_diag);
+        launch_gemm_trailing(c, A + (size_t)k1 + (size_t)k1 * ld, ld, Ap + k1, ld, Ap + k1, ld, ld - k1, cend - k1, K,
+                             k2 - k1);
+        gpg_prof_end(c);
+      } else {
+        gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, flops_all);
+        launch_gemm_trailing(c, A + (size_t)k1 + (size_t)k1 * ld, ld, Ap + k1, ld, Ap + k1, ld, ld - k1, cend - k1, K, 0);
+        gpg_prof_end(c);
+        factor_diag_block(c, k1, k2);
+      }
     }
   }
   c->stream = sM;

@@ -36,7 +36,8 @@ struct gpg_ctx {
   std::map<unsigned long long, TileMap> tilemaps;   // live-tile lists of the trailing updates, per shape
   int n = 0, d = 0, use_grad = 0, kernel = 0;
   int N = 0, Npad = 0, R = GPG_RHS_ROWS, ld = 0;
-  int nb_outer = 256;
+  int nb_outer = 256;   // panel width
+  int nb_super = 256;   // super-panel width of the two-level trailing update (== nb_outer: single level; measured best)
   // device buffers
   double* A = nullptr;       // [ld x Npad] column-major; lower triangle + RHS rows
   double* Xt = nullptr;      // [d x n]   (coordinate-major copy of x for coalesced loads)

@@ -131,7 +131,8 @@ int gpg_prof_enable(gpg_ctx* ctx, unsigned mask);
 int gpg_prof_read(gpg_ctx* ctx, double ms[GPG_PROF_NCAT], long long count[GPG_PROF_NCAT],
                   double work[GPG_PROF_NCAT]);
 
-/* Tuning knobs (defaults are the measured best): outer panel width (multiple of 128 in [128, 1024]). */
+/* Tuning knobs (defaults are the measured best): nb_outer = panel width (multiple of 128 in
+ * [128, 1024]) + 65536 * super-panel width (multiple of the panel width; 0 = keep). */
 int gpg_set_panel(gpg_ctx* ctx, int nb_outer);
 /* 1 (default): two-stream look-ahead Cholesky (next panel factorised under the trailing update);
  * 0: single stream. */
