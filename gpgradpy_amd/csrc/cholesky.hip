@@ -404,11 +404,12 @@ __device__ unsigned long long* g_stamp_buf;
 #define GPG_T(var)
 #endif
 
+template <int S>
 __global__ void __launch_bounds__(256, 2)
 gemm_dma_kernel(double* __restrict__ C, int ldc, const double* __restrict__ A, int lda, const double* __restrict__ B,
                 int ldb, int M, int Nc, int K, int lower, int skipM, int skipN, const int* __restrict__ tilemap,
                 int ntiles, int stagger_ticks) {
-  constexpr int BM = 128, BN = 128, KB = 8, S = 4;
+  constexpr int BM = 128, BN = 128, KB = 8;
   constexpr int ROW = 144;                 // doubles per LDS k-row (128 + 16 pad: conflict-free ds_read_b64)
   constexpr int STAGE = 2 * KB * ROW;      // A rows then B rows
   __shared__ __attribute__((aligned(16))) double smem[S * STAGE];
@@ -509,12 +510,12 @@ gemm_dma_kernel(double* __restrict__ C, int ldc, const double* __restrict__ A, i
 #pragma unroll
   for (int st = 0; st < S - 1; ++st)
     if (st < nchunk) GPG_DMA_ISSUE(st)
-#ifdef GPG_ABLATE_DMAB
-#define GPG_VMCNT_STEADY "s_waitcnt vmcnt(4)"
-#else
-#define GPG_VMCNT_STEADY "s_waitcnt vmcnt(8)"
-#endif
-  if (nchunk >= S - 1) asm volatile(GPG_VMCNT_STEADY ::: "memory");
+  // steady state: chunk i+1 must have landed, the S-2 younger chunks (4 DMAs per wave each) may fly on
+#define GPG_WAIT_STEADY()                                            \
+  if (S == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");       \
+  else if (S == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  \
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (nchunk >= S - 1) { GPG_WAIT_STEADY() }
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
@@ -535,7 +536,7 @@ gemm_dma_kernel(double* __restrict__ C, int ldc, const double* __restrict__ A, i
     GPG_DMA_COMPUTE(stage)
     GPG_T(s2)
     // chunk i+1 must have landed before anybody reads it; chunks i+2, i+3 may stay in flight
-    if (more) asm volatile(GPG_VMCNT_STEADY ::: "memory");
+    if (more) { GPG_WAIT_STEADY() }
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     GPG_T(s3)
     __builtin_amdgcn_s_barrier();
@@ -554,6 +555,7 @@ gemm_dma_kernel(double* __restrict__ C, int ldc, const double* __restrict__ A, i
 #endif
 #undef GPG_DMA_ISSUE
 #undef GPG_DMA_COMPUTE
+#undef GPG_WAIT_STEADY
 
   if (wave_active) {
 #pragma unroll
@@ -576,7 +578,7 @@ void launch_gemm(gpg_ctx* c, double* C, int ldc, const double* A, int lda, const
     return;
   }
   if (BM == 128 && BN == 128 && c->gemm_impl == 1) {
-    hipLaunchKernelGGL(gemm_dma_kernel, grid, dim3(256), 0, c->stream, C, ldc, A, lda, B, ldb, M, Nc, K, lower, skipM,
+    hipLaunchKernelGGL(gemm_dma_kernel<4>, grid, dim3(256), 0, c->stream, C, ldc, A, lda, B, ldb, M, Nc, K, lower, skipM,
                        skipN, (const int*)nullptr, 0, 0);
     return;
   }
@@ -625,8 +627,15 @@ void launch_gemm_trailing(gpg_ctx* c, double* C, int ldc, const double* A, int l
     // one tile takes ~ K / 256 * 55 us when two workgroups share a CU (100 MHz ticks); only worth it when
     // the launch runs for several rounds of 512 workgroups
     const int stagger = (c->gemm_stagger && tm.n >= 4 * 512) ? (int)(5500.0 * K / 256.0) : 0;
-    hipLaunchKernelGGL(gemm_dma_kernel, dim3(tm.n), dim3(256), 0, c->stream, C, ldc, A, lda, B, ldb, M, Nc, K, 1, 0, 0,
-                       (const int*)tm.dev, tm.n, stagger);
+    if (c->gemm_ring == 2)
+      hipLaunchKernelGGL(gemm_dma_kernel<2>, dim3(tm.n), dim3(256), 0, c->stream, C, ldc, A, lda, B, ldb, M, Nc, K, 1, 0, 0,
+                         (const int*)tm.dev, tm.n, stagger);
+    else if (c->gemm_ring == 3)
+      hipLaunchKernelGGL(gemm_dma_kernel<3>, dim3(tm.n), dim3(256), 0, c->stream, C, ldc, A, lda, B, ldb, M, Nc, K, 1, 0, 0,
+                         (const int*)tm.dev, tm.n, stagger);
+    else
+      hipLaunchKernelGGL(gemm_dma_kernel<4>, dim3(tm.n), dim3(256), 0, c->stream, C, ldc, A, lda, B, ldb, M, Nc, K, 1, 0, 0,
+                         (const int*)tm.dev, tm.n, stagger);
     return;
   }
   hipLaunchKernelGGL((gemm_nt_minus_kernel<128, 128>), dim3(tm.n), dim3(256), 0, c->stream, C, ldc, A, lda, B, ldb, M, Nc,

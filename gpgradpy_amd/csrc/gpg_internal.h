@@ -31,6 +31,7 @@ struct gpg_ctx {
   hipStream_t stream_upd = nullptr;  // high-priority stream: look-ahead factorisation of the next diagonal block
   int lookahead = 1;
   int gemm_stagger = 0;              // de-phase the first round of trailing-update workgroups
+  int gemm_ring = 4;                 // LDS ring depth of the DMA kernel (4: 2 workgroups/CU, 2: 3 workgroups/CU)
   int gemm_impl = 1;                 // 1: LDS-DMA ring kernel for the 128x128 updates, 0: register-staged kernel
   std::vector<hipEvent_t> ev_panel, ev_upd;
   std::map<unsigned long long, TileMap> tilemaps;   // live-tile lists of the trailing updates, per shape
