@@ -138,8 +138,10 @@ int gpg_create(gpg_ctx** out, int device, int n_eval, int dim, int use_grad, int
   {
     int prio_lo = 0, prio_hi = 0;
     CREATE_OK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));   // numerically lowest = highest priority
-    CREATE_OK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_lo));
+    const int prio_mid = (prio_lo + prio_hi) / 2;
+    CREATE_OK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_mid));
     CREATE_OK(hipStreamCreateWithPriority(&c->stream_upd, hipStreamNonBlocking, prio_hi));
+    CREATE_OK(hipStreamCreateWithPriority(&c->stream_bulk, hipStreamNonBlocking, prio_lo));
   }
   CREATE_OK(hipMalloc(&c->A, sizeof(double) * (size_t)c->ld * c->Npad));
   CREATE_OK(hipMalloc(&c->Xt, sizeof(double) * (size_t)c->n * c->d));
@@ -162,6 +164,7 @@ void gpg_destroy(gpg_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->stream_upd) (void)hipStreamSynchronize(c->stream_upd);
+  if (c->stream_bulk) (void)hipStreamSynchronize(c->stream_bulk);
   for (auto& pe : c->prof_pending) { (void)hipEventDestroy(pe.e0); (void)hipEventDestroy(pe.e1); }
   for (auto& ev : c->prof_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   double* bufs[] = {c->A, c->Xt, c->y, c->noise, c->dvec, c->invp, c->zvec, c->tmpv, c->dinv, c->scal, c->Wt, c->xq_dev,
@@ -173,6 +176,8 @@ void gpg_destroy(gpg_ctx* c) {
   for (auto& kv : c->tilemaps) if (kv.second.dev) (void)hipFree(kv.second.dev);
   for (auto e : c->ev_panel) (void)hipEventDestroy(e);
   for (auto e : c->ev_upd) (void)hipEventDestroy(e);
+  for (auto e : c->ev_bulk) (void)hipEventDestroy(e);
+  if (c->stream_bulk) (void)hipStreamDestroy(c->stream_bulk);
   if (c->stream_upd) (void)hipStreamDestroy(c->stream_upd);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -364,7 +369,7 @@ int gpg_prof_read(gpg_ctx* c, double ms[GPG_PROF_NCAT], long long count[GPG_PROF
 
 int gpg_set_lookahead(gpg_ctx* c, int on) {
   if (!c) return -1;
-  c->lookahead = (on & 1) ? 1 : 0;
+  c->lookahead = (on & 8) ? 2 : ((on & 1) ? 1 : 0);   // 8: full look-ahead over three streams
   c->gemm_impl = (on & 2) ? 0 : 1;   // bit 1: fall back to the register-staged 128x128 kernel (A/B runs)
   c->gemm_stagger = (on & 4) ? 1 : 0; // bit 2: first-round de-phasing of the trailing-update workgroups (measured: no gain)
   return 0;

@@ -533,7 +533,13 @@ gemm_dma_kernel(double* __restrict__ C, int ldc, const double* __restrict__ A, i
       GPG_DMA_ISSUE(st)
     }
     GPG_T(s1)
+#ifdef GPG_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
     GPG_DMA_COMPUTE(stage)
+#ifdef GPG_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     GPG_T(s2)
     // chunk i+1 must have landed before anybody reads it; chunks i+2, i+3 may stay in flight
     if (more) { GPG_WAIT_STEADY() }
@@ -619,7 +625,7 @@ void launch_gemm_trailing(gpg_ctx* c, double* C, int ldc, const double* A, int l
   const TileMap& tm = get_tilemap(c, (M + 127) / 128, Nc / 128, skip / 128);
   if (tm.n <= 0) return;
   if (c->gemm_impl == 2) {
-    hipLaunchKernelGGL(gemm_reg_kernel, dim3(tm.n), dim3(256), 0, c->stream, C, ldc, A, lda, B, ldb, M, Nc, K, 1, 0, 0,
+    hipLaunchKernelGGL(gemm_reg_kernel, dim3(tm.n), dim3(256), c->dyn_lds_ballast, c->stream, C, ldc, A, lda, B, ldb, M, Nc, K, 1, 0, 0,
                        (const int*)tm.dev, tm.n);
     return;
   }
@@ -634,7 +640,7 @@ void launch_gemm_trailing(gpg_ctx* c, double* C, int ldc, const double* A, int l
       hipLaunchKernelGGL(gemm_dma_kernel<3>, dim3(tm.n), dim3(256), 0, c->stream, C, ldc, A, lda, B, ldb, M, Nc, K, 1, 0, 0,
                          (const int*)tm.dev, tm.n, stagger);
     else
-      hipLaunchKernelGGL(gemm_dma_kernel<4>, dim3(tm.n), dim3(256), 0, c->stream, C, ldc, A, lda, B, ldb, M, Nc, K, 1, 0, 0,
+      hipLaunchKernelGGL(gemm_dma_kernel<4>, dim3(tm.n), dim3(256), c->dyn_lds_ballast, c->stream, C, ldc, A, lda, B, ldb, M, Nc, K, 1, 0, 0,
                          (const int*)tm.dev, tm.n, stagger);
     return;
   }
@@ -696,7 +702,78 @@ static void solve_below_block(gpg_ctx* c, int k0, int k1) {
   }
 }
 
+// lookahead == 2 ("full" look-ahead, three streams):
+//   panel stream sM : [wait D_p] B_p, [wait U_(p-1)^rest] U_p^LA (columns of panel p+1 only), B_(p+1), ...
+//   diag  stream sD : [wait B_p, U_(p-1)^rest] update of the next diagonal block with panel p, D_(p+1)
+//   bulk  stream sU : [wait B_p] U_p^rest (columns right of panel p+1)          <- the MFMA bulk
+// so that the latency-bound panel work (B, D) runs under the bulk update of the previous panel.
+static void cholesky_full_lookahead(gpg_ctx* c) {
+  const int ld = c->ld, Npad = c->Npad, NB = c->nb_outer;
+  double* A = c->A;
+  hipStream_t sM = c->stream, sD = c->stream_upd, sU = c->stream_bulk;
+  const int npanel = (Npad + NB - 1) / NB;
+  while ((int)c->ev_panel.size() < npanel + 1) {
+    hipEvent_t e1, e2;
+    (void)hipEventCreateWithFlags(&e1, hipEventDisableTiming);
+    (void)hipEventCreateWithFlags(&e2, hipEventDisableTiming);
+    c->ev_panel.push_back(e1);
+    c->ev_upd.push_back(e2);
+  }
+  while ((int)c->ev_bulk.size() < npanel + 1) {
+    hipEvent_t e;
+    (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    c->ev_bulk.push_back(e);
+  }
+  c->stream = sM;
+  factor_diag_block(c, 0, NB < Npad ? NB : Npad);
+  int last_bulk = -1;
+  int p = 0;
+  for (int k0 = 0; k0 < Npad; k0 += NB, ++p) {
+    const int k1 = (k0 + NB < Npad) ? k0 + NB : Npad;
+    c->stream = sM;
+    if (p > 0) (void)hipStreamWaitEvent(sM, c->ev_panel[p], 0);       // D_p done
+    solve_below_block(c, k0, k1);                                     // B_p
+    if (k1 >= Npad) break;
+    (void)hipEventRecord(c->ev_upd[p], sM);                           // eB_p
+    const int k2 = (k1 + NB < Npad) ? k1 + NB : Npad;
+    const int K = k1 - k0;
+    const double* Ap = A + (size_t)k0 * ld;
+    const double w = (double)(k2 - k1), nt = (double)(Npad - k1);
+    // --- diag stream: next diagonal block, then D_(p+1)
+    c->stream = sD;
+    (void)hipStreamWaitEvent(sD, c->ev_upd[p], 0);
+    if (last_bulk >= 0) (void)hipStreamWaitEvent(sD, c->ev_bulk[last_bulk], 0);
+    gpg_prof_begin(c, GPG_PROF_POTRF, w * (w + 1.0) * (double)K);
+    launch_gemm<64, 64>(c, A + (size_t)k1 + (size_t)k1 * ld, ld, Ap + k1, ld, Ap + k1, ld, k2 - k1, k2 - k1, K, 1);
+    gpg_prof_end(c);
+    factor_diag_block(c, k1, k2);
+    (void)hipEventRecord(c->ev_panel[p + 1], sD);
+    // --- bulk stream: everything right of panel p+1
+    if (k2 < Npad) {
+      c->stream = sU;
+      (void)hipStreamWaitEvent(sU, c->ev_upd[p], 0);
+      const double ntr = (double)(Npad - k2);
+      gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, ntr * (ntr + 1.0) * (double)K);
+      launch_gemm_trailing(c, A + (size_t)k2 + (size_t)k2 * ld, ld, Ap + k2, ld, Ap + k2, ld, ld - k2, Npad - k2, K, 0);
+      gpg_prof_end(c);
+    }
+    // --- panel stream: look-ahead update of panel p+1's columns (diag block excluded)
+    c->stream = sM;
+    if (last_bulk >= 0) (void)hipStreamWaitEvent(sM, c->ev_bulk[last_bulk], 0);
+    gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, 2.0 * (double)K * (w * nt - w * (w - 1.0) / 2.0) - w * (w + 1.0) * (double)K);
+    launch_gemm_trailing(c, A + (size_t)k1 + (size_t)k1 * ld, ld, Ap + k1, ld, Ap + k1, ld, ld - k1, k2 - k1, K, k2 - k1);
+    gpg_prof_end(c);
+    if (k2 < Npad) {
+      (void)hipEventRecord(c->ev_bulk[p], sU);
+      last_bulk = p;
+    }
+  }
+  c->stream = sM;
+  if (last_bulk >= 0) (void)hipStreamWaitEvent(sM, c->ev_bulk[last_bulk], 0);
+}
+
 void gpg_cholesky(gpg_ctx* c) {
+  if (c->lookahead == 2) { cholesky_full_lookahead(c); return; }
   const int ld = c->ld, Npad = c->Npad, NB = c->nb_outer;
   const int SB = (c->nb_super / NB > 0 ? c->nb_super / NB : 1) * NB;   // super-panel = whole number of panels
   double* A = c->A;

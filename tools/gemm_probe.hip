@@ -8,6 +8,7 @@ void gpg_prof_end(gpg_ctx*) {}
 int main(int argc, char** argv) {
   int Nt = argc > 1 ? atoi(argv[1]) : 16384, K = argc > 2 ? atoi(argv[2]) : 256, impl = argc > 3 ? atoi(argv[3]) : 1;
   gpg_ctx c;
+  c.dyn_lds_ballast = argc > 4 ? atoi(argv[4]) : 0;
   c.gemm_impl = impl & 3;
   c.gemm_stagger = 0;
   c.gemm_ring = (impl >> 2) ? (impl >> 2) : 4;   // impl = 1 + 4 * ring
