@@ -34,9 +34,10 @@ HBM_PEAK_GBS = 8000.0
 PMC_TRAFFIC_BYTES_PER_LAUNCH_CFG3 = (2 * 27.69e9 + 30.94e9) / 70.0
 
 
-def make_workload(n, d):
+def make_workload(n, d, cfg="cfg3"):
     """BASELINE.md section 3 synthetic inputs: X ~ U(-2,2)^(n x d) seed 0, Rosenbrock(a=10) values + gradients,
-    restart table default_rng(1).uniform(-2.5, -0.5, (64, d)) = log10 theta."""
+    restart table default_rng(1).uniform(-2.5, -0.5, (64, d)) = log10 theta (cfg2/3/4); cfg5: rows
+    [log10 theta ~ U(-3,-1)^d, log10 varK ~ U(-1,1)] seed 2 with known noise std_f = 1e-2, std_g = 1e-1."""
     rng = np.random.default_rng(0)
     X = rng.uniform(-2.0, 2.0, (n, d))
     f = np.zeros(n)
@@ -47,7 +48,11 @@ def make_workload(n, d):
         f += a * t ** 2 + (1 - X[:, k]) ** 2
         g[:, k] += -4 * a * X[:, k] * t - 2 * (1 - X[:, k])
         g[:, k + 1] += 2 * a * t
-    hp_table = np.random.default_rng(1).uniform(-2.5, -0.5, (64, d))
+    if cfg == "cfg5":
+        rng2 = np.random.default_rng(2)
+        hp_table = np.hstack((rng2.uniform(-3.0, -1.0, (64, d)), rng2.uniform(-1.0, 1.0, (64, 1))))
+    else:
+        hp_table = np.random.default_rng(1).uniform(-2.5, -0.5, (64, d))
     return X, f, g, hp_table
 
 
@@ -99,8 +104,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--n", type=int, default=2000)
-    ap.add_argument("--d", type=int, default=8)
+    ap.add_argument("--config", default="cfg3", choices=["cfg2", "cfg3", "cfg5"],
+                    help="BASELINE.json config: cfg2 n=500 d=4 SqExp, cfg3 n=2000 d=8 SqExp (headline), cfg5 n=4000 d=16 Ma5f2 noisy")
+    ap.add_argument("--n", type=int, default=0)
+    ap.add_argument("--d", type=int, default=0)
     ap.add_argument("--panel", type=int, default=0, help="panel width override")
     ap.add_argument("--super", type=int, default=0, dest="superp", help="super-panel width override")
     ap.add_argument("--lookahead", type=int, default=-1, help="1/0 force the two-stream look-ahead on/off")
@@ -127,11 +134,16 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    n, d = args.n, args.d
-    X, f, g, hp_table = make_workload(n, d)
+    n0, d0 = {"cfg2": (500, 4), "cfg3": (2000, 8), "cfg5": (4000, 16)}[args.config]
+    n, d = args.n or n0, args.d or d0
+    kernel = "Ma5f2" if args.config == "cfg5" else "SqExp"
+    X, f, g, hp_table = make_workload(n, d, args.config)
     N = n * (d + 1)
-    GP = gpgradpy_amd.GaussianProcess(d, True, "SqExp", "precon", device=local_rank)
-    GP.set_data(X, f, np.zeros(n), g, np.zeros((n, d)))          # resident in HBM before the timed region
+    GP = gpgradpy_amd.GaussianProcess(d, True, kernel, "precon", device=local_rank)
+    if args.config == "cfg5":
+        GP.set_data(X, f, np.full(n, 1e-2), g, np.full((n, d), 1e-1))   # known noise -> varK is a hyperparameter
+    else:
+        GP.set_data(X, f, np.zeros(n), g, np.zeros((n, d)))      # resident in HBM before the timed region
     if args.panel or args.superp:
         GP.set_panel(args.panel or 256, args.superp)
     if args.lookahead >= 0:
@@ -178,20 +190,21 @@ def main():
         achieved = tr["work"] / (tr["ms"] * 1e-3) * 1e-12 if tr["ms"] > 0 else 0.0
         asm = prof["assembly"]
         result = {
-            "metric": "marginal-likelihood evals/sec (grad-enh, n=2000 d=8)" if (n, d) == (2000, 8)
-                      else f"marginal-likelihood evals/sec (grad-enh, n={n} d={d})",
+            "metric": "marginal-likelihood evals/sec (grad-enh, n=2000 d=8)" if (n, d, args.config) == (2000, 8, "cfg3")
+                      else f"marginal-likelihood evals/sec (grad-enh, n={n} d={d}, {args.config})",
             "value": world * args.steps / elapsed, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"cfg3: gradient-enhanced SqExp GP, n={n} d={d} (K is {N}x{N}), noise-free, "
-                                   "precon + nugget, value-only likelihood evaluation per restart row "
-                                   "(rows of default_rng(1).uniform(-2.5,-0.5,(64,d)) = log10 theta, 8 per rank)",
-                       "n": n, "d": d, "N": N, "kernel": "SqExp", "wellcond": "precon",
+            "config": {"workload": f"{args.config}: gradient-enhanced {kernel} GP, n={n} d={d} (K is {N}x{N}), "
+                                   + ("known noise on f and grad f (varK a hyperparameter), " if args.config == "cfg5" else "noise-free, ")
+                                   + "precon + nugget, value-only likelihood evaluation per restart row "
+                                   "(rows of the BASELINE.md section 3 restart table, 8 per rank)",
+                       "n": n, "d": d, "N": N, "kernel": kernel, "wellcond": "precon",
                        "evals_per_gpu": args.steps, "parallelism": f"restarts sharded over {world} GPU(s), one all_gather"},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_minus_kernel<128,128> (Cholesky trailing update)",
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                         "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH_CFG3 if (n, d) == (2000, 8) else None,
+                         "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH_CFG3 if (n, d, args.config) == (2000, 8, "cfg3") else None,
                          "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_summary.txt)",
                          "launches": tr["count"], "avg_launch_ms": tr["ms"] / max(1, tr["count"]),
                          "algorithmic_flops": tr["work"],
@@ -202,7 +215,7 @@ def main():
         }
         if args.prof_all:
             result["kernel_ms_per_eval"] = {c: prof[c]["ms"] / args.steps for c in prof}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config == "cfg3":
             theta0 = 10.0 ** hp_table[0]
             cb, r = cpu_baseline(n, d, X, f, g, theta0)
             result["cpu_baseline"] = cb

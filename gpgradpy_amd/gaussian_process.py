@@ -424,8 +424,6 @@ class GaussianProcess:
             raise NotImplementedError('calc_grad=True (likelihood gradient) is not on the accelerated path yet (SURVEY.md 8f1)')
         if calc_cond:
             raise NotImplementedError('calc_cond=True is outside the accelerated path (SURVEY.md 8f4)')
-        if self.lkd_varK_pnlt_use:
-            raise NotImplementedError('lkd_varK_pnlt_use=True is outside the accelerated path')
         noisy = self.b_has_noisy_data
         if noisy:
             assert hp_vals.varK is not None, f'varK is not provided and hp_vals.varK is None, hp_vals = {hp_vals}'
@@ -444,11 +442,22 @@ class GaussianProcess:
         if rc > 0:
             # CalcLkd.py:308-311 / 330-333: the reference reports the SVD condition number here; not computed
             return LkdInfo(cond=np.nan), False
+        ln_lkd = out.ln_lkd
+        if not noisy:
+            ln_lkd -= self.calc_lkd_varK_pnlt(out.varK, self._fval_in)[0]        # CalcLkd.py:162,168
         info = LkdInfo(hp_beta=np.array([out.beta]), hp_varK=None if noisy else out.varK,
                        ln_det_Kmat=out.ln_det if calc_lkd or not noisy else None,
-                       ln_lkd=out.ln_lkd if calc_lkd else None,
+                       ln_lkd=ln_lkd if calc_lkd else None,
                        data_vec=self._data_vec if noisy else None, cond=None)
         return info, True
+
+    def calc_lkd_varK_pnlt(self, varK, fval_vec):
+        # CalcLkd.py:118-133 (noise-free path only, as in the reference: CalcLkd.py:204 leaves the noisy path out)
+        if self.lkd_varK_pnlt_use:
+            var_fval = np.max((np.var(fval_vec), self.lkd_varK_pnlt_lb_var))
+            max_fun = np.max((varK - self.lkd_varK_pnlt_c2 * var_fval, 0))
+            return self.lkd_varK_pnlt_c1 * var_fval * max_fun ** 2, 2 * self.lkd_varK_pnlt_c1 * var_fval * max_fun
+        return 0, 0
 
     def _rows_from_hp_x0(self, hp_x0):
         """Decode optimiser rows (GpHpara.py:56-103) into the C ABI's [theta(d), varK_mat, var_fval, var_fgrad]."""
@@ -481,6 +490,8 @@ class GaussianProcess:
         if rc != 0:
             raise _lib.GpgError(f'gpg_lkd_batch failed ({rc}): {self._err()}')
         ln = np.array([o.ln_lkd if o.info == 0 else np.nan for o in outs])
+        if self.lkd_varK_pnlt_use and not self.b_has_noisy_data:
+            ln = ln - np.array([self.calc_lkd_varK_pnlt(o.varK, self._fval_in)[0] if o.info == 0 else 0.0 for o in outs])
         if return_all:
             return ln, outs
         return ln

@@ -65,7 +65,7 @@ def rosenbrock(x, a=10.0):
 
 def make_case(GaussianProcess, name, n, d, kernel, noise, use_grad=True, wellcond='precon', seed=0,
               theta=None, varK=None, var_fval=None, var_fgrad=None, nq=8, near_dup=False, etaK=None,
-              store_mats=False):
+              store_mats=False, pnlt=None):
     rng = np.random.default_rng(seed)
     x = rng.uniform(-2, 2, (n, d))
     if near_dup and n > 2:
@@ -100,6 +100,9 @@ def make_case(GaussianProcess, name, n, d, kernel, noise, use_grad=True, wellcon
     if etaK is not None:
         GP._etaK = etaK
         GP._eta_Kgrad = etaK
+    if pnlt is not None:                      # varK penalty of CalcLkd.py:118-133 (off by default)
+        GP.lkd_varK_pnlt_use = True
+        GP.lkd_varK_pnlt_c1, GP.lkd_varK_pnlt_c2 = pnlt
 
     noisy = bool(GP.b_has_noisy_data)
     if noisy and varK is None:
@@ -119,7 +122,7 @@ def make_case(GaussianProcess, name, n, d, kernel, noise, use_grad=True, wellcon
                var_fval=np.nan if var_fval is None else var_fval,
                var_fgrad=np.nan if var_fgrad is None else var_fgrad,
                etaK=GP._etaK, b_has_noisy_data=noisy, b_chofac_good=bool(ok), xq=xq,
-               n_data=GP.n_data)
+               n_data=GP.n_data, pnlt=np.array([np.nan, np.nan] if pnlt is None else pnlt))
     if not ok:
         return out
 
@@ -192,6 +195,8 @@ def main():
     # gradient-enhanced with wellcond_mtd='base' (no preconditioner)
     add(name='SqExp_none_n12_d2_base', n=12, d=2, kernel='SqExp', noise='none', wellcond='base', seed=15,
         theta=np.array([0.4, 0.9]), store_mats=True)
+    # varK penalty active (c2 small so that varK > c2 * var(f))
+    add(name='SqExp_none_n17_d4_pnlt', n=17, d=4, kernel='SqExp', noise='none', seed=17, pnlt=(0.7, 1e-6))
     # Cholesky failure: 'base' method, near-duplicate points, tiny nugget -> cho_factor raises
     add(name='SqExp_none_n20_d2_chofail', n=20, d=2, kernel='SqExp', noise='none', wellcond='base', seed=16,
         near_dup=True, etaK=1e-30, theta=np.array([1e-4, 1e-4]))
@@ -270,7 +275,7 @@ def _micro(GaussianProcess):
     return dict(name='micro_d1', n=2, d=1, kernel='SqExp', noise='none', use_grad=True, wellcond='precon',
                 x=x, f=f, g=g, std_f=np.zeros(2), std_g=np.zeros((2, 1)), theta=np.array([0.5]),
                 varK_in=np.nan, var_fval=np.nan, var_fgrad=np.nan, etaK=GP._etaK, b_has_noisy_data=False,
-                b_chofac_good=True, xq=xq, n_data=4, hp_beta=lkd.hp_beta, hp_varK=lkd.hp_varK,
+                b_chofac_good=True, xq=xq, n_data=4, pnlt=np.array([np.nan, np.nan]), hp_beta=lkd.hp_beta, hp_varK=lkd.hp_varK,
                 ln_det_Kmat=lkd.ln_det_Kmat, ln_lkd=lkd.ln_lkd, noise_vec=np.zeros(4), chofac_lower=True,
                 chofac_diag=np.diag(chofac[0]).copy(), pvec=np.ones(4), Kern=Kern, Kcov=Kcov,
                 chofac=np.tril(chofac[0]), alpha=GP.invKernEta_fdiff, varK_model=hp2.varK, mu=mu, sig=sig)

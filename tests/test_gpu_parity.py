@@ -24,6 +24,9 @@ def _gp_from_case(c):
     if "chofail" in c["name"]:
         GP._etaK = c["etaK"]
         GP._eta_Kgrad = c["etaK"]
+    if "pnlt" in c and not np.isnan(c["pnlt"][0]):
+        GP.lkd_varK_pnlt_use = True
+        GP.lkd_varK_pnlt_c1, GP.lkd_varK_pnlt_c2 = c["pnlt"]
     return GP
 
 
