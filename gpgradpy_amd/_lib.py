@@ -17,7 +17,7 @@ PROF_NCAT = len(PROF_CATS)
 
 # every symbol include/gpgrad.h declares
 ABI_SYMBOLS = (
-    "gpg_create", "gpg_destroy", "gpg_last_error", "gpg_set_data", "gpg_lkd", "gpg_lkd_batch",
+    "gpg_create", "gpg_destroy", "gpg_last_error", "gpg_set_grad_mask", "gpg_set_data", "gpg_lkd", "gpg_lkd_batch",
     "gpg_setup_eval", "gpg_predict", "gpg_get_matrix", "gpg_prof_enable", "gpg_prof_read", "gpg_set_panel", "gpg_set_lookahead",
     "gpg_device_info",
 )
@@ -58,6 +58,8 @@ def load():
     lib.gpg_destroy.restype = None
     lib.gpg_last_error.argtypes = [vp]
     lib.gpg_last_error.restype = C.c_char_p
+    lib.gpg_set_grad_mask.argtypes = [vp, C.POINTER(C.c_ubyte)]
+    lib.gpg_set_grad_mask.restype = C.c_int
     lib.gpg_set_data.argtypes = [vp, dp, dp, dp]
     lib.gpg_set_data.restype = C.c_int
     lib.gpg_lkd.argtypes = [vp, C.POINTER(GpgHp), C.POINTER(GpgLkdOut)]

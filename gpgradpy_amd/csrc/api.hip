@@ -35,6 +35,7 @@ static AsmParams make_params(const gpg_ctx* c, const gpg_hp* hp, int mode) {
   AsmParams p;
   memset(&p, 0, sizeof(p));
   p.n = c->n; p.d = c->d; p.use_grad = c->use_grad; p.kernel = c->kernel;
+  p.ng = c->ng > 0 ? c->ng : 1; p.gpos = c->gpos;
   p.N = c->N; p.Npad = c->Npad; p.ld = c->ld;
   p.precon = hp->wellcond == GPG_WELLCOND_PRECON ? 1 : 0;
   p.mode = mode;
@@ -143,7 +144,15 @@ int gpg_create(gpg_ctx** out, int device, int n_eval, int dim, int use_grad, int
     CREATE_OK(hipStreamCreateWithPriority(&c->stream_upd, hipStreamNonBlocking, prio_hi));
     CREATE_OK(hipStreamCreateWithPriority(&c->stream_bulk, hipStreamNonBlocking, prio_lo));
   }
-  CREATE_OK(hipMalloc(&c->A, sizeof(double) * (size_t)c->ld * c->Npad));
+  c->ng = c->use_grad ? n_eval : 0;
+  c->A_elems = (size_t)c->ld * c->Npad;
+  CREATE_OK(hipMalloc(&c->A, sizeof(double) * c->A_elems));
+  CREATE_OK(hipMalloc(&c->gpos, sizeof(int) * c->n));
+  {
+    std::vector<int> ident(c->n);
+    for (int a = 0; a < c->n; ++a) ident[a] = c->use_grad ? a : -1;
+    CREATE_OK(hipMemcpy(c->gpos, ident.data(), sizeof(int) * c->n, hipMemcpyHostToDevice));
+  }
   CREATE_OK(hipMalloc(&c->Xt, sizeof(double) * (size_t)c->n * c->d));
   CREATE_OK(hipMalloc(&c->y, sizeof(double) * c->N));
   CREATE_OK(hipMalloc(&c->noise, sizeof(double) * c->N));
@@ -171,6 +180,7 @@ void gpg_destroy(gpg_ctx* c) {
                     c->musig, c->dense_tmp};
   for (double* b : bufs) if (b) (void)hipFree(b);
   if (c->info) (void)hipFree(c->info);
+  if (c->gpos) (void)hipFree(c->gpos);
   if (c->h_scal) (void)hipHostFree(c->h_scal);
   if (c->h_info) (void)hipHostFree(c->h_info);
   for (auto& kv : c->tilemaps) if (kv.second.dev) (void)hipFree(kv.second.dev);
@@ -184,6 +194,26 @@ void gpg_destroy(gpg_ctx* c) {
 }
 
 const char* gpg_last_error(const gpg_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+int gpg_set_grad_mask(gpg_ctx* c, const unsigned char* use_grad_pt) {
+  if (!c) return -1;
+  if (!c->use_grad) { c->err = "gradient mask given but use_grad = 0 (GaussianProcess.py:257)"; return -1; }
+  GPG_HIP_OK(c, hipSetDevice(c->device));
+  GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
+  std::vector<int> gp(c->n);
+  int ng = 0;
+  for (int a = 0; a < c->n; ++a) gp[a] = (!use_grad_pt || use_grad_pt[a]) ? ng++ : -1;
+  GPG_HIP_OK(c, hipMemcpy(c->gpos, gp.data(), sizeof(int) * c->n, hipMemcpyHostToDevice));
+  c->ng = ng;
+  c->N = c->n + ng * c->d;                                       // GaussianProcess.py:260-262
+  c->Npad = ((c->N + GPG_TILE - 1) / GPG_TILE) * GPG_TILE;
+  c->ld = c->Npad + c->R;                                        // never exceeds the allocation made for all gradients
+  c->have_data = false;
+  c->factor_valid = c->eval_ready = false;
+  if (c->dense_tmp) { (void)hipFree(c->dense_tmp); c->dense_tmp = nullptr; }
+  if (c->Wt) { (void)hipFree(c->Wt); (void)hipFree(c->xq_dev); (void)hipFree(c->musig); c->Wt = c->xq_dev = c->musig = nullptr; c->xq_cap = 0; }
+  return 0;
+}
 
 int gpg_set_data(gpg_ctx* c, const double* x, const double* data_vec, const double* noise_var) {
   if (!c) return -1;

@@ -29,7 +29,7 @@ __global__ void prep_diag_kernel(AsmParams P, const double* __restrict__ noise, 
   int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= P.Npad) return;
   if (r >= P.N) { dvec[r] = 1.0; invp[r] = 1.0; return; }
-  int blk = P.use_grad ? r / P.n : 0;
+  int blk = (P.use_grad && r >= P.n) ? 1 + (r - P.n) / P.ng : 0;
   double kd = kdiag_of(P.kernel, blk, P.theta);
   double nz = blk == 0 ? (var_fval >= 0.0 ? var_fval : noise[r]) : (var_fgrad >= 0.0 ? var_fgrad : noise[r]);
   double dv = kd + nz / P.varK;
@@ -63,26 +63,37 @@ __global__ void __launch_bounds__(256) assemble_kernel(AsmParams P, const double
                                                        const double* __restrict__ invp, double* __restrict__ A) {
   __shared__ double xb[kTB][D];
   __shared__ double ipb[kTB][D + 1];
-  const int n = P.n;
+  __shared__ int gpb[kTB];
+  const int n = P.n, ng = P.ng;
   const int a = blockIdx.x * 256 + threadIdx.x;
   const int b0 = blockIdx.y * kTB;
   const int nblk = P.use_grad ? D + 1 : 1;
+  // gradient rows / columns exist only for points whose gradient is used: index n + (I-1) ng + gpos[pt]
   for (int t = threadIdx.x; t < kTB * D; t += 256) {
     int bb = t / D, k = t % D, b = b0 + bb;
     xb[bb][k] = b < n ? Xt[(size_t)k * n + b] : 0.0;
   }
   for (int t = threadIdx.x; t < kTB * (D + 1); t += 256) {
     int bb = t / (D + 1), J = t % (D + 1), b = b0 + bb;
-    ipb[bb][J] = (b < n && J < nblk) ? invp[(size_t)J * n + b] : 0.0;
+    double v = 0.0;
+    if (b < n && J < nblk) {
+      const int gp = P.gpos[b];
+      if (J == 0) v = invp[b];
+      else if (gp >= 0) v = invp[(size_t)n + (size_t)(J - 1) * ng + gp];
+    }
+    ipb[bb][J] = v;
   }
+  if (threadIdx.x < kTB) gpb[threadIdx.x] = (b0 + threadIdx.x < n) ? P.gpos[b0 + threadIdx.x] : -1;
   __syncthreads();
   if (a >= n) return;
 
+  const int gpa = P.gpos[a];
   double xa[D], ipa[D + 1], th[D];
 #pragma unroll
   for (int k = 0; k < D; ++k) { xa[k] = Xt[(size_t)k * n + a]; th[k] = P.theta[k]; }
+  ipa[0] = invp[a];
 #pragma unroll
-  for (int I = 0; I <= D; ++I) ipa[I] = I < nblk ? invp[(size_t)I * n + a] : 0.0;
+  for (int I = 1; I <= D; ++I) ipa[I] = (I < nblk && gpa >= 0) ? invp[(size_t)n + (size_t)(I - 1) * ng + gpa] : 0.0;
 
   const int mode = P.mode, precon = P.precon, ld = P.ld;
   const double varK = P.varK, eta = P.eta;
@@ -110,10 +121,13 @@ __global__ void __launch_bounds__(256) assemble_kernel(AsmParams P, const double
     }
     const bool diag_pt = (a == b);
     const bool low_pt = (a >= b);
+    const int gpbb = gpb[bb];
 
     // emit one entry: block (I, J), kernel value v
     auto emit = [&](int I, int J, double v) {
-      const size_t r = (size_t)I * n + a, c = (size_t)J * n + b;
+      if ((I > 0 && gpa < 0) || (J > 0 && gpbb < 0)) return;   // gradient of that point not in use
+      const size_t r = I == 0 ? (size_t)a : (size_t)n + (size_t)(I - 1) * ng + gpa;
+      const size_t c = J == 0 ? (size_t)b : (size_t)n + (size_t)(J - 1) * ng + gpbb;
       double o;
       if (mode == 1) {
         o = v;
@@ -197,8 +211,10 @@ __global__ void __launch_bounds__(256) cross_kernel(AsmParams P, const double* _
       K00 = (1.0 + sqrt5 * nu + (5.0 / 3.0) * (nu * nu)) * E;
     }
   }
+  const int gpa = P.gpos[a];
   for (int I = 0; I < nblk; ++I) {
-    const size_t c = (size_t)I * n + a;
+    if (I > 0 && gpa < 0) break;
+    const size_t c = I == 0 ? (size_t)a : (size_t)n + (size_t)(I - 1) * P.ng + gpa;
     double v = 0.0;
     if (j < nx) {
       if (I == 0) v = K00;

@@ -14,6 +14,8 @@
 // Arguments of the fused assembly kernels (passed by value -> SGPRs / kernarg segment).
 struct AsmParams {
   int n, d, use_grad, kernel;
+  int ng;          // number of points that carry a gradient (== n unless a bvec_use_grad mask is set)
+  const int* gpos; // [n] position of point a among the gradient points, -1 if its gradient is not used
   int N, Npad, ld;
   int precon;      // 1: write varK*(P^-1 Kw P^-1 + eta I); 0: varK*(Kw + eta I)
   int mode;        // 0: matrix to factorise, 1: raw Kern, 2: Kcov (P Kp P for precon)
@@ -39,6 +41,9 @@ struct gpg_ctx {
   std::map<unsigned long long, TileMap> tilemaps;   // live-tile lists of the trailing updates, per shape
   int n = 0, d = 0, use_grad = 0, kernel = 0;
   int N = 0, Npad = 0, R = GPG_RHS_ROWS, ld = 0;
+  int ng = 0;                // gradient points in use (KernelSqExp.py:349-377: bvec_use_grad)
+  int* gpos = nullptr;       // device [n]
+  size_t A_elems = 0;        // allocated size of A (doubles), sized for all gradients
   int nb_outer = 256;   // panel width
   int nb_super = 256;   // super-panel width of the two-level trailing update (== nb_outer: single level; measured best)
   // device buffers

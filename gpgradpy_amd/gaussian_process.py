@@ -221,13 +221,15 @@ class GaussianProcess:
         # reference GaussianProcess.py:219-363
         n_eval = fval.size
         if self.use_grad:
-            if bvec_use_grad is not None:
+            if bvec_use_grad is None:
+                n_grad = n_eval
+            else:
+                bvec_use_grad = np.asarray(bvec_use_grad, dtype=bool)
+                n_grad = int(np.sum(bvec_use_grad))
                 assert bvec_use_grad.size == n_eval, \
                     f'Length of bvec_use_grad is {bvec_use_grad.size} but it should be n_eval = {n_eval}'
-                if not np.all(bvec_use_grad):
-                    raise NotImplementedError('partial gradients (bvec_use_grad mask) are outside the accelerated path')
-                bvec_use_grad = None
-            n_grad = n_eval
+                assert grad.shape[0] == n_grad, \
+                    f'No. of rows of grad is {grad.shape[0]} but it should be n_grad = {n_grad}'
         else:
             assert bvec_use_grad is None, 'bvec_use_grad must be None if grads are not used for the GP'
             n_grad = 0
@@ -263,7 +265,7 @@ class GaussianProcess:
         self._std_fval_in = std_fval if self.known_eps_fval else None
         self._grad_in = grad
         self._std_grad_in = std_grad if self.known_eps_fgrad else None
-        self.bvec_use_grad = None
+        self.bvec_use_grad = bvec_use_grad
         if self.known_eps_fval:
             self.b_optz_var_fval = False
             self.b_fval_zero = bool(np.max(std_fval) < 1e-10)
@@ -304,6 +306,11 @@ class GaussianProcess:
             if rc != 0:
                 raise _lib.GpgError(f'gpg_create failed ({rc}): {self._lib.gpg_last_error(None).decode()}')
             self._ctx, self._ctx_shape = ctx, shape
+        if self.use_grad:
+            mask = None if self.bvec_use_grad is None else np.ascontiguousarray(self.bvec_use_grad, dtype=np.uint8)
+            rc = self._lib.gpg_set_grad_mask(self._ctx, None if mask is None else mask.ctypes.data_as(C.POINTER(C.c_ubyte)))
+            if rc != 0:
+                raise _lib.GpgError(f'gpg_set_grad_mask failed ({rc}): {self._err()}')
         x = np.ascontiguousarray(self._x_eval_in, dtype=np.float64)
         y = np.ascontiguousarray(self.make_data_vec(self._fval_in, self._grad_in if self.use_grad else None),
                                  dtype=np.float64)

@@ -66,6 +66,12 @@ int gpg_create(gpg_ctx** out, int device, int n_eval, int dim, int use_grad, int
 void gpg_destroy(gpg_ctx* ctx);
 const char* gpg_last_error(const gpg_ctx* ctx); /* ctx may be NULL: error of the last failed create */
 
+/* Optional, before gpg_set_data: replaces the bvec_use_grad handling of set_data / calc_KernGrad
+ * (GaussianProcess.py:246-262, KernelSqExp.py:349-377).  use_grad_pt [n_eval] != 0 marks the points whose
+ * gradient enters the model; NULL restores "all".  N becomes n_eval + n_grad * dim and data_vec / noise_var
+ * of gpg_set_data are [N] with the gradient part laid out [n_grad, dim] column-major (CommonFun.py:170-171). */
+int gpg_set_grad_mask(gpg_ctx* ctx, const unsigned char* use_grad_pt);
+
 /* Replaces the data ingest of set_data (GaussianProcess.py:296-302,363) and make_data_vec
  * (CommonFun.py:151-173).  x [n_eval, dim] row-major; data_vec [N] = [f, d1 f(all pts), ...];
  * noise_var [N] = known noise variances in the same ordering (Kernel.py:343-353) or NULL (zeros).

@@ -60,13 +60,16 @@ def make_data_vec(fval, fgrad=None):
     return np.concatenate((fval, np.asarray(fgrad, dtype=float).T.ravel()))
 
 
-def calc_noise_vec(n, d, use_grad, std_f, std_g, var_fval=None, var_fgrad=None):
+def calc_noise_vec(n, d, use_grad, std_f, std_g, var_fval=None, var_fgrad=None, n_grad=None):
     """Noise variance per row of K -- reference Kernel.py:309-357.
 
-    std_f / std_g None  => that variance is a hyperparameter (var_fval / var_fgrad)."""
+    std_f / std_g None  => that variance is a hyperparameter (var_fval / var_fgrad).
+    n_grad = number of points whose gradient is used (default: all, or the rows of std_g)."""
     if not use_grad:
         return np.asarray(std_f, dtype=float) ** 2 if std_f is not None else np.full(n, float(var_fval))
-    out = np.zeros(n * (d + 1))
+    if n_grad is None:
+        n_grad = n if std_g is None else np.asarray(std_g).shape[0]
+    out = np.zeros(n + n_grad * d)
     out[:n] = np.asarray(std_f, dtype=float) ** 2 if std_f is not None else float(var_fval)
     out[n:] = (np.asarray(std_g, dtype=float) ** 2).T.ravel() if std_g is not None else float(var_fgrad)
     return out
@@ -91,11 +94,25 @@ def kern_base(X, Y, theta, kernel):
     return (1.0 + r5 * nu + (5.0 / 3.0) * nu ** 2) * np.exp(-r5 * nu)
 
 
-def kern_grad(X, Y, theta, kernel, grad_cols=True):
-    """Gradient-enhanced kernel matrix [(n1 (d+1)) x (n2 (d+1))] (all gradients used).
+def _mask_index(n, d, mask):
+    """Rows of the full [n (d+1)] ordering kept by a bvec_use_grad mask (KernelSqExp.py:349-377)."""
+    g = np.flatnonzero(mask)
+    return np.concatenate([np.arange(n)] + [n * (i + 1) + g for i in range(d)])
+
+
+def kern_grad(X, Y, theta, kernel, grad_cols=True, mask1=None, mask2=None):
+    """Gradient-enhanced kernel matrix [(n1 + n1g d) x (n2 + n2g d)].
 
     Reference KernelSqExp.py:320-410 (SqExp) and KernelMatern5f2.py:352-450 (Matern 5/2).
-    grad_cols=False keeps only the first n2 columns (the cross matrix of GpEvalModel.py:135-139)."""
+    grad_cols=False keeps only the first n2 columns (the cross matrix of GpEvalModel.py:135-139);
+    mask1 / mask2 = bvec_use_grad1 / bvec_use_grad2 (points whose gradient rows / columns are kept)."""
+    if mask1 is not None or mask2 is not None:
+        K = kern_grad(X, Y, theta, kernel, grad_cols)
+        n1, d = X.shape
+        n2 = Y.shape[0]
+        rows = slice(None) if mask1 is None else _mask_index(n1, d, mask1)
+        cols = slice(None) if (mask2 is None or not grad_cols) else _mask_index(n2, d, mask2)
+        return K[rows][:, cols]
     n1, d = X.shape
     n2 = Y.shape[0]
     R = _rtensor(X, Y)
@@ -146,13 +163,14 @@ class Factor:
 
 
 def calc_all_K_w_chofac(X, theta, kernel, use_grad, wellcond, etaK, noise_vec, varK=1.0,
-                        as_written=False):
+                        as_written=False, grad_mask=None):
     """Kernel + noise + (preconditioner) + nugget + Cholesky -- reference Kernel.py:140-307.
 
     as_written=True keeps the reference's dense diagonal-matrix products (Kernel.py:224-227,237,252)
     so that the CPU baseline is timed on the algorithm the reference actually runs; False applies the
     same scaling element-wise (identical values up to rounding)."""
-    Kern = kern_grad(X, X, theta, kernel) if use_grad else kern_base(X, X, theta, kernel)
+    Kern = kern_grad(X, X, theta, kernel, mask1=grad_mask, mask2=grad_mask) if use_grad \
+        else kern_base(X, X, theta, kernel)
     N = Kern.shape[0]
     Kw = Kern + np.diag(noise_vec / varK)
     if wellcond == "precon":
@@ -195,9 +213,10 @@ class LkdResult:
     factor: Factor | None = field(default=None, repr=False)
 
 
-def _vand_aug(n, d, use_grad):
+def _vand_aug(n, d, use_grad, n_grad=None):
     """V = [1_n ; 0] -- reference GpMeanFun.py:172-191 with poly_ord_0 (:195-204)."""
-    V = np.zeros((n * (d + 1) if use_grad else n, 1))
+    n_grad = n if n_grad is None else n_grad
+    V = np.zeros((n + n_grad * d if use_grad else n, 1))
     V[:n, 0] = 1.0
     return V
 
@@ -211,17 +230,17 @@ def _gls_mean(chofac, V, y):
 
 
 def calc_lkd(X, y, theta, kernel, use_grad, wellcond, etaK, noise_vec, noisy, varK=None,
-             as_written=False):
+             as_written=False, grad_mask=None):
     """One marginal-log-likelihood evaluation (value only) -- reference CalcLkd.py:270-346.
 
     noisy=False: CalcLkd.py:30-95 + :149-181 (varK in closed form, matrix built with varK = 1).
     noisy=True : CalcLkd.py:185-251 (varK is a hyperparameter)."""
     n, d = X.shape
     fac = calc_all_K_w_chofac(X, theta, kernel, use_grad, wellcond, etaK, noise_vec,
-                              varK=(varK if noisy else 1.0), as_written=as_written)
+                              varK=(varK if noisy else 1.0), as_written=as_written, grad_mask=grad_mask)
     if fac.chofac is None:
         return LkdResult(False, factor=fac)
-    V = _vand_aug(n, d, use_grad)
+    V = _vand_aug(n, d, use_grad, None if grad_mask is None else int(np.sum(grad_mask)))
     beta, mean_val = _gls_mean(fac.chofac, V, y)
     res = y - mean_val
     alpha = cho_solve(fac.chofac, res)
@@ -246,26 +265,27 @@ class EvalModel:
     varK: float
     chofac: tuple
     alpha: np.ndarray
+    grad_mask: np.ndarray | None = None
 
 
-def setup_eval_model(X, y, theta, kernel, use_grad, wellcond, etaK, noise_vec, beta, varK):
+def setup_eval_model(X, y, theta, kernel, use_grad, wellcond, etaK, noise_vec, beta, varK, grad_mask=None):
     """Reference GpEvalModel.py:17-57.  Built with b_normlz_w_varK=True: varK := 1 *before* the
     noise is divided by it (Kernel.py:196-197,218), so known noise is not scaled by the true varK."""
     n, d = X.shape
-    fac = calc_all_K_w_chofac(X, theta, kernel, use_grad, wellcond, etaK, noise_vec, varK=1.0)
+    fac = calc_all_K_w_chofac(X, theta, kernel, use_grad, wellcond, etaK, noise_vec, varK=1.0, grad_mask=grad_mask)
     if fac.chofac is None:
         return None
-    V = _vand_aug(n, d, use_grad)
+    V = _vand_aug(n, d, use_grad, None if grad_mask is None else int(np.sum(grad_mask)))
     alpha = cho_solve(fac.chofac, y - V @ beta)
     return EvalModel(X, np.asarray(theta, float), kernel, use_grad, np.asarray(beta, float), float(varK),
-                     fac.chofac, alpha)
+                     fac.chofac, alpha, grad_mask)
 
 
 def eval_model(m: EvalModel, xq):
     """Posterior mean and standard deviation -- reference GpEvalModel.py:59-198 (calc_grad=False)."""
     xq = np.atleast_2d(np.asarray(xq, dtype=float))
     if m.use_grad:
-        Kyx = kern_grad(m.X, xq, m.theta, m.kernel, grad_cols=False)
+        Kyx = kern_grad(m.X, xq, m.theta, m.kernel, grad_cols=False, mask1=m.grad_mask)
     else:
         Kyx = kern_base(m.X, xq, m.theta, m.kernel)
     sol = cho_solve(m.chofac, Kyx)

@@ -31,6 +31,8 @@ def load_case(path):
     for k in ("varK_in", "var_fval", "var_fgrad", "etaK", "hp_varK", "ln_det_Kmat", "ln_lkd", "varK_model"):
         if k in c:
             c[k] = float(c[k])
+    if "bvec_use_grad" in c:
+        c["bvec_use_grad"] = c["bvec_use_grad"].astype(bool)
     c["std_f"] = None if c["std_f"].size == 0 else c["std_f"]
     c["std_g"] = None if c["std_g"].size == 0 else c["std_g"]
     return c

@@ -65,7 +65,7 @@ def rosenbrock(x, a=10.0):
 
 def make_case(GaussianProcess, name, n, d, kernel, noise, use_grad=True, wellcond='precon', seed=0,
               theta=None, varK=None, var_fval=None, var_fgrad=None, nq=8, near_dup=False, etaK=None,
-              store_mats=False, pnlt=None):
+              store_mats=False, pnlt=None, mask=False):
     rng = np.random.default_rng(seed)
     x = rng.uniform(-2, 2, (n, d))
     if near_dup and n > 2:
@@ -92,9 +92,18 @@ def make_case(GaussianProcess, name, n, d, kernel, noise, use_grad=True, wellcon
     else:
         raise ValueError(noise)
 
+    bvec = None
+    if mask:                                  # bvec_use_grad: drop ~1/3 of the gradients, the last one for sure
+        bvec = rng.random(n) > 0.35
+        bvec[-1] = False
+        bvec[0] = True
+        g = g[bvec]
+        if std_g is not None:
+            std_g = std_g[bvec]
+
     GP = GaussianProcess(d, use_grad, kernel, wellcond)
     if use_grad:
-        GP.set_data(x, f, std_f, g, std_g)
+        GP.set_data(x, f, std_f, g, std_g, bvec)
     else:
         GP.set_data(x, f, std_f)
     if etaK is not None:
@@ -122,7 +131,7 @@ def make_case(GaussianProcess, name, n, d, kernel, noise, use_grad=True, wellcon
                var_fval=np.nan if var_fval is None else var_fval,
                var_fgrad=np.nan if var_fgrad is None else var_fgrad,
                etaK=GP._etaK, b_has_noisy_data=noisy, b_chofac_good=bool(ok), xq=xq,
-               n_data=GP.n_data, pnlt=np.array([np.nan, np.nan] if pnlt is None else pnlt))
+               n_data=GP.n_data, bvec_use_grad=np.ones(n, dtype=bool) if bvec is None else bvec, pnlt=np.array([np.nan, np.nan] if pnlt is None else pnlt))
     if not ok:
         return out
 
@@ -195,6 +204,10 @@ def main():
     # gradient-enhanced with wellcond_mtd='base' (no preconditioner)
     add(name='SqExp_none_n12_d2_base', n=12, d=2, kernel='SqExp', noise='none', wellcond='base', seed=15,
         theta=np.array([0.4, 0.9]), store_mats=True)
+    # gradient masks (bvec_use_grad): value path of KernelSqExp.py:349-377 / KernelMatern5f2.py:380-417
+    add(name='SqExp_none_n17_d4_mask', n=17, d=4, kernel='SqExp', noise='none', seed=21, mask=True, store_mats=True)
+    add(name='Ma5f2_known_n23_d3_mask', n=23, d=3, kernel='Ma5f2', noise='known', seed=22, mask=True, store_mats=True)
+    add(name='SqExp_unknown_n40_d5_mask', n=40, d=5, kernel='SqExp', noise='unknown', seed=23, mask=True)
     # varK penalty active (c2 small so that varK > c2 * var(f))
     add(name='SqExp_none_n17_d4_pnlt', n=17, d=4, kernel='SqExp', noise='none', seed=17, pnlt=(0.7, 1e-6))
     # Cholesky failure: 'base' method, near-duplicate points, tiny nugget -> cho_factor raises
@@ -275,7 +288,7 @@ def _micro(GaussianProcess):
     return dict(name='micro_d1', n=2, d=1, kernel='SqExp', noise='none', use_grad=True, wellcond='precon',
                 x=x, f=f, g=g, std_f=np.zeros(2), std_g=np.zeros((2, 1)), theta=np.array([0.5]),
                 varK_in=np.nan, var_fval=np.nan, var_fgrad=np.nan, etaK=GP._etaK, b_has_noisy_data=False,
-                b_chofac_good=True, xq=xq, n_data=4, pnlt=np.array([np.nan, np.nan]), hp_beta=lkd.hp_beta, hp_varK=lkd.hp_varK,
+                b_chofac_good=True, xq=xq, n_data=4, bvec_use_grad=np.ones(2, dtype=bool), pnlt=np.array([np.nan, np.nan]), hp_beta=lkd.hp_beta, hp_varK=lkd.hp_varK,
                 ln_det_Kmat=lkd.ln_det_Kmat, ln_lkd=lkd.ln_lkd, noise_vec=np.zeros(4), chofac_lower=True,
                 chofac_diag=np.diag(chofac[0]).copy(), pvec=np.ones(4), Kern=Kern, Kcov=Kcov,
                 chofac=np.tril(chofac[0]), alpha=GP.invKernEta_fdiff, varK_model=hp2.varK, mu=mu, sig=sig)

@@ -18,7 +18,8 @@ def _gp_from_case(c):
     import gpgradpy_amd
     GP = gpgradpy_amd.GaussianProcess(c["d"], c["use_grad"], c["kernel"], c["wellcond"] if c["use_grad"] else "base")
     if c["use_grad"]:
-        GP.set_data(c["x"], c["f"], c["std_f"], c["g"], c["std_g"])
+        bvec = None if c["bvec_use_grad"].all() else c["bvec_use_grad"]
+        GP.set_data(c["x"], c["f"], c["std_f"], c["g"], c["std_g"], bvec)
     else:
         GP.set_data(c["x"], c["f"], c["std_f"])
     if "chofail" in c["name"]:
