@@ -130,16 +130,24 @@ def main():
     if not torch.cuda.is_available():
         print("[bench] no GPU visible: the product path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % ndev
+    torch.cuda.set_device(dev_index)
+    # one rank per GPU -> RCCL ("nccl"); more ranks than GPUs (a rehearsal on a 1-GPU box) -> gloo on host tensors
+    backend = "nccl" if world <= ndev else "gloo"
+    coll_dev = torch.device("cuda", dev_index) if backend == "nccl" else torch.device("cpu")
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     n0, d0 = {"cfg2": (500, 4), "cfg3": (2000, 8), "cfg5": (4000, 16)}[args.config]
     n, d = args.n or n0, args.d or d0
     kernel = "Ma5f2" if args.config == "cfg5" else "SqExp"
     X, f, g, hp_table = make_workload(n, d, args.config)
     N = n * (d + 1)
-    GP = gpgradpy_amd.GaussianProcess(d, True, kernel, "precon", device=local_rank)
+    GP = gpgradpy_amd.GaussianProcess(d, True, kernel, "precon", device=dev_index)
     if args.config == "cfg5":
         GP.set_data(X, f, np.full(n, 1e-2), g, np.full((n, d), 1e-1))   # known noise -> varK is a hyperparameter
     else:
@@ -169,7 +177,7 @@ def main():
     t0 = time.perf_counter()
     ln_local = GP.calc_lkd_batch(rows_for(args.steps))           # K evaluations queued back-to-back, one sync
     if world > 1:                                                # the single collective: gather ln_lkd, pick best
-        buf = torch.from_numpy(ln_local).cuda()
+        buf = torch.from_numpy(ln_local).to(coll_dev)
         out = [torch.empty_like(buf) for _ in range(world)]
         dist.all_gather(out, buf)
         ln_all = torch.cat(out).cpu().numpy()
@@ -181,7 +189,7 @@ def main():
     prof = GP.prof_read()
     GP.prof_enable([])
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -200,7 +208,7 @@ def main():
                                    + "precon + nugget, value-only likelihood evaluation per restart row "
                                    "(rows of the BASELINE.md section 3 restart table, 8 per rank)",
                        "n": n, "d": d, "N": N, "kernel": kernel, "wellcond": "precon",
-                       "evals_per_gpu": args.steps, "parallelism": f"restarts sharded over {world} GPU(s), one all_gather"},
+                       "evals_per_gpu": args.steps, "parallelism": f"restarts sharded over {world} rank(s), one all_gather ({backend if world > 1 else 'none'})"},
             "roofline": {"bound": "mfma", "kernel": "gemm_nt_minus_kernel<128,128> (Cholesky trailing update)",
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
