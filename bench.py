@@ -109,7 +109,6 @@ def main():
     ap.add_argument("--n", type=int, default=0)
     ap.add_argument("--d", type=int, default=0)
     ap.add_argument("--panel", type=int, default=0, help="panel width override")
-    ap.add_argument("--super", type=int, default=0, dest="superp", help="super-panel width override")
     ap.add_argument("--lookahead", type=int, default=-1, help="1/0 force the two-stream look-ahead on/off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-all", action="store_true", help="time every kernel category (adds event overhead)")
@@ -152,8 +151,8 @@ def main():
         GP.set_data(X, f, np.full(n, 1e-2), g, np.full((n, d), 1e-1))   # known noise -> varK is a hyperparameter
     else:
         GP.set_data(X, f, np.zeros(n), g, np.zeros((n, d)))      # resident in HBM before the timed region
-    if args.panel or args.superp:
-        GP.set_panel(args.panel or 256, args.superp)
+    if args.panel:
+        GP.set_panel(args.panel)
     if args.lookahead >= 0:
         GP.set_lookahead(args.lookahead)
 

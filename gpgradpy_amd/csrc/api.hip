@@ -126,6 +126,7 @@ int gpg_create(gpg_ctx** out, int device, int n_eval, int dim, int use_grad, int
   c->Npad = ((c->N + GPG_TILE - 1) / GPG_TILE) * GPG_TILE;
   c->R = GPG_RHS_ROWS;
   c->ld = c->Npad + c->R;
+  c->nb_outer = c->Npad >= 8192 ? 512 : 256;   // wider panels amortise the C-tile traffic of the trailing update (measured)
 #define CREATE_OK(call)                                                              \
   do {                                                                               \
     hipError_t e_ = (call);                                                          \
@@ -139,10 +140,8 @@ int gpg_create(gpg_ctx** out, int device, int n_eval, int dim, int use_grad, int
   {
     int prio_lo = 0, prio_hi = 0;
     CREATE_OK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));   // numerically lowest = highest priority
-    const int prio_mid = (prio_lo + prio_hi) / 2;
-    CREATE_OK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_mid));
+    CREATE_OK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_lo));
     CREATE_OK(hipStreamCreateWithPriority(&c->stream_upd, hipStreamNonBlocking, prio_hi));
-    CREATE_OK(hipStreamCreateWithPriority(&c->stream_bulk, hipStreamNonBlocking, prio_lo));
   }
   c->ng = c->use_grad ? n_eval : 0;
   c->A_elems = (size_t)c->ld * c->Npad;
@@ -173,7 +172,6 @@ void gpg_destroy(gpg_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->stream_upd) (void)hipStreamSynchronize(c->stream_upd);
-  if (c->stream_bulk) (void)hipStreamSynchronize(c->stream_bulk);
   for (auto& pe : c->prof_pending) { (void)hipEventDestroy(pe.e0); (void)hipEventDestroy(pe.e1); }
   for (auto& ev : c->prof_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   double* bufs[] = {c->A, c->Xt, c->y, c->noise, c->dvec, c->invp, c->zvec, c->tmpv, c->dinv, c->scal, c->Wt, c->xq_dev,
@@ -186,8 +184,6 @@ void gpg_destroy(gpg_ctx* c) {
   for (auto& kv : c->tilemaps) if (kv.second.dev) (void)hipFree(kv.second.dev);
   for (auto e : c->ev_panel) (void)hipEventDestroy(e);
   for (auto e : c->ev_upd) (void)hipEventDestroy(e);
-  for (auto e : c->ev_bulk) (void)hipEventDestroy(e);
-  if (c->stream_bulk) (void)hipStreamDestroy(c->stream_bulk);
   if (c->stream_upd) (void)hipStreamDestroy(c->stream_upd);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
@@ -399,21 +395,15 @@ int gpg_prof_read(gpg_ctx* c, double ms[GPG_PROF_NCAT], long long count[GPG_PROF
 
 int gpg_set_lookahead(gpg_ctx* c, int on) {
   if (!c) return -1;
-  c->lookahead = (on & 8) ? 2 : ((on & 1) ? 1 : 0);   // 8: full look-ahead over three streams
+  c->lookahead = (on & 1) ? 1 : 0;
   c->gemm_impl = (on & 2) ? 0 : 1;   // bit 1: fall back to the register-staged 128x128 kernel (A/B runs)
-  c->gemm_stagger = (on & 4) ? 1 : 0; // bit 2: first-round de-phasing of the trailing-update workgroups (measured: no gain)
   return 0;
 }
 
 int gpg_set_panel(gpg_ctx* c, int nb_outer) {
   if (!c) return -1;
-  // nb_outer = panel + 65536 * super-panel (super-panel 0 keeps the current one)
-  const int nb = nb_outer & 0xffff, sb = nb_outer >> 16;
-  if (nb < 128 || nb > 1024 || nb % 128) { c->err = "panel width must be a multiple of 128 in [128, 1024]"; return -1; }
-  if (sb != 0 && (sb < nb || sb % nb || sb > 8192)) { c->err = "super-panel width must be a multiple of the panel width, <= 8192"; return -1; }
-  c->nb_outer = nb;
-  if (sb) c->nb_super = sb;
-  if (c->nb_super < nb || c->nb_super % nb) c->nb_super = nb;
+  if (nb_outer < 128 || nb_outer > 1024 || nb_outer % 128) { c->err = "panel width must be a multiple of 128 in [128, 1024]"; return -1; }
+  c->nb_outer = nb_outer;
   return 0;
 }
 

@@ -269,123 +269,6 @@ gemm_nt_minus_kernel(double* __restrict__ C, int ldc, const double* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-// gemm_reg_kernel: 128 x 128 tile update  C -= A B^T, register-staged double buffering with the prefetch
-// pinned ahead of the MFMAs.  Per 8-deep k-chunk a thread issues four 16-byte global loads (two of the
-// A slice, two of the B slice) BEFORE the chunk's 32 MFMAs and parks them in LDS after them; plain loads
-// cost their issuing wave a few cycles each (an LDS-DMA costs ~380: measured with in-kernel stamps), so
-// the MFMA waves never stall on the memory pipe.
-// ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 2)
-gemm_reg_kernel(double* __restrict__ C, int ldc, const double* __restrict__ A, int lda, const double* __restrict__ B,
-                int ldb, int M, int Nc, int K, int lower, int skipM, int skipN, const int* __restrict__ tilemap,
-                int ntiles) {
-  constexpr int BM = 128, BN = 128, KB = 8;
-  constexpr int ROW = 144;
-  constexpr int STAGE = 2 * KB * ROW;
-  __shared__ __attribute__((aligned(16))) double smem[2 * STAGE];
-
-  int m0, n0;
-  if (tilemap) {
-    const int nwg = ntiles, b = blockIdx.x;
-    const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
-    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-    const int t = tilemap[v];
-    m0 = (t & 0xffff) * BM;
-    n0 = (t >> 16) * BN;
-  } else {
-    m0 = blockIdx.x * BM;
-    n0 = blockIdx.y * BN;
-    if (lower && m0 + BM <= n0) return;
-    if (m0 < skipM && n0 < skipN) return;
-  }
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int wm = w & 1, wn = w >> 1;
-  const int l15 = lane & 15, l4 = lane >> 4;
-  const bool wave_active = (m0 + wm * 64) < M;
-
-  d4 acc[4][4] = {};
-  double* Cw = C + (size_t)(m0 + wm * 64 + l15) + (size_t)(n0 + wn * 64 + l4) * ldc;
-  if (wave_active) {
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[ni][mi][r] = Cw[mi * 16 + (size_t)(ni * 16 + 4 * r) * ldc];
-  }
-
-  // this thread moves rows (2 lane, 2 lane + 1) of k-rows w and w + 4, for A and for B
-  int rowa = m0 + 2 * lane;
-  rowa = rowa < M ? rowa : M - 2;
-  const double* ga = A + rowa + (size_t)w * lda;
-  const double* gb = B + n0 + 2 * lane + (size_t)w * ldb;
-  const size_t a4 = (size_t)4 * lda, b4 = (size_t)4 * ldb, aK = (size_t)KB * lda, bK = (size_t)KB * ldb;
-  double* const sw = smem + w * ROW + 2 * lane;      // + stage * STAGE ; A rows at 0, B rows at KB * ROW
-  const double* const pa0 = smem + l4 * ROW + wm * 64 + l15;
-  const double* const pb0 = smem + (KB + l4) * ROW + wn * 64 + l15;
-
-  double2 ra0, ra1, rb0, rb1;
-#define GPG_REG_LOAD()                                              \
-  ra0 = *reinterpret_cast<const double2*>(ga);                      \
-  ra1 = *reinterpret_cast<const double2*>(ga + a4);                 \
-  rb0 = *reinterpret_cast<const double2*>(gb);                      \
-  rb1 = *reinterpret_cast<const double2*>(gb + b4);                 \
-  ga += aK;                                                         \
-  gb += bK;
-#define GPG_REG_STORE(stage)                                        \
-  {                                                                 \
-    double* d = sw + (stage) * STAGE;                                \
-    double2 n0v, n1v;                                               \
-    n0v.x = -ra0.x; n0v.y = -ra0.y; n1v.x = -ra1.x; n1v.y = -ra1.y; \
-    *reinterpret_cast<double2*>(d) = n0v;                           \
-    *reinterpret_cast<double2*>(d + 4 * ROW) = n1v;                 \
-    *reinterpret_cast<double2*>(d + KB * ROW) = rb0;                \
-    *reinterpret_cast<double2*>(d + (KB + 4) * ROW) = rb1;          \
-  }
-#define GPG_REG_COMPUTE(stage)                                                                        \
-  {                                                                                                   \
-    const double* pa = pa0 + (stage) * STAGE;                                                          \
-    const double* pb = pb0 + (stage) * STAGE;                                                          \
-    _Pragma("unroll") for (int kk = 0; kk < KB; kk += 4) {                                             \
-      double fm[4], fn[4];                                                                            \
-      _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) fm[mi] = pa[kk * ROW + mi * 16];                 \
-      _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) fn[ni] = pb[kk * ROW + ni * 16];                 \
-      _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                 \
-        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                               \
-          acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fn[ni], fm[mi], acc[ni][mi], 0, 0, 0);    \
-    }                                                                                                 \
-  }
-
-  const int nchunk = K / KB;
-  GPG_REG_LOAD()
-  GPG_REG_STORE(0)
-  __syncthreads();
-  int stage = 0;
-  for (int i = 0; i + 1 < nchunk; ++i) {
-    GPG_REG_LOAD()                           // next chunk: issued before the MFMAs ...
-    __builtin_amdgcn_sched_barrier(0);       // ... and kept there (hipcc otherwise sinks the loads below them)
-    GPG_REG_COMPUTE(stage)
-    __builtin_amdgcn_sched_barrier(0);
-    GPG_REG_STORE(stage ^ 1)
-    __syncthreads();
-    stage ^= 1;
-  }
-  GPG_REG_COMPUTE(stage)
-#undef GPG_REG_LOAD
-#undef GPG_REG_STORE
-#undef GPG_REG_COMPUTE
-
-  if (wave_active) {
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) Cw[mi * 16 + (size_t)(ni * 16 + 4 * r) * ldc] = acc[ni][mi][r];
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // gemm_dma_kernel: the 128 x 128 tile update  C -= A B^T  with the panel streamed by LDS-DMA.
 // Same tile / wave / MFMA mapping as gemm_nt_minus_kernel<128,128>, but the k-chunks (8 deep) are
 // written straight into a 4-stage LDS ring with global_load_lds_dwordx4: one wave-instruction moves one
@@ -408,7 +291,7 @@ template <int S>
 __global__ void __launch_bounds__(256, 2)
 gemm_dma_kernel(double* __restrict__ C, int ldc, const double* __restrict__ A, int lda, const double* __restrict__ B,
                 int ldb, int M, int Nc, int K, int lower, int skipM, int skipN, const int* __restrict__ tilemap,
-                int ntiles, int stagger_ticks) {
+                int ntiles) {
   constexpr int BM = 128, BN = 128, KB = 8;
   constexpr int ROW = 144;                 // doubles per LDS k-row (128 + 16 pad: conflict-free ds_read_b64)
   constexpr int STAGE = 2 * KB * ROW;      // A rows then B rows
@@ -433,18 +316,6 @@ gemm_dma_kernel(double* __restrict__ C, int ldc, const double* __restrict__ A, i
   const int l15 = lane & 15, l4 = lane >> 4;
   const bool wave_active = (m0 + wm * 64) < M;
 
-  // De-phase the first round.  All 512 co-resident workgroups of a launch would otherwise load their C
-  // tiles, stream and store in lockstep: HBM sees 64 MB bursts and both workgroups of a CU leave the MFMA
-  // pipe idle together.  Workgroup j of an XCD (b >> 3; j < 32 is the first on its CU, 32 <= j < 64 the
-  // second, by the observed round-robin placement) waits a fraction of one tile time before starting, so
-  // that the pair on a CU runs half a tile apart and the CUs are spread over the other half.
-  if (stagger_ticks > 0 && (blockIdx.x >> 3) < 64) {
-    const int j = blockIdx.x >> 3;
-    const unsigned wait_ticks = (unsigned)(((j & 31) * (stagger_ticks >> 1)) >> 5) + (j >= 32 ? (stagger_ticks >> 1) : 0);
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while ((unsigned)(__builtin_amdgcn_s_memrealtime() - t0) < wait_ticks) __builtin_amdgcn_s_sleep(32);
-  }
-
   d4 acc[4][4] = {};
   double* Cw = C + (size_t)(m0 + wm * 64 + l15) + (size_t)(n0 + wn * 64 + l4) * ldc;
 #ifndef GPG_ABLATE_CLOAD
@@ -461,23 +332,11 @@ gemm_dma_kernel(double* __restrict__ C, int ldc, const double* __restrict__ A, i
   // per-lane DMA sources: this wave moves k-rows w and w + 4 of every chunk, for A and for B
   int rowa = m0 + 2 * lane;
   rowa = rowa < M ? rowa : M - 2;          // ragged last row tile: clamp (those rows are never stored)
-#ifdef GPG_ABLATE_SAMEPANEL
-  const double* ga = A + 2 * lane + (size_t)w * lda;   // diagnostic: every tile streams the same (L2-resident) slices
-  const double* gb = B + 2 * lane + (size_t)w * ldb;
-#else
   const double* ga = A + rowa + (size_t)w * lda;
   const double* gb = B + n0 + 2 * lane + (size_t)w * ldb;
-#endif
   const size_t a4 = (size_t)4 * lda, b4 = (size_t)4 * ldb, aK = (size_t)KB * lda, bK = (size_t)KB * ldb;
   double* const sbase = smem;
 
-#ifdef GPG_ABLATE_DMAB   // diagnostic: stream only the A slice (half the panel bytes)
-#define GPG_DMA_B_HALF
-#else
-#define GPG_DMA_B_HALF                                                                                    \
-    __builtin_amdgcn_global_load_lds((glb_ptr_t)gb, (lds_ptr_t)(sa + KB * ROW), 16, 0, 0);                 \
-    __builtin_amdgcn_global_load_lds((glb_ptr_t)(gb + b4), (lds_ptr_t)(sa + (KB + 4) * ROW), 16, 0, 0);
-#endif
 #ifdef GPG_ABLATE_DMA
 #define GPG_DMA_ISSUE(stage) {}
 #else
@@ -486,7 +345,8 @@ gemm_dma_kernel(double* __restrict__ C, int ldc, const double* __restrict__ A, i
     double* sa = sbase + (stage) * STAGE + w * ROW;                                                        \
     __builtin_amdgcn_global_load_lds((glb_ptr_t)ga, (lds_ptr_t)sa, 16, 0, 0);                              \
     __builtin_amdgcn_global_load_lds((glb_ptr_t)(ga + a4), (lds_ptr_t)(sa + 4 * ROW), 16, 0, 0);          \
-    GPG_DMA_B_HALF                                                                                        \
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)gb, (lds_ptr_t)(sa + KB * ROW), 16, 0, 0);                 \
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(gb + b4), (lds_ptr_t)(sa + (KB + 4) * ROW), 16, 0, 0);    \
     ga += aK;                                                                                             \
     gb += bK;                                                                                             \
   }
@@ -533,13 +393,7 @@ gemm_dma_kernel(double* __restrict__ C, int ldc, const double* __restrict__ A, i
       GPG_DMA_ISSUE(st)
     }
     GPG_T(s1)
-#ifdef GPG_SETPRIO
-    __builtin_amdgcn_s_setprio(1);
-#endif
     GPG_DMA_COMPUTE(stage)
-#ifdef GPG_SETPRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
     GPG_T(s2)
     // chunk i+1 must have landed before anybody reads it; chunks i+2, i+3 may stay in flight
     if (more) { GPG_WAIT_STEADY() }
@@ -578,14 +432,9 @@ void launch_gemm(gpg_ctx* c, double* C, int ldc, const double* A, int lda, const
                  int K, int lower, int skipM = 0, int skipN = 0) {
   if (M <= 0 || Nc <= 0 || K <= 0) return;
   dim3 grid((M + BM - 1) / BM, Nc / BN);
-  if (BM == 128 && BN == 128 && c->gemm_impl == 2) {
-    hipLaunchKernelGGL(gemm_reg_kernel, grid, dim3(256), 0, c->stream, C, ldc, A, lda, B, ldb, M, Nc, K, lower, skipM,
-                       skipN, (const int*)nullptr, 0);
-    return;
-  }
   if (BM == 128 && BN == 128 && c->gemm_impl == 1) {
     hipLaunchKernelGGL(gemm_dma_kernel<4>, grid, dim3(256), 0, c->stream, C, ldc, A, lda, B, ldb, M, Nc, K, lower, skipM,
-                       skipN, (const int*)nullptr, 0, 0);
+                       skipN, (const int*)nullptr, 0);
     return;
   }
   hipLaunchKernelGGL((gemm_nt_minus_kernel<BM, BN>), grid, dim3(256), 0, c->stream, C, ldc, A, lda, B, ldb, M, Nc, K,
@@ -624,24 +473,9 @@ void launch_gemm_trailing(gpg_ctx* c, double* C, int ldc, const double* A, int l
                           int Nc, int K, int skip) {
   const TileMap& tm = get_tilemap(c, (M + 127) / 128, Nc / 128, skip / 128);
   if (tm.n <= 0) return;
-  if (c->gemm_impl == 2) {
-    hipLaunchKernelGGL(gemm_reg_kernel, dim3(tm.n), dim3(256), c->dyn_lds_ballast, c->stream, C, ldc, A, lda, B, ldb, M, Nc, K, 1, 0, 0,
-                       (const int*)tm.dev, tm.n);
-    return;
-  }
   if (c->gemm_impl == 1) {
-    // one tile takes ~ K / 256 * 55 us when two workgroups share a CU (100 MHz ticks); only worth it when
-    // the launch runs for several rounds of 512 workgroups
-    const int stagger = (c->gemm_stagger && tm.n >= 4 * 512) ? (int)(5500.0 * K / 256.0) : 0;
-    if (c->gemm_ring == 2)
-      hipLaunchKernelGGL(gemm_dma_kernel<2>, dim3(tm.n), dim3(256), 0, c->stream, C, ldc, A, lda, B, ldb, M, Nc, K, 1, 0, 0,
-                         (const int*)tm.dev, tm.n, stagger);
-    else if (c->gemm_ring == 3)
-      hipLaunchKernelGGL(gemm_dma_kernel<3>, dim3(tm.n), dim3(256), 0, c->stream, C, ldc, A, lda, B, ldb, M, Nc, K, 1, 0, 0,
-                         (const int*)tm.dev, tm.n, stagger);
-    else
-      hipLaunchKernelGGL(gemm_dma_kernel<4>, dim3(tm.n), dim3(256), c->dyn_lds_ballast, c->stream, C, ldc, A, lda, B, ldb, M, Nc, K, 1, 0, 0,
-                         (const int*)tm.dev, tm.n, stagger);
+    hipLaunchKernelGGL(gemm_dma_kernel<4>, dim3(tm.n), dim3(256), 0, c->stream, C, ldc, A, lda, B, ldb, M, Nc, K, 1, 0, 0,
+                       (const int*)tm.dev, tm.n);
     return;
   }
   hipLaunchKernelGGL((gemm_nt_minus_kernel<128, 128>), dim3(tm.n), dim3(256), 0, c->stream, C, ldc, A, lda, B, ldb, M, Nc,
@@ -702,80 +536,8 @@ static void solve_below_block(gpg_ctx* c, int k0, int k1) {
   }
 }
 
-// lookahead == 2 ("full" look-ahead, three streams):
-//   panel stream sM : [wait D_p] B_p, [wait U_(p-1)^rest] U_p^LA (columns of panel p+1 only), B_(p+1), ...
-//   diag  stream sD : [wait B_p, U_(p-1)^rest] update of the next diagonal block with panel p, D_(p+1)
-//   bulk  stream sU : [wait B_p] U_p^rest (columns right of panel p+1)          <- the MFMA bulk
-// so that the latency-bound panel work (B, D) runs under the bulk update of the previous panel.
-static void cholesky_full_lookahead(gpg_ctx* c) {
-  const int ld = c->ld, Npad = c->Npad, NB = c->nb_outer;
-  double* A = c->A;
-  hipStream_t sM = c->stream, sD = c->stream_upd, sU = c->stream_bulk;
-  const int npanel = (Npad + NB - 1) / NB;
-  while ((int)c->ev_panel.size() < npanel + 1) {
-    hipEvent_t e1, e2;
-    (void)hipEventCreateWithFlags(&e1, hipEventDisableTiming);
-    (void)hipEventCreateWithFlags(&e2, hipEventDisableTiming);
-    c->ev_panel.push_back(e1);
-    c->ev_upd.push_back(e2);
-  }
-  while ((int)c->ev_bulk.size() < npanel + 1) {
-    hipEvent_t e;
-    (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
-    c->ev_bulk.push_back(e);
-  }
-  c->stream = sM;
-  factor_diag_block(c, 0, NB < Npad ? NB : Npad);
-  int last_bulk = -1;
-  int p = 0;
-  for (int k0 = 0; k0 < Npad; k0 += NB, ++p) {
-    const int k1 = (k0 + NB < Npad) ? k0 + NB : Npad;
-    c->stream = sM;
-    if (p > 0) (void)hipStreamWaitEvent(sM, c->ev_panel[p], 0);       // D_p done
-    solve_below_block(c, k0, k1);                                     // B_p
-    if (k1 >= Npad) break;
-    (void)hipEventRecord(c->ev_upd[p], sM);                           // eB_p
-    const int k2 = (k1 + NB < Npad) ? k1 + NB : Npad;
-    const int K = k1 - k0;
-    const double* Ap = A + (size_t)k0 * ld;
-    const double w = (double)(k2 - k1), nt = (double)(Npad - k1);
-    // --- diag stream: next diagonal block, then D_(p+1)
-    c->stream = sD;
-    (void)hipStreamWaitEvent(sD, c->ev_upd[p], 0);
-    if (last_bulk >= 0) (void)hipStreamWaitEvent(sD, c->ev_bulk[last_bulk], 0);
-    gpg_prof_begin(c, GPG_PROF_POTRF, w * (w + 1.0) * (double)K);
-    launch_gemm<64, 64>(c, A + (size_t)k1 + (size_t)k1 * ld, ld, Ap + k1, ld, Ap + k1, ld, k2 - k1, k2 - k1, K, 1);
-    gpg_prof_end(c);
-    factor_diag_block(c, k1, k2);
-    (void)hipEventRecord(c->ev_panel[p + 1], sD);
-    // --- bulk stream: everything right of panel p+1
-    if (k2 < Npad) {
-      c->stream = sU;
-      (void)hipStreamWaitEvent(sU, c->ev_upd[p], 0);
-      const double ntr = (double)(Npad - k2);
-      gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, ntr * (ntr + 1.0) * (double)K);
-      launch_gemm_trailing(c, A + (size_t)k2 + (size_t)k2 * ld, ld, Ap + k2, ld, Ap + k2, ld, ld - k2, Npad - k2, K, 0);
-      gpg_prof_end(c);
-    }
-    // --- panel stream: look-ahead update of panel p+1's columns (diag block excluded)
-    c->stream = sM;
-    if (last_bulk >= 0) (void)hipStreamWaitEvent(sM, c->ev_bulk[last_bulk], 0);
-    gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, 2.0 * (double)K * (w * nt - w * (w - 1.0) / 2.0) - w * (w + 1.0) * (double)K);
-    launch_gemm_trailing(c, A + (size_t)k1 + (size_t)k1 * ld, ld, Ap + k1, ld, Ap + k1, ld, ld - k1, k2 - k1, K, k2 - k1);
-    gpg_prof_end(c);
-    if (k2 < Npad) {
-      (void)hipEventRecord(c->ev_bulk[p], sU);
-      last_bulk = p;
-    }
-  }
-  c->stream = sM;
-  if (last_bulk >= 0) (void)hipStreamWaitEvent(sM, c->ev_bulk[last_bulk], 0);
-}
-
 void gpg_cholesky(gpg_ctx* c) {
-  if (c->lookahead == 2) { cholesky_full_lookahead(c); return; }
   const int ld = c->ld, Npad = c->Npad, NB = c->nb_outer;
-  const int SB = (c->nb_super / NB > 0 ? c->nb_super / NB : 1) * NB;   // super-panel = whole number of panels
   double* A = c->A;
   hipStream_t sM = c->stream, sD = c->lookahead ? c->stream_upd : c->stream;
   const bool two = (sD != sM);
@@ -790,50 +552,38 @@ void gpg_cholesky(gpg_ctx* c) {
   // D_0 follows the assembly on the main stream
   c->stream = sM;
   factor_diag_block(c, 0, NB < Npad ? NB : Npad);
-  int p = 0;
-  for (int s0 = 0; s0 < Npad; s0 += SB) {
-    const int s1 = (s0 + SB < Npad) ? s0 + SB : Npad;             // super-panel = columns [s0, s1)
-    for (int k0 = s0; k0 < s1; k0 += NB, ++p) {
-      const int k1 = (k0 + NB < s1) ? k0 + NB : s1;                // panel p = columns [k0, k1)
+  for (int k0 = 0, p = 0; k0 < Npad; k0 += NB, ++p) {
+    const int k1 = (k0 + NB < Npad) ? k0 + NB : Npad;               // panel p = columns [k0, k1)
+    c->stream = sM;
+    if (two && p > 0) (void)hipStreamWaitEvent(sM, c->ev_panel[p], 0);
+    solve_below_block(c, k0, k1);                                   // B_p (also carries the RHS rows)
+    if (k1 >= Npad) break;
+    const int k2 = (k1 + NB < Npad) ? k1 + NB : Npad;               // next diagonal block = [k1, k2)
+    const int K = k1 - k0;
+    const double* Ap = A + (size_t)k0 * ld;
+    const double w = (double)(k2 - k1), nt = (double)(Npad - k1);
+    const double flops_all = nt * (nt + 1.0) * (double)K;           // lower triangle of the trailing block
+    const double flops_diag = w * (w + 1.0) * (double)K;
+    if (two) {
+      (void)hipEventRecord(c->ev_upd[p], sM);
+      // diag stream: next diagonal block -= its rows of panel p, then D_(p+1)
+      c->stream = sD;
+      (void)hipStreamWaitEvent(sD, c->ev_upd[p], 0);
+      gpg_prof_begin(c, GPG_PROF_POTRF, flops_diag);
+      launch_gemm<64, 64>(c, A + (size_t)k1 + (size_t)k1 * ld, ld, Ap + k1, ld, Ap + k1, ld, k2 - k1, k2 - k1, K, 1);
+      gpg_prof_end(c);
+      factor_diag_block(c, k1, k2);
+      (void)hipEventRecord(c->ev_panel[p + 1], sD);
+      // main stream: the rest of the trailing update
       c->stream = sM;
-      if (two && p > 0) (void)hipStreamWaitEvent(sM, c->ev_panel[p], 0);
-      solve_below_block(c, k0, k1);                                 // B_p (also carries the RHS rows)
-      if (k1 >= Npad) break;
-      const int k2 = (k1 + NB < Npad) ? k1 + NB : Npad;             // next diagonal block = [k1, k2)
-      // Two-level blocking: inside a super-panel the update with panel p only reaches the remaining
-      // columns of the super-panel (K = panel width); everything right of the super-panel is updated
-      // once per super-panel with K = super-panel width, which divides the C read+write traffic of the
-      // far region by SB / NB.
-      const bool far = (k1 == s1);
-      const int kc0 = far ? s0 : k0;                                // first column of the A operand
-      const int K = k1 - kc0;
-      const int cend = far ? Npad : s1;                             // update columns [k1, cend)
-      const double* Ap = A + (size_t)kc0 * ld;
-      const double w = (double)(k2 - k1), wc = (double)(cend - k1), nt = (double)(Npad - k1);
-      const double flops_all = 2.0 * (double)K * (wc * nt - wc * (wc - 1.0) / 2.0);   // lower trapezoid
-      const double flops_diag = w * (w + 1.0) * (double)K;
-      if (two) {
-        (void)hipEventRecord(c->ev_upd[p], sM);
-        // diag stream: next diagonal block -= its rows of the A operand, then D_(p+1)
-        c->stream = sD;
-        (void)hipStreamWaitEvent(sD, c->ev_upd[p], 0);
-        gpg_prof_begin(c, GPG_PROF_POTRF, flops_diag);
-        launch_gemm<64, 64>(c, A + (size_t)k1 + (size_t)k1 * ld, ld, Ap + k1, ld, Ap + k1, ld, k2 - k1, k2 - k1, K, 1);
-        gpg_prof_end(c);
-        factor_diag_block(c, k1, k2);
-        (void)hipEventRecord(c->ev_panel[p + 1], sD);
-        // main stream: the rest of the update
-        c->stream = sM;
-        gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, flops_all - flops_diag);
-        launch_gemm_trailing(c, A + (size_t)k1 + (size_t)k1 * ld, ld, Ap + k1, ld, Ap + k1, ld, ld - k1, cend - k1, K,
-                             k2 - k1);
-        gpg_prof_end(c);
-      } else {
-        gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, flops_all);
-        launch_gemm_trailing(c, A + (size_t)k1 + (size_t)k1 * ld, ld, Ap + k1, ld, Ap + k1, ld, ld - k1, cend - k1, K, 0);
-        gpg_prof_end(c);
-        factor_diag_block(c, k1, k2);
-      }
+      gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, flops_all - flops_diag);
+      launch_gemm_trailing(c, A + (size_t)k1 + (size_t)k1 * ld, ld, Ap + k1, ld, Ap + k1, ld, ld - k1, Npad - k1, K, k2 - k1);
+      gpg_prof_end(c);
+    } else {
+      gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, flops_all);
+      launch_gemm_trailing(c, A + (size_t)k1 + (size_t)k1 * ld, ld, Ap + k1, ld, Ap + k1, ld, ld - k1, Npad - k1, K, 0);
+      gpg_prof_end(c);
+      factor_diag_block(c, k1, k2);
     }
   }
   c->stream = sM;

@@ -32,12 +32,8 @@ struct gpg_ctx {
   hipStream_t stream = nullptr;      // main stream
   hipStream_t stream_upd = nullptr;  // high-priority stream: look-ahead factorisation of the next diagonal block
   int lookahead = 1;
-  int gemm_stagger = 0;              // de-phase the first round of trailing-update workgroups
-  int dyn_lds_ballast = 0;           // diagnostic only: extra dynamic LDS per workgroup (limits residency)
-  int gemm_ring = 4;                 // LDS ring depth of the DMA kernel (4: 2 workgroups/CU, 2: 3 workgroups/CU)
-  int gemm_impl = 1;                 // 1: LDS-DMA ring kernel for the 128x128 updates, 0: register-staged kernel
-  std::vector<hipEvent_t> ev_panel, ev_upd, ev_bulk;
-  hipStream_t stream_bulk = nullptr; // lowest priority: bulk trailing updates of the full look-ahead
+  int gemm_impl = 1;                 // 1: LDS-DMA ring kernel for the 128x128 updates, 0: register-staged kernel (A/B runs)
+  std::vector<hipEvent_t> ev_panel, ev_upd;
   std::map<unsigned long long, TileMap> tilemaps;   // live-tile lists of the trailing updates, per shape
   int n = 0, d = 0, use_grad = 0, kernel = 0;
   int N = 0, Npad = 0, R = GPG_RHS_ROWS, ld = 0;
@@ -45,7 +41,6 @@ struct gpg_ctx {
   int* gpos = nullptr;       // device [n]
   size_t A_elems = 0;        // allocated size of A (doubles), sized for all gradients
   int nb_outer = 256;   // panel width
-  int nb_super = 256;   // super-panel width of the two-level trailing update (== nb_outer: single level; measured best)
   // device buffers
   double* A = nullptr;       // [ld x Npad] column-major; lower triangle + RHS rows
   double* Xt = nullptr;      // [d x n]   (coordinate-major copy of x for coalesced loads)

@@ -605,8 +605,8 @@ class GaussianProcess:
             raise _lib.GpgError(f'gpg_prof_read failed ({rc}): {self._err()}')
         return {c: dict(ms=ms[i], count=cnt[i], work=work[i]) for i, c in enumerate(_lib.PROF_CATS)}
 
-    def set_panel(self, nb_outer, nb_super=0):
-        rc = self._lib.gpg_set_panel(self._ctx, int(nb_outer) + 65536 * int(nb_super))
+    def set_panel(self, nb_outer):
+        rc = self._lib.gpg_set_panel(self._ctx, int(nb_outer))
         if rc != 0:
             raise _lib.GpgError(f'gpg_set_panel failed ({rc}): {self._err()}')
 

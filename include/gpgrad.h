@@ -137,11 +137,11 @@ int gpg_prof_enable(gpg_ctx* ctx, unsigned mask);
 int gpg_prof_read(gpg_ctx* ctx, double ms[GPG_PROF_NCAT], long long count[GPG_PROF_NCAT],
                   double work[GPG_PROF_NCAT]);
 
-/* Tuning knobs (defaults are the measured best): nb_outer = panel width (multiple of 128 in
- * [128, 1024]) + 65536 * super-panel width (multiple of the panel width; 0 = keep). */
+/* Tuning knobs (defaults are the measured best): panel width (multiple of 128 in [128, 1024]). */
 int gpg_set_panel(gpg_ctx* ctx, int nb_outer);
-/* 1 (default): two-stream look-ahead Cholesky (next panel factorised under the trailing update);
- * 0: single stream. */
+/* bit 0 = 1 (default): look-ahead Cholesky (the next diagonal block is factorised on a second,
+ * high-priority stream under the trailing update); 0: single stream.  bit 1 = 1: register-staged
+ * 128x128 update kernel instead of the LDS-DMA one (A/B measurements only). */
 int gpg_set_lookahead(gpg_ctx* ctx, int on);
 
 /* Library / device facts for logs: writes "gfx950 MI355X ..." style text. */

@@ -8,10 +8,7 @@ void gpg_prof_end(gpg_ctx*) {}
 int main(int argc, char** argv) {
   int Nt = argc > 1 ? atoi(argv[1]) : 16384, K = argc > 2 ? atoi(argv[2]) : 256, impl = argc > 3 ? atoi(argv[3]) : 1;
   gpg_ctx c;
-  c.dyn_lds_ballast = argc > 4 ? atoi(argv[4]) : 0;
-  c.gemm_impl = impl & 3;
-  c.gemm_stagger = 0;
-  c.gemm_ring = (impl >> 2) ? (impl >> 2) : 4;   // impl = 1 + 4 * ring
+  c.gemm_impl = impl & 1;
   hipStreamCreate(&c.stream);
   int ld = Nt + 128;
   double *C, *P;
@@ -25,8 +22,8 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   {
     int nb = -1;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_dma_kernel<2>, 256, 0);
-    hipFuncAttributes fa; hipFuncGetAttributes(&fa, (const void*)gemm_dma_kernel<2>);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, gemm_dma_kernel<4>, 256, 0);
+    hipFuncAttributes fa; hipFuncGetAttributes(&fa, (const void*)gemm_dma_kernel<4>);
     printf("gemm_dma_kernel: occupancy API %d blocks/CU, regs %d, static LDS %zu B\n", nb, fa.numRegs, fa.sharedSizeBytes);
   }
 #ifdef GPG_STAMP
