@@ -27,11 +27,12 @@ if ROOT not in sys.path:
 FP64_MFMA_PEAK_TFLOPS = 78.6   # v_mfma_f64_16x16x4_f64: 64 cycles / instr / SIMD measured (profiles/r01_fp64_pipe_probe.log)
                                # = 32 flop/clk/SIMD x 1024 SIMDs x 2.4 GHz; equals AMD's datasheet FP64 matrix figure
 HBM_PEAK_GBS = 8000.0
-# HBM bytes per trailing-update launch at n=2000, d=8 from the PMC passes of profiles/r01_pmc_summary.txt
-# (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes over this same command; gfx950 FETCH_SIZE
-# x2 for wide streamed reads per MI355X_MICROARCH.md; 70 launches per evaluation):
-# (2 * 27.69 GB + 30.94 GB) / 70 = 1.233 GB, against 0.857 GB of algorithmic C read + write.
-PMC_TRAFFIC_BYTES_PER_LAUNCH_CFG3 = (2 * 27.69e9 + 30.94e9) / 70.0
+# HBM bytes per trailing-update launch at n=2000, d=8 (panel 512: 35 launches per evaluation) from the PMC
+# passes of profiles/r01_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes over
+# this same command, 2 evaluations = 70 launches): WRITE_SIZE 30.28 GB = the C tiles exactly; FETCH_SIZE
+# 39.06 GB raw, doubled per MI355X_MICROARCH.md (gfx950 counts wide streamed reads at half their bytes; the
+# 8-byte C-tile loads are uncalibrated, so this is an upper bound).  Algorithmic C read + write: 0.865 GB.
+PMC_TRAFFIC_BYTES_PER_LAUNCH_CFG3 = (2 * 39.06e9 + 30.28e9) / 70.0
 
 
 def make_workload(n, d, cfg="cfg3"):
@@ -208,7 +209,7 @@ def main():
                                    "(rows of the BASELINE.md section 3 restart table, 8 per rank)",
                        "n": n, "d": d, "N": N, "kernel": kernel, "wellcond": "precon",
                        "evals_per_gpu": args.steps, "parallelism": f"restarts sharded over {world} rank(s), one all_gather ({backend if world > 1 else 'none'})"},
-            "roofline": {"bound": "mfma", "kernel": "gemm_nt_minus_kernel<128,128> (Cholesky trailing update)",
+            "roofline": {"bound": "mfma", "kernel": "gemm_dma_kernel<4> (Cholesky trailing update C -= A_p A_p^T, 128x128 tiles)",
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
                          "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH_CFG3 if (n, d, args.config) == (2000, 8, "cfg3") else None,
