@@ -175,7 +175,7 @@ void gpg_destroy(gpg_ctx* c) {
   for (auto& pe : c->prof_pending) { (void)hipEventDestroy(pe.e0); (void)hipEventDestroy(pe.e1); }
   for (auto& ev : c->prof_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   double* bufs[] = {c->A, c->Xt, c->y, c->noise, c->dvec, c->invp, c->zvec, c->tmpv, c->dinv, c->scal, c->Wt, c->xq_dev,
-                    c->musig, c->dense_tmp};
+                    c->musig, c->gradbuf, c->dense_tmp};
   for (double* b : bufs) if (b) (void)hipFree(b);
   if (c->info) (void)hipFree(c->info);
   if (c->gpos) (void)hipFree(c->gpos);
@@ -207,7 +207,7 @@ int gpg_set_grad_mask(gpg_ctx* c, const unsigned char* use_grad_pt) {
   c->have_data = false;
   c->factor_valid = c->eval_ready = false;
   if (c->dense_tmp) { (void)hipFree(c->dense_tmp); c->dense_tmp = nullptr; }
-  if (c->Wt) { (void)hipFree(c->Wt); (void)hipFree(c->xq_dev); (void)hipFree(c->musig); c->Wt = c->xq_dev = c->musig = nullptr; c->xq_cap = 0; }
+  if (c->Wt) { (void)hipFree(c->Wt); (void)hipFree(c->xq_dev); (void)hipFree(c->musig); (void)hipFree(c->gradbuf); c->Wt = c->xq_dev = c->musig = c->gradbuf = nullptr; c->xq_cap = 0; }
   return 0;
 }
 
@@ -306,7 +306,21 @@ int gpg_setup_eval(gpg_ctx* c, const gpg_hp* hp, double beta, double* alpha_out)
   return 0;
 }
 
+static int predict_impl(gpg_ctx* c, int nx, const double* xq, double varK, double* mu, double* sig, double* sig2_raw,
+                        double* dmudx, double* dsigdx);
+
 int gpg_predict(gpg_ctx* c, int nx, const double* xq, double varK, double* mu, double* sig, double* sig2_raw) {
+  return predict_impl(c, nx, xq, varK, mu, sig, sig2_raw, nullptr, nullptr);
+}
+
+int gpg_predict_grad(gpg_ctx* c, int nx, const double* xq, double varK, double* mu, double* sig, double* sig2_raw,
+                     double* dmudx, double* dsigdx) {
+  if (c && (!dmudx || !dsigdx)) { c->err = "dmudx / dsigdx is NULL"; return -1; }
+  return predict_impl(c, nx, xq, varK, mu, sig, sig2_raw, dmudx, dsigdx);
+}
+
+static int predict_impl(gpg_ctx* c, int nx, const double* xq, double varK, double* mu, double* sig, double* sig2_raw,
+                        double* dmudx, double* dsigdx) {
   if (!c) return -1;
   if (!c->eval_ready) { c->err = "gpg_setup_eval must succeed before gpg_predict"; return -1; }
   if (nx < 1 || !xq || !mu || !sig) { c->err = "bad predict arguments"; return -1; }
@@ -316,10 +330,12 @@ int gpg_predict(gpg_ctx* c, int nx, const double* xq, double varK, double* mu, d
     if (c->Wt) (void)hipFree(c->Wt);
     if (c->xq_dev) (void)hipFree(c->xq_dev);
     if (c->musig) (void)hipFree(c->musig);
-    c->Wt = c->xq_dev = c->musig = nullptr; c->xq_cap = 0;
+    if (c->gradbuf) (void)hipFree(c->gradbuf);
+    c->Wt = c->xq_dev = c->musig = c->gradbuf = nullptr; c->xq_cap = 0;
     GPG_HIP_OK(c, hipMalloc(&c->Wt, sizeof(double) * (size_t)nxp * c->Npad));
     GPG_HIP_OK(c, hipMalloc(&c->xq_dev, sizeof(double) * (size_t)nxp * c->d));
     GPG_HIP_OK(c, hipMalloc(&c->musig, sizeof(double) * 2 * nxp));
+    GPG_HIP_OK(c, hipMalloc(&c->gradbuf, sizeof(double) * ((size_t)2 * nxp * GPG_MAX_DIM + (size_t)nxp * 64)));
     c->xq_cap = nxp;
   }
   // the allocation may be larger than this call's nxp: kernels index with this call's nxp
@@ -333,6 +349,17 @@ int gpg_predict(gpg_ctx* c, int nx, const double* xq, double varK, double* mu, d
   gpg_launch_predict_reduce(c, nx, nxp, c->eval_beta, varK, 0);
   gpg_forward_rows(c, c->Wt, nxp, nxp);
   gpg_launch_predict_reduce(c, nx, nxp, c->eval_beta, varK, 1);
+  std::vector<double> hgrad;
+  if (dmudx) {
+    // K^-1 Kyx needs the second triangular sweep too (GpEvalModel.py:154), then the fused gradient reductions
+    double* g1 = c->gradbuf;
+    double* g2 = c->gradbuf + (size_t)nxp * GPG_MAX_DIM;
+    double* tbuf = c->gradbuf + (size_t)2 * nxp * GPG_MAX_DIM;
+    gpg_backward_rows(c, c->Wt, nxp, nx, tbuf);
+    gpg_launch_cross_grad(c, p, nx, nxp, g1, g2);
+    hgrad.resize((size_t)2 * nxp * GPG_MAX_DIM);
+    GPG_HIP_OK(c, hipMemcpyAsync(hgrad.data(), c->gradbuf, sizeof(double) * hgrad.size(), hipMemcpyDeviceToHost, c->stream));
+  }
   std::vector<double> host(2 * (size_t)nxp);
   GPG_HIP_OK(c, hipMemcpyAsync(host.data(), c->musig, sizeof(double) * 2 * nxp, hipMemcpyDeviceToHost, c->stream));
   GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
@@ -343,6 +370,13 @@ int gpg_predict(gpg_ctx* c, int nx, const double* xq, double varK, double* mu, d
     double s2 = host[nxp + j];
     if (sig2_raw) sig2_raw[j] = s2;
     sig[j] = sqrt(s2 < 0.0 ? 0.0 : s2) * sigK;   // GpEvalModel.py:165-166
+    if (dmudx) {
+      const double inv_sig = sig[j] != 0.0 ? 1.0 / sig[j] : 0.0;      // GpEvalModel.py:346
+      for (int k = 0; k < c->d; ++k) {
+        dmudx[(size_t)j * c->d + k] = hgrad[(size_t)j * c->d + k];                                        // :319-325
+        dsigdx[(size_t)j * c->d + k] = -inv_sig * (hgrad[(size_t)nxp * GPG_MAX_DIM + (size_t)j * c->d + k] * varK);   // :339-354
+      }
+    }
   }
   return 0;
 }

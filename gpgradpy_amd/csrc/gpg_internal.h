@@ -57,6 +57,7 @@ struct gpg_ctx {
   int wt_rows = 0;
   double* xq_dev = nullptr;  // [d x nxp]
   double* musig = nullptr;   // [2 x nxp]
+  double* gradbuf = nullptr; // [2 x nxp x d] posterior-gradient reductions + [nxp x 64] backward-solve scratch
   int xq_cap = 0;
   double* dense_tmp = nullptr;  // [N x N] materialisation buffer (on request)
   // pinned host staging
@@ -92,6 +93,8 @@ void gpg_launch_lkd_reduce(gpg_ctx* c, int slot);                        // writ
 void gpg_backward_solve(gpg_ctx* c);                                     // zvec <- L^-T (RHS row 0)
 void gpg_launch_alpha(gpg_ctx* c, double* alpha_dev);                    // alpha = zvec * invp
 void gpg_launch_predict_reduce(gpg_ctx* c, int nx, int nxp, double beta, double varK, int phase);
+void gpg_backward_rows(gpg_ctx* c, double* Z, int ldz, int nrhs, double* tbuf);  // Z <- Z L^-1 (multi-RHS)
+void gpg_launch_cross_grad(gpg_ctx* c, const AsmParams& p, int nx, int nxp, double* g1, double* g2);
 void gpg_launch_extract(gpg_ctx* c, int which);                          // dense_tmp <- sym / P L
 
 // profiling helpers

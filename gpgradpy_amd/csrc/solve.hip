@@ -123,6 +123,135 @@ __global__ void __launch_bounds__(1024) predict_reduce_kernel(const double* __re
   }
 }
 
+// ---- multi right-hand-side backward solve on the "RHS rows" layout Z[r + i * ldz] (in place) ----------
+// t[r * 64 + j] = sum_{i >= k0+64} L[i, k0+j] Z[r, i]   (workgroup = column j x a group of 16 right-hand sides)
+__global__ void __launch_bounds__(256) bs_dot_multi_kernel(const double* __restrict__ A, int ld, int Npad, int k0,
+                                                           const double* __restrict__ Z, int ldz, int nrhs,
+                                                           double* __restrict__ t) {
+  __shared__ double sh[16 * 16];
+  const int j = blockIdx.x, r0 = blockIdx.y * 16;
+  const double* colp = A + (size_t)(k0 + j) * ld;
+  double v[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) v[q] = 0.0;
+  for (int i = k0 + 64 + threadIdx.x; i < Npad; i += 256) {
+    const double l = colp[i];
+    const double* zp = Z + (size_t)i * ldz + r0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] += l * zp[q];
+  }
+  block_sum<16>(v, sh);
+  if (threadIdx.x < 16 && r0 + threadIdx.x < nrhs) t[(size_t)(r0 + threadIdx.x) * 64 + j] = v[threadIdx.x];
+}
+
+// solve L_kk^T z_k = w_k - t for right-hand side r = blockIdx.x (one wave, lane j <-> unknown j)
+__global__ void __launch_bounds__(64) bs_tri_multi_kernel(const double* __restrict__ A, int ld, int k0,
+                                                          const double* __restrict__ t, int has_t,
+                                                          double* __restrict__ Z, int ldz) {
+  __shared__ double Ls[64][65];
+  const int j = threadIdx.x, r = blockIdx.x;
+  for (int q = 0; q < 64; ++q) Ls[j][q] = A[(size_t)(k0 + j) + (size_t)(k0 + q) * ld];
+  __syncthreads();
+  double rhs = Z[(size_t)(k0 + j) * ldz + r] - (has_t ? t[(size_t)r * 64 + j] : 0.0);
+  double zj = 0.0;
+  for (int i = 63; i >= 0; --i) {
+    double zi = __shfl(rhs, i, 64) / Ls[i][i];
+    if (j == i) zj = zi;
+    if (j < i) rhs -= Ls[i][j] * zi;
+  }
+  Z[(size_t)(k0 + j) * ldz + r] = zj;
+}
+
+// Posterior gradient reductions (reference GpEvalModel.py:135-140, 319-354): for query q and direction j'
+//   g1[q, j'] = sum_c dKxy_dx[(j', q), c] alpha_c              -> dmu/dx
+//   g2[q, j'] = sum_c dKxy_dx[(j', q), c] (K^-1 Kyx)[c, q]     -> d sig/dx = -varK g2 / sig
+// dKxy_dx[(j', q), c] = block (I, j'+1) of the gradient-enhanced kernel at (x_a, xq_q), c = (I, a); it is
+// recomputed on the fly (never stored).  zvec = p * alpha, Z = L^-T L^-1 P^-1 Kyx (RHS-rows layout).
+template <int KERN, int D>
+__global__ void __launch_bounds__(256) cross_grad_kernel(AsmParams P, const double* __restrict__ Xt,
+                                                         const double* __restrict__ Xq, int nxp,
+                                                         const double* __restrict__ invp, const double* __restrict__ zvec,
+                                                         const double* __restrict__ Z, double* __restrict__ g1o,
+                                                         double* __restrict__ g2o) {
+  __shared__ double sh[2 * D * 16];
+  const int q = blockIdx.x, n = P.n, ng = P.ng;
+  const int nblk = P.use_grad ? D + 1 : 1;
+  double g[2 * D];
+#pragma unroll
+  for (int k = 0; k < 2 * D; ++k) g[k] = 0.0;
+  double xq[D], th[D];
+#pragma unroll
+  for (int k = 0; k < D; ++k) { xq[k] = Xq[(size_t)k * nxp + q]; th[k] = P.theta[k]; }
+  const double sqrt5 = sqrt(5.0);
+  for (int a = threadIdx.x; a < n; a += 256) {
+    double R[D], E, M1 = 0.0;
+    if (KERN == GPG_KERNEL_SQEXP) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) { R[k] = Xt[(size_t)k * n + a] - xq[k]; s -= th[k] * (R[k] * R[k]); }
+      E = exp(s);
+    } else {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) { R[k] = Xt[(size_t)k * n + a] - xq[k]; s += th[k] * (R[k] * R[k]); }
+      const double nu = sqrt(s);
+      E = exp(-sqrt5 * nu);
+      M1 = ((5.0 / 3.0) * (1.0 + sqrt5 * nu)) * E;
+    }
+    const int gpa = P.gpos[a];
+    // I = 0 : block (0, j'+1) = +2 th R E  (SqExp) / + th R mat1 (Matern)
+    {
+      const double wa = zvec[a] * invp[a], ws = Z[(size_t)a * nxp + q] * invp[a];
+#pragma unroll
+      for (int jp = 0; jp < D; ++jp) {
+        const double v = KERN == GPG_KERNEL_SQEXP ? ((2.0 * th[jp]) * R[jp]) * E : (th[jp] * R[jp]) * M1;
+        g[jp] += v * wa;
+        g[D + jp] += v * ws;
+      }
+    }
+    if (nblk > 1 && gpa >= 0) {
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        const size_t c = (size_t)n + (size_t)i * ng + gpa;
+        const double ip = invp[c];
+        const double wa = zvec[c] * ip, ws = Z[c * nxp + q] * ip;
+#pragma unroll
+        for (int jp = 0; jp < D; ++jp) {
+          double v;
+          if (KERN == GPG_KERNEL_SQEXP) {
+            v = (i == jp) ? (2.0 * th[i] - (4.0 * (th[i] * th[i])) * (R[i] * R[i])) * E
+                          : ((-4.0 * th[i]) * th[jp]) * ((R[i] * R[jp]) * E);
+          } else {
+            v = (i == jp) ? th[i] * M1 - (((25.0 / 3.0) * (th[i] * th[i])) * (R[i] * R[i])) * E
+                          : (((((-(25.0 / 3.0)) * th[i]) * th[jp]) * R[i]) * R[jp]) * E;
+          }
+          g[jp] += v * wa;
+          g[D + jp] += v * ws;
+        }
+      }
+    }
+  }
+  block_sum<2 * D>(g, sh);
+  if (threadIdx.x < D) {
+    g1o[(size_t)q * D + threadIdx.x] = g[threadIdx.x];
+    g2o[(size_t)q * D + threadIdx.x] = g[D + threadIdx.x];
+  }
+}
+
+template <int KERN>
+void launch_cross_grad_d(gpg_ctx* c, const AsmParams& p, int nx, int nxp, double* g1, double* g2) {
+#define CASE_D(DD)                                                                                          \
+  case DD:                                                                                                  \
+    hipLaunchKernelGGL((cross_grad_kernel<KERN, DD>), dim3(nx), dim3(256), 0, c->stream, p, c->Xt, c->xq_dev, nxp, \
+                       c->invp, c->zvec, c->Wt, g1, g2);                                                    \
+    break;
+  switch (p.d) {
+    CASE_D(1) CASE_D(2) CASE_D(3) CASE_D(4) CASE_D(5) CASE_D(6) CASE_D(7) CASE_D(8)
+    CASE_D(9) CASE_D(10) CASE_D(11) CASE_D(12) CASE_D(13) CASE_D(14) CASE_D(15) CASE_D(16)
+  }
+#undef CASE_D
+}
+
 // which 0..2: symmetric copy of the lower triangle; which 3: P L (lower), zeros above
 __global__ void extract_kernel(const double* __restrict__ A, int ld, int N, const double* __restrict__ dvec,
                                int precon, int which, double* __restrict__ out) {
@@ -154,6 +283,23 @@ void gpg_backward_solve(gpg_ctx* c) {
       hipLaunchKernelGGL(bs_dot_kernel, dim3(64), dim3(256), 0, c->stream, c->A, c->ld, Npad, k0, c->zvec, c->tmpv);
     hipLaunchKernelGGL(bs_tri_kernel, dim3(1), dim3(64), 0, c->stream, c->A, c->ld, Npad, k0, c->tmpv, has_t, c->zvec);
   }
+}
+
+// Z (nrhs x Npad, RHS-rows layout, leading dimension ldz) <- Z L^-1, i.e. every row solved against L^T
+void gpg_backward_rows(gpg_ctx* c, double* Z, int ldz, int nrhs, double* tbuf) {
+  const int Npad = c->Npad;
+  for (int k0 = Npad - 64; k0 >= 0; k0 -= 64) {
+    const int has_t = (k0 + 64 < Npad);
+    if (has_t)
+      hipLaunchKernelGGL(bs_dot_multi_kernel, dim3(64, (nrhs + 15) / 16), dim3(256), 0, c->stream, c->A, c->ld, Npad, k0, Z,
+                         ldz, nrhs, tbuf);
+    hipLaunchKernelGGL(bs_tri_multi_kernel, dim3(nrhs), dim3(64), 0, c->stream, c->A, c->ld, k0, tbuf, has_t, Z, ldz);
+  }
+}
+
+void gpg_launch_cross_grad(gpg_ctx* c, const AsmParams& p, int nx, int nxp, double* g1, double* g2) {
+  if (p.kernel == GPG_KERNEL_SQEXP) launch_cross_grad_d<GPG_KERNEL_SQEXP>(c, p, nx, nxp, g1, g2);
+  else launch_cross_grad_d<GPG_KERNEL_MA5F2>(c, p, nx, nxp, g1, g2);
 }
 
 void gpg_launch_alpha(gpg_ctx* c, double* alpha_dev) {

@@ -560,10 +560,11 @@ class GaussianProcess:
             self._eval_ready = True
 
     def eval_model(self, x2model_in, calc_grad=False, calc_hess=False, squeeze_nx=False):
-        """GpEvalModel.py:59-198 for calc_grad=False: returns (mu, sig, None, None, None, None)."""
+        """GpEvalModel.py:59-198: returns (mu, sig, dmudx, dsigdx, None, None); Hessians are not built."""
         assert self.KernEta_chofac is not None, 'To evaluate the surr the Cholesky decomposition is required'
-        if calc_grad or calc_hess:
-            raise NotImplementedError('posterior derivatives are not on the accelerated path yet (SURVEY.md 8f3)')
+        if calc_hess:
+            assert calc_grad, 'To return the hessian calc_grad must also be set to True'      # GpEvalModel.py:126-127
+            raise NotImplementedError('posterior Hessians are not on the accelerated path yet (SURVEY.md 8f3)')
         if x2model_in.ndim == 1:
             x2model = x2model_in[None, :]
         elif x2model_in.ndim == 2:
@@ -579,15 +580,23 @@ class GaussianProcess:
             raise Exception('setup_eval_model() must be called again: the device factor was overwritten by a likelihood evaluation')
         xq = np.ascontiguousarray(x2model, dtype=np.float64)
         mu, sig, s2 = np.empty(nx), np.empty(nx), np.empty(nx)
-        rc = self._lib.gpg_predict(self._ctx, nx, _lib.as_dp(xq), float(self.hp_vals.varK), _lib.as_dp(mu),
-                                   _lib.as_dp(sig), _lib.as_dp(s2))
+        dmudx = dsigdx = None
+        if calc_grad:
+            dmudx, dsigdx = np.empty((nx, self.dim)), np.empty((nx, self.dim))
+            rc = self._lib.gpg_predict_grad(self._ctx, nx, _lib.as_dp(xq), float(self.hp_vals.varK), _lib.as_dp(mu),
+                                            _lib.as_dp(sig), _lib.as_dp(s2), _lib.as_dp(dmudx), _lib.as_dp(dsigdx))
+        else:
+            rc = self._lib.gpg_predict(self._ctx, nx, _lib.as_dp(xq), float(self.hp_vals.varK), _lib.as_dp(mu),
+                                       _lib.as_dp(sig), _lib.as_dp(s2))
         if rc != 0:
             raise _lib.GpgError(f'gpg_predict failed ({rc}): {self._err()}')
         assert np.min(s2) >= 0, \
             f'The variance of the surr should be non-negative but min(sig2_wo_sigK) = {np.min(s2)}'   # GpEvalModel.py:163
         if squeeze_nx:
+            if calc_grad:
+                return mu[0], sig[0], dmudx[0, :], dsigdx[0, :], None, None                 # GpEvalModel.py:186-192
             return mu[0], sig[0], None, None, None, None
-        return mu, sig, None, None, None, None
+        return mu, sig, dmudx, dsigdx, None, None
 
     # ---- instrumentation -------------------------------------------------------------------------------
     def prof_enable(self, cats):

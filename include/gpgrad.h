@@ -110,6 +110,12 @@ int gpg_setup_eval(gpg_ctx* ctx, const gpg_hp* hp, double beta, double* alpha_ou
 int gpg_predict(gpg_ctx* ctx, int nx, const double* xq, double varK, double* mu, double* sig,
                 double* sig2_raw);
 
+/* Replaces eval_model(x, calc_grad=True) (GpEvalModel.py:133-140,170-172,319-354): additionally returns
+ * dmudx, dsigdx [nx, dim] row-major.  The derivative blocks of the cross-kernel are recomputed on the fly
+ * (the [N, nx*dim] matrix dKxy_dx is never formed); K^-1 Kyx costs one extra triangular sweep per query. */
+int gpg_predict_grad(gpg_ctx* ctx, int nx, const double* xq, double varK, double* mu, double* sig,
+                     double* sig2_raw, double* dmudx, double* dsigdx);
+
 /* Materialisation on request (the 7-tuple of Kernel.py:307 carries N x N arrays; the fast path never
  * copies them).  out is [N, N] column-major == row-major (symmetric) for which = 0..2:
  *   0 Kern (Kernel.py:213-216), 1 Kcov (Kernel.py:237 / 277), 2 the matrix that is factorised

@@ -281,6 +281,26 @@ def setup_eval_model(X, y, theta, kernel, use_grad, wellcond, etaK, noise_vec, b
                      fac.chofac, alpha, grad_mask)
 
 
+def eval_model_grad(m: EvalModel, xq):
+    """(mu, sig, dmudx, dsigdx) -- reference GpEvalModel.py:59-198 with calc_grad=True (:133-140, :319-354)."""
+    xq = np.atleast_2d(np.asarray(xq, dtype=float))
+    nx, d = xq.shape
+    Kg = kern_grad(m.X, xq, m.theta, m.kernel, grad_cols=True, mask1=m.grad_mask if m.use_grad else None)
+    if not m.use_grad:
+        Kg = Kg[:m.X.shape[0], :]                              # GpEvalModel.py:142-144
+    Kyx, dKxy_dx = Kg[:, :nx], Kg[:, nx:].T
+    sol = cho_solve(m.chofac, Kyx)
+    sig2 = 1.0 - np.einsum("ij,ij->j", Kyx, sol)
+    sig2[sig2 < 0] = 0.0
+    sig = np.sqrt(sig2) * np.sqrt(m.varK)
+    mu = m.beta[0] + Kyx.T @ m.alpha
+    dmudx = np.reshape(dKxy_dx @ m.alpha, (nx, d), order="F")
+    inv_sig = np.divide(1.0, sig, out=np.zeros_like(sig), where=sig != 0)
+    term2 = np.sum(dKxy_dx * np.kron(np.ones((d, 1)), sol.T), axis=1) * m.varK
+    dsigdx = -inv_sig[:, None] * term2.reshape((nx, d), order="F")
+    return mu, sig, dmudx, dsigdx
+
+
 def eval_model(m: EvalModel, xq):
     """Posterior mean and standard deviation -- reference GpEvalModel.py:59-198 (calc_grad=False)."""
     xq = np.atleast_2d(np.asarray(xq, dtype=float))

@@ -164,9 +164,11 @@ def make_case(GaussianProcess, name, n, d, kernel, noise, use_grad=True, wellcon
     GP.set_hpara('set', 0, hp_vals=hp2)
     out['alpha'] = np.asarray(GP.invKernEta_fdiff, dtype=float)
     out['varK_model'] = float(hp2.varK)
-    mu, sig = GP.eval_model(xq)[:2]
+    mu, sig, dmudx, dsigdx = GP.eval_model(xq, calc_grad=True)[:4]
     out['mu'] = mu
     out['sig'] = sig
+    out['dmudx'] = dmudx
+    out['dsigdx'] = dsigdx
     return out
 
 
@@ -284,14 +286,14 @@ def _micro(GaussianProcess):
     hp2 = GP.optz_closed_form_hp(hp)
     GP.set_hpara('set', 0, hp_vals=hp2)
     xq = np.array([[0.4]])
-    mu, sig = GP.eval_model(xq)[:2]
+    mu, sig, dmudx, dsigdx = GP.eval_model(xq, calc_grad=True)[:4]
     return dict(name='micro_d1', n=2, d=1, kernel='SqExp', noise='none', use_grad=True, wellcond='precon',
                 x=x, f=f, g=g, std_f=np.zeros(2), std_g=np.zeros((2, 1)), theta=np.array([0.5]),
                 varK_in=np.nan, var_fval=np.nan, var_fgrad=np.nan, etaK=GP._etaK, b_has_noisy_data=False,
                 b_chofac_good=True, xq=xq, n_data=4, bvec_use_grad=np.ones(2, dtype=bool), pnlt=np.array([np.nan, np.nan]), hp_beta=lkd.hp_beta, hp_varK=lkd.hp_varK,
                 ln_det_Kmat=lkd.ln_det_Kmat, ln_lkd=lkd.ln_lkd, noise_vec=np.zeros(4), chofac_lower=True,
                 chofac_diag=np.diag(chofac[0]).copy(), pvec=np.ones(4), Kern=Kern, Kcov=Kcov,
-                chofac=np.tril(chofac[0]), alpha=GP.invKernEta_fdiff, varK_model=hp2.varK, mu=mu, sig=sig)
+                chofac=np.tril(chofac[0]), alpha=GP.invKernEta_fdiff, varK_model=hp2.varK, mu=mu, sig=sig, dmudx=dmudx, dsigdx=dsigdx)
 
 
 if __name__ == '__main__':

@@ -77,9 +77,15 @@ def test_golden_case(path):
     mu, sig = GP.eval_model(c["xq"])[:2]
     np.testing.assert_allclose(mu, c["mu"], rtol=tol.MU_RTOL, atol=tol.MU_ATOL_SCALE * max(1.0, np.abs(c["mu"]).max()))
     np.testing.assert_allclose(sig, c["sig"], rtol=tol.SIG_RTOL, atol=tol.SIG_ATOL_SCALE * np.sqrt(hp2.varK))
+    # posterior gradients (reference GpEvalModel.py:170-172, 319-354)
+    mu_g, sig_g, dmudx, dsigdx, h1, h2 = GP.eval_model(c["xq"], calc_grad=True)
+    assert h1 is None and h2 is None and np.allclose(mu_g, mu, rtol=1e-12) and np.allclose(sig_g, sig, rtol=1e-9, atol=1e-14)
+    tol.check_post_grad(dmudx, dsigdx, c)
     # squeeze_nx contract
-    m1, s1 = GP.eval_model(c["xq"][0], squeeze_nx=True)[:2]
-    assert np.isclose(m1, mu[0]) and np.isclose(s1, sig[0])
+    m1, s1, dm1, ds1 = GP.eval_model(c["xq"][0], calc_grad=True, squeeze_nx=True)[:4]
+    assert np.isclose(m1, mu[0]) and np.isclose(s1, sig[0]) and dm1.shape == (c["d"],) and np.allclose(dm1, dmudx[0])
+    with pytest.raises(NotImplementedError):
+        GP.eval_model(c["xq"], calc_grad=True, calc_hess=True)
 
 
 def test_alpha_residual_against_reference_matrix():
@@ -165,6 +171,20 @@ def test_against_oracle_multi_panel(kernel, noise, n, d, panel):
     mu_o, sig_o = orc.eval_model(m, xq)
     np.testing.assert_allclose(mu, mu_o, rtol=tol.MU_RTOL, atol=tol.MU_ATOL_SCALE * max(1.0, np.abs(mu_o).max()))
     np.testing.assert_allclose(sig, sig_o, rtol=tol.SIG_RTOL, atol=tol.SIG_ATOL_SCALE * np.sqrt(hp2.varK))
+    # posterior gradients vs the oracle and vs central finite differences of the GPU mean itself
+    # (the design of the reference's unit_test/test_grad_surr.py:131-182)
+    dmudx, dsigdx = GP.eval_model(xq[:5], calc_grad=True)[2:4]
+    _, _, dmu_o, dsig_o = orc.eval_model_grad(m, xq[:5])
+    tol.check_post_grad(dmudx, dsigdx, dict(dmudx=dmu_o, dsigdx=dsig_o))
+    eps = 1e-5
+    x0 = xq[0]
+    fd = np.zeros(d)
+    for k in range(d):
+        xp, xm = x0.copy(), x0.copy()
+        xp[k] += eps
+        xm[k] -= eps
+        fd[k] = (GP.eval_model(xp[None, :])[0][0] - GP.eval_model(xm[None, :])[0][0]) / (2 * eps)
+    np.testing.assert_allclose(dmudx[0], fd, rtol=1e-4, atol=1e-6 * np.abs(fd).max())
 
 
 def test_gradient_free_base():

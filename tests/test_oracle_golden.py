@@ -66,6 +66,9 @@ def test_oracle_matches_reference(path):
     mu, sig = orc.eval_model(m, c["xq"])
     np.testing.assert_allclose(mu, c["mu"], rtol=tol.MU_RTOL, atol=tol.MU_ATOL_SCALE * max(1.0, np.abs(c["mu"]).max()))
     np.testing.assert_allclose(sig, c["sig"], rtol=tol.SIG_RTOL, atol=tol.SIG_ATOL_SCALE * np.sqrt(varK_model))
+    mu2, sig2, dmudx, dsigdx = orc.eval_model_grad(m, c["xq"])
+    np.testing.assert_allclose(mu2, mu, rtol=1e-12)
+    tol.check_post_grad(dmudx, dsigdx, c)
 
 
 def test_micro_example_survey_values():

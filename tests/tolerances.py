@@ -18,6 +18,7 @@ ALPHA_RESIDUAL = 1e-13    # ||Kcov alpha - r|| / (||Kcov|| ||alpha||)
 MU_RTOL, MU_ATOL_SCALE = 1e-7, 1e-9
 SIG_ATOL_SCALE = 1e-7     # abs tol = SIG_ATOL_SCALE * sqrt(varK)  (plus rtol 1e-5)
 SIG_RTOL = 1e-5
+DMU_RTOL, DSIG_RTOL = 1e-6, 1e-5      # posterior gradients (abs tol scaled by the largest entry)
 KERN_RTOL, KERN_ATOL = 1e-13, 1e-15   # assembled matrix entries (exp/sqrt ulp differences only)
 
 
@@ -27,3 +28,8 @@ def check_scalars(got_beta, got_varK, got_ln_det, got_ln_lkd, c, N, noisy):
     np.testing.assert_allclose(got_ln_lkd, c["ln_lkd"], rtol=LN_LKD_RTOL)
     if not noisy:
         np.testing.assert_allclose(got_varK, c["hp_varK"], rtol=VARK_RTOL)
+
+
+def check_post_grad(dmudx, dsigdx, c):
+    np.testing.assert_allclose(dmudx, c["dmudx"], rtol=DMU_RTOL, atol=DMU_RTOL * max(1e-12, np.abs(c["dmudx"]).max()))
+    np.testing.assert_allclose(dsigdx, c["dsigdx"], rtol=DSIG_RTOL, atol=DSIG_RTOL * max(1e-12, np.abs(c["dsigdx"]).max()))
