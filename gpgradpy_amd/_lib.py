@@ -17,7 +17,7 @@ PROF_NCAT = len(PROF_CATS)
 
 # every symbol include/gpgrad.h declares
 ABI_SYMBOLS = (
-    "gpg_create", "gpg_destroy", "gpg_last_error", "gpg_set_grad_mask", "gpg_set_data", "gpg_lkd", "gpg_lkd_batch",
+    "gpg_create", "gpg_destroy", "gpg_last_error", "gpg_set_grad_mask", "gpg_set_data", "gpg_lkd", "gpg_lkd_grad", "gpg_lkd_batch",
     "gpg_setup_eval", "gpg_predict", "gpg_predict_grad", "gpg_get_matrix", "gpg_prof_enable", "gpg_prof_read", "gpg_set_panel", "gpg_set_lookahead",
     "gpg_device_info",
 )
@@ -64,6 +64,8 @@ def load():
     lib.gpg_set_data.restype = C.c_int
     lib.gpg_lkd.argtypes = [vp, C.POINTER(GpgHp), C.POINTER(GpgLkdOut)]
     lib.gpg_lkd.restype = C.c_int
+    lib.gpg_lkd_grad.argtypes = [vp, C.POINTER(GpgHp), C.POINTER(GpgLkdOut), dp, dp]
+    lib.gpg_lkd_grad.restype = C.c_int
     lib.gpg_lkd_batch.argtypes = [vp, C.c_int, dp, C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(GpgLkdOut)]
     lib.gpg_lkd_batch.restype = C.c_int
     lib.gpg_setup_eval.argtypes = [vp, C.POINTER(GpgHp), C.c_double, dp]

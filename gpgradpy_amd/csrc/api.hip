@@ -175,7 +175,7 @@ void gpg_destroy(gpg_ctx* c) {
   for (auto& pe : c->prof_pending) { (void)hipEventDestroy(pe.e0); (void)hipEventDestroy(pe.e1); }
   for (auto& ev : c->prof_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   double* bufs[] = {c->A, c->Xt, c->y, c->noise, c->dvec, c->invp, c->zvec, c->tmpv, c->dinv, c->scal, c->Wt, c->xq_dev,
-                    c->musig, c->gradbuf, c->dense_tmp};
+                    c->musig, c->gradbuf, c->dense_tmp, c->Wfull, c->Minv, c->gpartial};
   for (double* b : bufs) if (b) (void)hipFree(b);
   if (c->info) (void)hipFree(c->info);
   if (c->gpos) (void)hipFree(c->gpos);
@@ -207,6 +207,7 @@ int gpg_set_grad_mask(gpg_ctx* c, const unsigned char* use_grad_pt) {
   c->have_data = false;
   c->factor_valid = c->eval_ready = false;
   if (c->dense_tmp) { (void)hipFree(c->dense_tmp); c->dense_tmp = nullptr; }
+  if (c->Wfull) { (void)hipFree(c->Wfull); (void)hipFree(c->Minv); c->Wfull = c->Minv = nullptr; }
   if (c->Wt) { (void)hipFree(c->Wt); (void)hipFree(c->xq_dev); (void)hipFree(c->musig); (void)hipFree(c->gradbuf); c->Wt = c->xq_dev = c->musig = c->gradbuf = nullptr; c->xq_cap = 0; }
   return 0;
 }
@@ -243,6 +244,44 @@ int gpg_lkd(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out) {
   c->eval_ready = false;
   finish_lkd(c, hp, c->h_scal, c->h_info[0], out);
   return out->info;
+}
+
+int gpg_lkd_grad(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out, double* g_aa, double* g_inv) {
+  int rc = check_hp(c, hp);
+  if (rc) return rc;
+  if (!out || !g_aa || !g_inv) { c->err = "out / g_aa / g_inv is NULL"; return -1; }
+  GPG_HIP_OK(c, hipSetDevice(c->device));
+  const size_t nn = (size_t)c->Npad * c->Npad;
+  if (!c->Wfull) {
+    GPG_HIP_OK(c, hipMalloc(&c->Wfull, sizeof(double) * nn));
+    GPG_HIP_OK(c, hipMalloc(&c->Minv, sizeof(double) * nn));
+  }
+  const int nblk = gpg_grad_partial_blocks(c);
+  const int nval = 2 * (GPG_MAX_DIM + 3);
+  if (!c->gpartial) GPG_HIP_OK(c, hipMalloc(&c->gpartial, sizeof(double) * (size_t)nval * (nblk + 1)));
+  GPG_HIP_OK(c, hipMemsetAsync(c->info, 0, sizeof(int), c->stream));
+  enqueue_lkd(c, hp, 0);                                   // factor + beta + r'K^-1 r + ln det (scal slot 0)
+  GPG_HIP_OK(c, hipMemcpyAsync(c->h_scal, c->scal, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
+  GPG_HIP_OK(c, hipMemcpyAsync(c->h_info, c->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
+  GPG_HIP_OK(c, hipGetLastError());
+  c->eval_ready = false;
+  c->factor_valid = (c->h_info[0] == 0);
+  finish_lkd(c, hp, c->h_scal, c->h_info[0], out);
+  if (out->info != 0) return out->info;
+  // alpha = Kcov^-1 (y - V beta):  z = L^-T (w2 - beta w1) = p * alpha
+  AsmParams p = make_params(c, hp, 0);
+  gpg_launch_combine_rows(c, 0);
+  gpg_backward_solve(c);
+  gpg_inverse_from_factor(c, c->Wfull, c->Minv);
+  double* res = c->gpartial + (size_t)nval * nblk;
+  gpg_launch_grad_contract(c, p, c->gpartial, res);
+  std::vector<double> h(nval);
+  GPG_HIP_OK(c, hipMemcpyAsync(h.data(), res, sizeof(double) * 2 * (c->d + 3), hipMemcpyDeviceToHost, c->stream));
+  GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
+  GPG_HIP_OK(c, hipGetLastError());
+  for (int k = 0; k < c->d + 3; ++k) { g_aa[k] = h[k]; g_inv[k] = h[c->d + 3 + k]; }
+  return 0;
 }
 
 int gpg_lkd_batch(gpg_ctx* c, int m, const double* hp_rows, int row_len, double eta, int wellcond,

@@ -610,3 +610,32 @@ void gpg_forward_rows(gpg_ctx* c, double* W, int ldw, int rows) {
                             ld, rows, Npad - k1, nbw, 0);
   }
 }
+
+// Minv <- -(L L^T)^-1 (lower triangle) from the factor in c->A:
+//   (1) W = I L^-T by a forward sweep over the "RHS rows" layout.  W is upper triangular (W[r, c] = 0 for c < r),
+//       so panel [k0, k1) only touches rows [0, k1): about N^3/3 flop, the cost of the factorisation.
+//   (2) Minv[0:k1, 0:k1] -= W[0:k1, k0:k1] W[0:k1, k0:k1]^T panel by panel with the trailing-update kernel
+//       (lower tiles only): another N^3/3.
+// Replaces adj_ln_detK = cho_solve(chofac, eye(N)) of the reference (CalcLkd.py:174,234).
+void gpg_inverse_from_factor(gpg_ctx* c, double* W, double* Minv) {
+  const int ld = c->ld, Npad = c->Npad, NB = c->nb_outer, ldw = c->Npad;
+  const double* A = c->A;
+  gpg_launch_identity(c, W, ldw);
+  (void)hipMemsetAsync(Minv, 0, sizeof(double) * (size_t)ldw * Npad, c->stream);
+  for (int k0 = 0; k0 < Npad; k0 += NB) {
+    const int k1 = (k0 + NB < Npad) ? k0 + NB : Npad;
+    for (int j0 = k0; j0 < k1; j0 += GPG_NBI) {
+      const int j1 = j0 + GPG_NBI;
+      hipLaunchKernelGGL(trsm64_kernel, dim3(j1 / 64), dim3(256), 0, c->stream, A + (size_t)j0 + (size_t)j0 * ld, ld,
+                         c->dinv + j0, W + (size_t)j0 * ldw, ldw, j1);
+      const int ncols = k1 - j1;
+      if (ncols > 0)
+        launch_gemm<128, 64>(c, W + (size_t)j1 * ldw, ldw, W + (size_t)j0 * ldw, ldw, A + (size_t)j1 + (size_t)j0 * ld, ld,
+                             j1, ncols, GPG_NBI, 0);
+    }
+    if (k1 < Npad)
+      launch_gemm<128, 128>(c, W + (size_t)k1 * ldw, ldw, W + (size_t)k0 * ldw, ldw, A + (size_t)k1 + (size_t)k0 * ld, ld,
+                            k1, Npad - k1, k1 - k0, 0);
+    launch_gemm_trailing(c, Minv, ldw, W + (size_t)k0 * ldw, ldw, W + (size_t)k0 * ldw, ldw, k1, k1, k1 - k0, 0);
+  }
+}

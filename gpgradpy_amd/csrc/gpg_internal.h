@@ -60,6 +60,9 @@ struct gpg_ctx {
   double* gradbuf = nullptr; // [2 x nxp x d] posterior-gradient reductions + [nxp x 64] backward-solve scratch
   int xq_cap = 0;
   double* dense_tmp = nullptr;  // [N x N] materialisation buffer (on request)
+  double* Wfull = nullptr;      // [Npad x Npad] L^-T (likelihood gradient, on first use)
+  double* Minv = nullptr;       // [Npad x Npad] -(L L^T)^-1, lower triangle
+  double* gpartial = nullptr;   // per-workgroup partial sums of the gradient contraction + 2 (d+3) results
   // pinned host staging
   double* h_scal = nullptr;
   int* h_info = nullptr;
@@ -95,6 +98,11 @@ void gpg_launch_alpha(gpg_ctx* c, double* alpha_dev);                    // alph
 void gpg_launch_predict_reduce(gpg_ctx* c, int nx, int nxp, double beta, double varK, int phase);
 void gpg_backward_rows(gpg_ctx* c, double* Z, int ldz, int nrhs, double* tbuf);  // Z <- Z L^-1 (multi-RHS)
 void gpg_launch_cross_grad(gpg_ctx* c, const AsmParams& p, int nx, int nxp, double* g1, double* g2);
+void gpg_launch_combine_rows(gpg_ctx* c, int slot);                       // RHS row 0 <- L^-1 P^-1 (y - V beta)
+void gpg_launch_identity(gpg_ctx* c, double* W, int ldw);
+void gpg_inverse_from_factor(gpg_ctx* c, double* W, double* Minv);       // Minv <- -(L L^T)^-1 (lower)
+void gpg_launch_grad_contract(gpg_ctx* c, const AsmParams& p, double* partial, double* out_dev);
+int gpg_grad_partial_blocks(const gpg_ctx* c);
 void gpg_launch_extract(gpg_ctx* c, int which);                          // dense_tmp <- sym / P L
 
 // profiling helpers

@@ -427,8 +427,11 @@ class GaussianProcess:
     # ---- likelihood ------------------------------------------------------------------------------------
     def calc_lkd_all(self, hp_vals, calc_lkd=True, calc_cond=False, calc_grad=False, lkd_use_adj_mtd=None):
         """One marginal-log-likelihood evaluation -- reference CalcLkd.py:270-346 (value path)."""
-        if calc_grad:
-            raise NotImplementedError('calc_grad=True (likelihood gradient) is not on the accelerated path yet (SURVEY.md 8f1)')
+        if calc_grad and self.bvec_use_grad is not None and not np.all(self.bvec_use_grad):
+            # the reference itself fails here (shape bug KernelSqExp.py:552-554, SURVEY.md section 4): nothing to pin against
+            raise NotImplementedError('likelihood gradient with a bvec_use_grad mask is not supported')
+        if calc_grad and not (lkd_use_adj_mtd is None or lkd_use_adj_mtd) and not self.lkd_use_adj_mtd:
+            raise NotImplementedError('only the adjoint gradient method is on the accelerated path')
         if calc_cond:
             raise NotImplementedError('calc_cond=True is outside the accelerated path (SURVEY.md 8f4)')
         noisy = self.b_has_noisy_data
@@ -441,7 +444,11 @@ class GaussianProcess:
         hp, keep = self._make_hp(hp_vals, varK_mat, closed_form=not noisy)
         out = _lib.GpgLkdOut()
         t0 = time.time()
-        rc = self._lib.gpg_lkd(self._ctx, C.byref(hp), C.byref(out))
+        if calc_grad:
+            g_aa, g_inv = np.zeros(self.dim + 3), np.zeros(self.dim + 3)
+            rc = self._lib.gpg_lkd_grad(self._ctx, C.byref(hp), C.byref(out), _lib.as_dp(g_aa), _lib.as_dp(g_inv))
+        else:
+            rc = self._lib.gpg_lkd(self._ctx, C.byref(hp), C.byref(out))
         self._time_chofac += time.time() - t0
         self._eval_ready = False
         if rc < 0:
@@ -452,9 +459,26 @@ class GaussianProcess:
         ln_lkd = out.ln_lkd
         if not noisy:
             ln_lkd -= self.calc_lkd_varK_pnlt(out.varK, self._fval_in)[0]        # CalcLkd.py:162,168
+        ln_lkd_grad = None
+        if calc_grad and calc_lkd:
+            # adjoint weights: CalcLkd.py:173-177 (noise-free), :233-235 (noisy)
+            if noisy:
+                s_aa = 0.5
+            else:
+                s_aa = self.calc_lkd_varK_pnlt(out.varK, self._fval_in)[1] / self.n_data + 1.0 / (2.0 * out.varK)
+            g_all = s_aa * g_aa + g_inv
+            hi, d = self.hp_info_optz_lkd, self.dim
+            ln_lkd_grad = np.zeros(hi.n_hp)
+            ln_lkd_grad[hi.idx_theta] = g_all[:d]
+            if hi.has_varK:
+                ln_lkd_grad[hi.idx_varK] = g_all[d]
+            if hi.has_var_fval:
+                ln_lkd_grad[hi.idx_var_fval] = g_all[d + 1]
+            if hi.has_var_fgrad:
+                ln_lkd_grad[hi.idx_var_fgrad] = g_all[d + 2]
         info = LkdInfo(hp_beta=np.array([out.beta]), hp_varK=None if noisy else out.varK,
                        ln_det_Kmat=out.ln_det if calc_lkd or not noisy else None,
-                       ln_lkd=ln_lkd if calc_lkd else None,
+                       ln_lkd=ln_lkd if calc_lkd else None, ln_lkd_grad=ln_lkd_grad,
                        data_vec=self._data_vec if noisy else None, cond=None)
         return info, True
 

@@ -86,6 +86,15 @@ int gpg_set_data(gpg_ctx* ctx, const double* x, const double* data_vec, const do
  * (CalcLkd.py:149-181 / 185-251).  Returns out->info as well. */
 int gpg_lkd(gpg_ctx* ctx, const gpg_hp* hp, gpg_lkd_out* out);
 
+/* Replaces CalcLkd.calc_lkd_all(hp, calc_grad=True) with the adjoint method (CalcLkd.py:170-177, 230-235;
+ * kernel derivatives GpHparaGrad.py:13-155, KernelSqExp.py:470-568, KernelMatern5f2.py:532-642).
+ * out as gpg_lkd.  For hyperparameter slot k in [0, dim+3) = theta_0..theta_(dim-1), varK, var_fval, var_fgrad:
+ *   g_aa[k]  = sum_{r,c} G_k[r,c] alpha_r alpha_c,    g_inv[k] = sum_{r,c} G_k[r,c] (-1/2 Kcov^-1)[r,c],
+ * G_k = d Kcov / d hp_k, alpha = Kcov^-1 (y - V beta).  The caller forms ln_lkd_grad = s g_aa + g_inv with
+ * s = 1/2 (noisy, CalcLkd.py:233) or pnlt'/N + 1/(2 varK) (noise-free, CalcLkd.py:173-175).  Neither the
+ * [n_hp, N, N] derivative tensor nor a dense identity solve is formed; costs two more N^3/3 sweeps. */
+int gpg_lkd_grad(gpg_ctx* ctx, const gpg_hp* hp, gpg_lkd_out* out, double* g_aa, double* g_inv);
+
 /* Replaces the serial restart loop of GpHparaX0.select_hp_optz_x0 (GpHparaX0.py:33-59) on ONE
  * device: m hyperparameter rows, hp_rows [m, row_len] with row = [theta(d), varK_mat, var_fval,
  * var_fgrad] already decoded from log10 (GpHpara.py:56-103); eta / wellcond / closed_form_varK are

@@ -252,6 +252,59 @@ def calc_lkd(X, y, theta, kernel, use_grad, wellcond, etaK, noise_vec, noisy, va
     return LkdResult(True, beta, varK_opt, ln_det, -(N * np.log(varK_opt) + ln_det) / 2.0, alpha, fac)
 
 
+def _kcov_only(X, theta, kernel, use_grad, wellcond, etaK, n, d, noise_fun, varK):
+    """Regularised covariance as a function of the hyperparameters (no factorisation)."""
+    Kern = kern_grad(X, X, theta, kernel) if use_grad else kern_base(X, X, theta, kernel)
+    Kw = Kern + np.diag(noise_fun() / varK)
+    if wellcond == "precon":
+        return varK * (Kw + etaK * np.diag(np.diag(Kw)))       # = P (Kcor + eta I) P, Kernel.py:227-237
+    return varK * (Kw + etaK * np.eye(Kw.shape[0]))
+
+
+def calc_lkd_grad(X, y, theta, kernel, use_grad, wellcond, etaK, std_f, std_g, noisy, varK=None,
+                  var_fval=None, var_fgrad=None, rel_step=1e-6):
+    """d ln_lkd / d hp by the adjoint formula of the reference (CalcLkd.py:170-177 noise-free, :230-235 noisy)
+    with the derivative tensor d Kcov / d hp_k (GpHparaGrad.py:13-155) replaced by central differences of the
+    covariance matrix itself (rel. step 1e-6: truncation ~1e-12, rounding ~1e-10 relative per entry).
+    Returns the vector ordered [theta(d), varK?, var_fval?, var_fgrad?] like HparaOptzInfo."""
+    n, d = X.shape
+    nv = lambda vf=var_fval, vg=var_fgrad: calc_noise_vec(n, d, use_grad, std_f, std_g, vf, vg)
+    vK = varK if noisy else 1.0
+    r0 = calc_lkd(X, y, theta, kernel, use_grad, wellcond, etaK, nv(), noisy, varK=varK)
+    N = y.size
+    Kinv = cho_solve(r0.factor.chofac, np.eye(N))
+    al = r0.alpha
+    Lam = (0.5 if noisy else 1.0 / (2.0 * r0.hp_varK)) * np.outer(al, al) - 0.5 * Kinv
+    out = []
+
+    def dcov(f_plus, f_minus, h):
+        return (f_plus - f_minus) / (2.0 * h)
+    for k in range(d):
+        h = rel_step * theta[k]
+        tp, tm = theta.copy(), theta.copy()
+        tp[k] += h
+        tm[k] -= h
+        G = dcov(_kcov_only(X, tp, kernel, use_grad, wellcond, etaK, n, d, nv, vK),
+                 _kcov_only(X, tm, kernel, use_grad, wellcond, etaK, n, d, nv, vK), h)
+        out.append(np.sum(G * Lam))
+    if noisy:
+        h = rel_step * varK
+        G = dcov(_kcov_only(X, theta, kernel, use_grad, wellcond, etaK, n, d, nv, varK + h),
+                 _kcov_only(X, theta, kernel, use_grad, wellcond, etaK, n, d, nv, varK - h), h)
+        out.append(np.sum(G * Lam))
+        if std_f is None:
+            h = rel_step * var_fval
+            G = dcov(_kcov_only(X, theta, kernel, use_grad, wellcond, etaK, n, d, lambda: nv(var_fval + h, var_fgrad), varK),
+                     _kcov_only(X, theta, kernel, use_grad, wellcond, etaK, n, d, lambda: nv(var_fval - h, var_fgrad), varK), h)
+            out.append(np.sum(G * Lam))
+        if use_grad and std_g is None:
+            h = rel_step * var_fgrad
+            G = dcov(_kcov_only(X, theta, kernel, use_grad, wellcond, etaK, n, d, lambda: nv(var_fval, var_fgrad + h), varK),
+                     _kcov_only(X, theta, kernel, use_grad, wellcond, etaK, n, d, lambda: nv(var_fval, var_fgrad - h), varK), h)
+            out.append(np.sum(G * Lam))
+    return np.array(out)
+
+
 # --------------------------------------------------------------------------------------------
 # posterior
 # --------------------------------------------------------------------------------------------

@@ -135,6 +135,9 @@ def make_case(GaussianProcess, name, n, d, kernel, noise, use_grad=True, wellcon
     if not ok:
         return out
 
+    if not mask:
+        lkd_g, ok_g = GP.calc_lkd_all(hp, calc_lkd=True, calc_cond=False, calc_grad=True)
+        out['ln_lkd_grad'] = np.asarray(lkd_g.ln_lkd_grad, dtype=float)
     out.update(hp_beta=np.asarray(lkd.hp_beta, dtype=float),
                hp_varK=np.nan if lkd.hp_varK is None else float(lkd.hp_varK),
                ln_det_Kmat=float(lkd.ln_det_Kmat), ln_lkd=float(lkd.ln_lkd))
@@ -282,6 +285,7 @@ def _micro(GaussianProcess):
     GP.set_data(x, f, np.zeros(2), g, np.zeros((2, 1)))
     hp = GP.make_hp_class(theta=np.array([0.5]))
     lkd, ok = GP.calc_lkd_all(hp)
+    lkd_g = GP.calc_lkd_all(hp, calc_grad=True)[0]
     Kern, Kcor, Kcov, chofac, _, _, _ = GP.calc_Kern_w_chofac(GP.Rtensor_init, hp)
     hp2 = GP.optz_closed_form_hp(hp)
     GP.set_hpara('set', 0, hp_vals=hp2)
@@ -293,7 +297,7 @@ def _micro(GaussianProcess):
                 b_chofac_good=True, xq=xq, n_data=4, bvec_use_grad=np.ones(2, dtype=bool), pnlt=np.array([np.nan, np.nan]), hp_beta=lkd.hp_beta, hp_varK=lkd.hp_varK,
                 ln_det_Kmat=lkd.ln_det_Kmat, ln_lkd=lkd.ln_lkd, noise_vec=np.zeros(4), chofac_lower=True,
                 chofac_diag=np.diag(chofac[0]).copy(), pvec=np.ones(4), Kern=Kern, Kcov=Kcov,
-                chofac=np.tril(chofac[0]), alpha=GP.invKernEta_fdiff, varK_model=hp2.varK, mu=mu, sig=sig, dmudx=dmudx, dsigdx=dsigdx)
+                chofac=np.tril(chofac[0]), alpha=GP.invKernEta_fdiff, varK_model=hp2.varK, mu=mu, sig=sig, dmudx=dmudx, dsigdx=dsigdx, ln_lkd_grad=np.asarray(lkd_g.ln_lkd_grad, dtype=float))
 
 
 if __name__ == '__main__':

@@ -31,6 +31,19 @@ def _gp_from_case(c):
     return GP
 
 
+def _oracle_cond(c):
+    """2-norm condition number of the covariance that is factorised (CPU, small cases only)."""
+    from oracle import gp_oracle as orc
+    vf = None if np.isnan(c["var_fval"]) else c["var_fval"]
+    vg = None if np.isnan(c["var_fgrad"]) else c["var_fgrad"]
+    nv = orc.calc_noise_vec(c["n"], c["d"], c["use_grad"], c["std_f"], c["std_g"] if c["use_grad"] else None, vf, vg,
+                            n_grad=int(c["bvec_use_grad"].sum()))
+    gm = None if c["bvec_use_grad"].all() else c["bvec_use_grad"]
+    fac = orc.calc_all_K_w_chofac(c["x"], c["theta"], c["kernel"], c["use_grad"], c["wellcond"] if c["use_grad"] else "base",
+                                  c["etaK"], nv, varK=c["varK_in"] if c["b_has_noisy_data"] else 1.0, grad_mask=gm)
+    return np.linalg.cond(fac.Kcov)
+
+
 def _hp_from_case(GP, c):
     noisy = c["b_has_noisy_data"]
     vf = None if np.isnan(c["var_fval"]) else c["var_fval"]
@@ -53,6 +66,17 @@ def test_golden_case(path):
         return
     noisy = c["b_has_noisy_data"]
     tol.check_scalars(info.hp_beta[0], info.hp_varK, info.ln_det_Kmat, info.ln_lkd, c, GP.n_data, noisy)
+
+    # adjoint likelihood gradient (reference CalcLkd.py:170-177 / 230-235)
+    if "ln_lkd_grad" in c:
+        info_g, ok_g = GP.calc_lkd_all(hp, calc_grad=True)
+        assert ok_g and np.isclose(info_g.ln_lkd, info.ln_lkd, rtol=1e-12)
+        assert info_g.ln_lkd_grad.shape == c["ln_lkd_grad"].shape
+        cond = np.linalg.cond(c["Kcov"]) if "Kcov" in c else _oracle_cond(c)
+        tol.check_lkd_grad(info_g.ln_lkd_grad, c["ln_lkd_grad"], tol.lkd_grad_slots_to_check(c), cond=cond)
+    else:
+        with pytest.raises(NotImplementedError):
+            GP.calc_lkd_all(hp, calc_grad=True)
 
     # assembled matrices and the factor (reference Kernel.py:213-252)
     if "Kern" in c:

@@ -56,6 +56,16 @@ def test_oracle_matches_reference(path):
     if np.isnan(c["pnlt"][0]):
         np.testing.assert_allclose(r2.ln_lkd, c["ln_lkd"], rtol=tol.LN_LKD_RTOL)
 
+    # adjoint gradient of the likelihood (reference CalcLkd.py:170-177 / 230-235, GpHparaGrad.py:13-155)
+    if "ln_lkd_grad" in c and np.isnan(c["pnlt"][0]) and c["n_data"] <= 200:
+        vf = None if np.isnan(c["var_fval"]) else c["var_fval"]
+        vg = None if np.isnan(c["var_fgrad"]) else c["var_fgrad"]
+        g = orc.calc_lkd_grad(c["x"], y, c["theta"], c["kernel"], c["use_grad"], wc, c["etaK"], c["std_f"],
+                              c["std_g"] if c["use_grad"] else None, noisy, varK=c["varK_in"] if noisy else None,
+                              var_fval=vf, var_fgrad=vg)
+        sl = tol.lkd_grad_slots_to_check(c)
+        tol.check_lkd_grad(g, c["ln_lkd_grad"], sl, cond=max(3e6, np.linalg.cond(r.factor.Kcov)))
+
     # posterior (reference GpEvalModel.py:17-198)
     beta = r.hp_beta
     varK_model = c["varK_in"] if noisy else r.hp_varK
