@@ -185,6 +185,21 @@ def test_against_oracle_multi_panel(kernel, noise, n, d, panel):
     assert ok and r.ok
     ref = dict(hp_beta=r.hp_beta, hp_varK=r.hp_varK, ln_det_Kmat=r.ln_det_Kmat, ln_lkd=r.ln_lkd)
     tol.check_scalars(info.hp_beta[0], info.hp_varK, info.ln_det_Kmat, info.ln_lkd, ref, y.size, noisy)
+    # likelihood gradient vs central finite differences of the device ln_lkd itself (several panels deep);
+    # FD noise: kappa * eps / step, so the check is on the largest components only
+    info_g, ok_g = GP.calc_lkd_all(hp, calc_grad=True)
+    assert ok_g and info_g.ln_lkd_grad.shape == (GP.hp_info_optz_lkd.n_hp,)
+    big = np.argsort(-np.abs(info_g.ln_lkd_grad[:d]))[:2]
+    for k in big:
+        h = 1e-4 * theta[k]
+        tp, tm = theta.copy(), theta.copy()
+        tp[k] += h
+        tm[k] -= h
+        fp = GP.calc_lkd_all(GP.make_hp_class(theta=tp, varK=varK, var_fval=vf, var_fgrad=vg))[0].ln_lkd
+        fm = GP.calc_lkd_all(GP.make_hp_class(theta=tm, varK=varK, var_fval=vf, var_fgrad=vg))[0].ln_lkd
+        fd = (fp - fm) / (2 * h)
+        assert abs(fd - info_g.ln_lkd_grad[k]) <= 2e-3 * abs(fd) + 1e-6 * np.abs(info_g.ln_lkd_grad).max(), (k, fd, info_g.ln_lkd_grad[k])
+
     # posterior
     hp2 = GP.optz_closed_form_hp(hp)
     GP.set_hpara('set', 0, hp_vals=hp2)
