@@ -316,6 +316,9 @@ gemm_dma_kernel(double* __restrict__ C, int ldc, const double* __restrict__ A, i
   const int l15 = lane & 15, l4 = lane >> 4;
   const bool wave_active = (m0 + wm * 64) < M;
 
+#ifdef GPG_STAMP
+  const unsigned long long tl_start = __builtin_amdgcn_s_memrealtime();
+#endif
   d4 acc[4][4] = {};
   double* Cw = C + (size_t)(m0 + wm * 64 + l15) + (size_t)(n0 + wn * 64 + l4) * ldc;
 #ifndef GPG_ABLATE_CLOAD
@@ -407,6 +410,7 @@ gemm_dma_kernel(double* __restrict__ C, int ldc, const double* __restrict__ A, i
     stage = stage + 1 == S ? 0 : stage + 1;
   }
 #ifdef GPG_STAMP
+  const unsigned long long tl_main_end = __builtin_amdgcn_s_memrealtime();
   if (lane == 0 && blockIdx.x < 4096 && g_stamp_buf != nullptr) {
     unsigned long long* o = g_stamp_buf + ((size_t)blockIdx.x * 4 + w) * 4;
     const unsigned long long tc1 = __builtin_amdgcn_s_memtime(), tr1 = __builtin_amdgcn_s_memrealtime();
@@ -425,6 +429,17 @@ gemm_dma_kernel(double* __restrict__ C, int ldc, const double* __restrict__ A, i
 #pragma unroll
         for (int r = 0; r < 4; ++r) Cw[mi * 16 + (size_t)(ni * 16 + 4 * r) * ldc] = acc[ni][mi][r];
   }
+#ifdef GPG_STAMP
+  // timeline record of wave 0 (diagnostic): hw id, start, main-loop start, main-loop end, stores issued
+  if (lane == 0 && w == 0 && blockIdx.x < 4096 && g_stamp_buf != nullptr) {
+    unsigned long long* o = g_stamp_buf + 4096 * 16 + (size_t)blockIdx.x * 8;
+    unsigned hwid, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    o[0] = ((unsigned long long)xcc << 32) | hwid;
+    o[1] = tl_start; o[2] = tr0; o[3] = tl_main_end; o[4] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 template <int BM, int BN>

@@ -5,6 +5,7 @@
 #include <cstdlib>
 void gpg_prof_begin(gpg_ctx*, int, double) {}
 void gpg_prof_end(gpg_ctx*) {}
+void gpg_launch_identity(gpg_ctx*, double*, int) {}
 int main(int argc, char** argv) {
   int Nt = argc > 1 ? atoi(argv[1]) : 16384, K = argc > 2 ? atoi(argv[2]) : 256, impl = argc > 3 ? atoi(argv[3]) : 1;
   gpg_ctx c;
@@ -28,8 +29,8 @@ int main(int argc, char** argv) {
   }
 #ifdef GPG_STAMP
   unsigned long long* dbuf = nullptr;
-  if (hipMalloc(&dbuf, 4096 * 16 * 8) != hipSuccess || dbuf == nullptr) { printf("stamp buffer alloc failed\n"); return 1; }
-  hipMemset(dbuf, 0, 4096 * 16 * 8);
+  if (hipMalloc(&dbuf, 4096 * 24 * 8) != hipSuccess || dbuf == nullptr) { printf("stamp buffer alloc failed\n"); return 1; }
+  hipMemset(dbuf, 0, 4096 * 24 * 8);
   if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &dbuf, sizeof(dbuf)) != hipSuccess) { printf("symbol copy failed\n"); return 1; }
   hipDeviceSynchronize();
 #endif
@@ -51,6 +52,21 @@ int main(int argc, char** argv) {
     hipMemcpy(hb.data(), dbuf, hb.size() * 8, hipMemcpyDeviceToHost);
     double sum[4] = {0, 0, 0, 0}; int nw = 0;
     for (int b = 0; b < 4096; ++b) for (int w = 0; w < 4; ++w) { const unsigned long long* o = &hb[(b * 4 + w) * 4]; if (o[1] == 0) continue; ++nw; for (int q = 0; q < 4; ++q) sum[q] += (double)o[q]; }
+    {
+      // per-CU timeline: do the C phases of co-resident workgroups coincide?
+      std::vector<unsigned long long> tl(4096 * 8);
+      hipMemcpy(tl.data(), dbuf + 4096 * 16, tl.size() * 8, hipMemcpyDeviceToHost);
+      FILE* f = fopen("../gpurun_out/gemm_timeline.csv", "w");
+      if (f) {
+        fprintf(f, "block,xcc,hwid,start,main_start,main_end,end\n");
+        for (int b = 0; b < 4096; ++b) {
+          const unsigned long long* o = &tl[(size_t)b * 8];
+          if (o[1] == 0) continue;
+          fprintf(f, "%d,%llu,%llu,%llu,%llu,%llu,%llu\n", b, o[0] >> 32, o[0] & 0xffffffffULL, o[1], o[2], o[3], o[4]);
+        }
+        fclose(f);
+      }
+    }
     printf("stamps over %d waves: issue %.0f + compute %.0f cycles per chunk; main loop %.0f cycles = %.2f us per tile -> held clock %.3f GHz\n", nw,
            sum[0] / nw / (K / 8), sum[1] / nw / (K / 8), sum[2] / nw, sum[3] / nw * 0.01, (sum[2] / nw) / (sum[3] / nw * 10.0));
   }
