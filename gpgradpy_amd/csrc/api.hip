@@ -1,6 +1,7 @@
 // C ABI of libgpgrad_hip.so (see include/gpgrad.h for the contract and the reference citations).
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include "gpg_internal.h"
@@ -127,6 +128,8 @@ int gpg_create(gpg_ctx** out, int device, int n_eval, int dim, int use_grad, int
   c->R = GPG_RHS_ROWS;
   c->ld = c->Npad + c->R;
   c->nb_outer = c->Npad >= 8192 ? 512 : 256;   // wider panels amortise the C-tile traffic of the trailing update (measured)
+  if (const char* e = getenv("GPG_NB_BIG")) c->nb_big = atoi(e);       // tuning knobs for measurements
+  if (const char* e = getenv("GPG_BIG_ROWS")) c->big_rows = atoi(e);
 #define CREATE_OK(call)                                                              \
   do {                                                                               \
     hipError_t e_ = (call);                                                          \
@@ -470,6 +473,7 @@ int gpg_set_lookahead(gpg_ctx* c, int on) {
   if (!c) return -1;
   c->lookahead = (on & 1) ? 1 : 0;
   c->gemm_impl = (on & 2) ? 0 : 1;   // bit 1: fall back to the register-staged 128x128 kernel (A/B runs)
+  c->panel_impl = (on & 4) ? 0 : 1;  // bit 2: fall back to per-64-column trsm + gemm launches for B_p (A/B runs)
   return 0;
 }
 

@@ -141,6 +141,202 @@ __global__ void __launch_bounds__(256) trsm64_kernel(const double* __restrict__ 
   }
 }
 
+#ifdef GPG_STAMP   // diagnostic build of tools/gemm_probe.hip only: per-wave cycle shares of the loop phases
+__device__ unsigned long long* g_stamp_buf;
+#define GPG_T(var) unsigned long long var; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0);
+#else
+#define GPG_T(var)
+#endif
+
+// ------------------------------------------------------------------------------------------------
+// panel_solve_kernel: X <- X L^-T for `rows` rows against a factorised nb x nb diagonal block
+// (nb a multiple of 64) in ONE launch.  A workgroup owns 64 rows; wave w owns rows 16w .. 16w+15.
+// Left-looking over the 64-column blocks j of the panel:
+//   (1) T_j = X_j - sum_{k<j} X_k L_jk^T   on MFMA (wave tile 16 x 64, K = 64 j; X_k is the workgroup's own
+//       earlier output re-read through L1/L2, L_jk comes from L2; both staged through LDS, 16-deep chunks)
+//   (2) X_j = T_j L_jj^-T by the quad-row substitution of trsm64_kernel (the accumulators are transposed
+//       through a wave-private LDS tile into the 4-lanes-per-row layout)
+// Replaces nb/64 trsm64 + nb/64 - 1 small-K gemm launches, whose ~15 us dependent-launch latency each
+// (not their flops) set the cost of B_p.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2)
+panel_solve_kernel(const double* __restrict__ L, int ldl, const double* __restrict__ dinv, double* X, int ldx,
+                   int rows, int nb) {
+  constexpr int KB = 16, SA = 80;                     // SA: +128 B pad keeps ds_read_b64 conflict-free
+  constexpr int BUF = KB * SA;                        // doubles per staging buffer
+  __shared__ __attribute__((aligned(16))) double U[4 * BUF];   // sA[2] | sB[2]; re-used as the transposition tile Ts[64][SA]
+  __shared__ __attribute__((aligned(16))) double Ls[64][4][18];
+  __shared__ double sdinv[64];
+  double* const sA = U;
+  double* const sB = U + 2 * BUF;
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int m0 = blockIdx.x * 64;
+  // MFMA-side row of this lane, substitution-side row of this lane (both inside the wave's 16 rows)
+  int rowc = m0 + 16 * w + l15;
+  const bool c_ok = rowc < rows;
+  rowc = c_ok ? rowc : rows - 1;
+  const int q = tid & 3;
+  int rowt = m0 + (tid >> 2);
+  const bool t_ok = rowt < rows;
+  rowt = t_ok ? rowt : rows - 1;
+
+  // staging: thread -> (row pair p, k) ; two double2 per operand per chunk
+  const int sp = tid & 31, sk = tid >> 5;             // sk in 0..7, second load at sk + 8
+  int rowa = m0 + 2 * sp;
+  rowa = rowa + 1 < rows ? rowa : (rows >= 2 ? rows - 2 : 0);
+
+  double cx[16], li[16];   // next block's X tile (MFMA layout) and L_jj (linear), prefetched
+#define GPG_PS_PREFETCH(jb)                                                                   \
+  {                                                                                          \
+    const double* Cw = X + rowc + (size_t)(64 * (jb) + l4) * ldx;                             \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) cx[i] = Cw[(size_t)((i >> 2) * 16 + 4 * (i & 3)) * ldx]; \
+    const double* Ljj = L + (size_t)(64 * (jb)) + (size_t)(64 * (jb)) * ldl;                   \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                          \
+      const int t = tid + 256 * i;                                                           \
+      li[i] = Ljj[(t & 63) + (size_t)(t >> 6) * ldl];                                         \
+    }                                                                                        \
+  }
+  GPG_PS_PREFETCH(0)
+#ifdef GPG_STAMP
+  unsigned long long ps_pre = 0, ps_gemm = 0, ps_tr = 0, ps_sub = 0, ps_st = 0;
+#endif
+  for (int j = 0; j < nb / 64; ++j) {
+    GPG_T(p0)
+    // ---- accumulators start as X_j; LDS image of L_jj for the substitution (nobody reads Ls during the MFMA
+    //      phase).  Both were fetched into registers one block ahead, behind the previous substitution. ----------
+    d4 acc[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[ni][r] = cx[4 * ni + r];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int t = tid + 256 * i, jj = t >> 6, k = t & 63;
+      Ls[jj][k & 3][k >> 2] = li[i];
+    }
+    if (tid < 64) sdinv[tid] = dinv[64 * j + tid];
+    // ---- (1) MFMA phase -----------------------------------------------------------------------------------
+    const int nchunk = 4 * j;                          // K = 64 j in chunks of 16
+    GPG_T(p1)
+    if (nchunk > 0) {
+      const double* ga = X + rowa + (size_t)sk * ldx;
+      const double* gb = L + (size_t)(64 * j + 2 * sp) + (size_t)sk * ldl;
+      const size_t a8 = (size_t)8 * ldx, b8 = (size_t)8 * ldl;
+      // register prefetch two chunks ahead (one wave per SIMD: nothing else hides the L2 latency)
+      double2 ra0_a, ra0_b, rb0_a, rb0_b, ra1_a, ra1_b, rb1_a, rb1_b;
+#define GPG_PS_GLOAD(set)                                        \
+  ra##set##_a = *reinterpret_cast<const double2*>(ga);            \
+  ra##set##_b = *reinterpret_cast<const double2*>(ga + a8);       \
+  rb##set##_a = *reinterpret_cast<const double2*>(gb);            \
+  rb##set##_b = *reinterpret_cast<const double2*>(gb + b8);       \
+  ga += 2 * a8;                                                  \
+  gb += 2 * b8;
+#define GPG_PS_SSTORE(buf, set)                                                              \
+  {                                                                                          \
+    double2 v0, v1;                                                                          \
+    v0.x = -ra##set##_a.x; v0.y = -ra##set##_a.y; v1.x = -ra##set##_b.x; v1.y = -ra##set##_b.y;  \
+    *reinterpret_cast<double2*>(sA + (buf) * BUF + sk * SA + 2 * sp) = v0;                    \
+    *reinterpret_cast<double2*>(sA + (buf) * BUF + (sk + 8) * SA + 2 * sp) = v1;              \
+    *reinterpret_cast<double2*>(sB + (buf) * BUF + sk * SA + 2 * sp) = rb##set##_a;            \
+    *reinterpret_cast<double2*>(sB + (buf) * BUF + (sk + 8) * SA + 2 * sp) = rb##set##_b;      \
+  }
+#define GPG_PS_COMPUTE(buf)                                                                  \
+  _Pragma("unroll") for (int kk = 0; kk < KB; kk += 4) {                                      \
+    const double fm = sA[(buf) * BUF + (kk + l4) * SA + 16 * w + l15];                        \
+    double fn[4];                                                                            \
+    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) fn[ni] = sB[(buf) * BUF + (kk + l4) * SA + ni * 16 + l15]; \
+    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                          \
+      acc[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(fn[ni], fm, acc[ni], 0, 0, 0);           \
+  }
+      // nchunk is a multiple of 4: the loop is unrolled by two so that the register sets are static
+      GPG_PS_GLOAD(0);            // chunk 0
+      GPG_PS_GLOAD(1);            // chunk 1
+      GPG_PS_SSTORE(0, 0);
+      __syncthreads();
+      for (int ch = 0; ch < nchunk; ch += 2) {
+        if (ch + 2 < nchunk) { GPG_PS_GLOAD(0); }      // chunk ch + 2
+        GPG_PS_COMPUTE(0);                             // chunk ch
+        GPG_PS_SSTORE(1, 1);                           // chunk ch + 1
+        __syncthreads();
+        if (ch + 3 < nchunk) { GPG_PS_GLOAD(1); }      // chunk ch + 3
+        GPG_PS_COMPUTE(1);                             // chunk ch + 1
+        if (ch + 2 < nchunk) { GPG_PS_SSTORE(0, 0); }  // chunk ch + 2
+        __syncthreads();
+      }
+#undef GPG_PS_GLOAD
+#undef GPG_PS_SSTORE
+#undef GPG_PS_COMPUTE
+    }
+    __syncthreads();   // staging buffers free (they become Ts), L_jj image complete
+    GPG_T(p2)
+    // ---- (2) substitution phase: accumulators -> Ts[col][row] -> 4 lanes per row ---------------------------
+    {
+      double* Ts = U;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ts[(ni * 16 + 4 * r + l4) * SA + 16 * w + l15] = acc[ni][r];
+    }
+    __syncthreads();
+    double x[16];
+    {
+      const double* Tr = U + q * SA + (tid >> 2);
+#pragma unroll
+      for (int m = 0; m < 16; ++m) x[m] = Tr[(4 * m) * SA];
+    }
+    if (j + 1 < nb / 64) GPG_PS_PREFETCH(j + 1)
+    GPG_T(p3)
+    double lv[2][16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) lv[0][m] = Ls[0][q][m];
+#define GPG_TRSM_STEP(QJ)                                                                   \
+  {                                                                                         \
+    constexpr int cur = QJ & 1, nxt = cur ^ 1;                                               \
+    const int jc = 4 * mj + QJ;                                                             \
+    const int jn = jc + 1 < 64 ? jc + 1 : 63;                                               \
+    const int m0n = (jc + 1) >> 2;                                                          \
+    _Pragma("unroll") for (int m = 0; m < 16; ++m) if (m >= m0n) lv[nxt][m] = Ls[jn][q][m]; \
+    const double xs = x[mj] * sdinv[jc];                                                    \
+    x[mj] = (q == QJ) ? xs : x[mj];                                                         \
+    const double xj = quad_bcast<QJ>(x[mj]);                                                \
+    if (QJ < 3) {                                                                           \
+      const double t = x[mj] - xj * lv[cur][mj];                                            \
+      x[mj] = (q > QJ) ? t : x[mj];                                                         \
+    }                                                                                       \
+    _Pragma("unroll") for (int m = mj + 1; m < 16; ++m) x[m] -= xj * lv[cur][m];            \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+  }
+#pragma unroll
+    for (int mj = 0; mj < 16; ++mj) {
+      GPG_TRSM_STEP(0)
+      GPG_TRSM_STEP(1)
+      GPG_TRSM_STEP(2)
+      GPG_TRSM_STEP(3)
+    }
+#undef GPG_TRSM_STEP
+    GPG_T(p4)
+    if (t_ok) {
+      double* Xr = X + rowt + (size_t)(64 * j + q) * ldx;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) Xr[(size_t)(4 * m) * ldx] = x[m];
+    }
+    __syncthreads();   // X_j visible to the whole workgroup (vmcnt(0) + barrier), Ts / Ls free again
+    GPG_T(p5)
+#ifdef GPG_STAMP
+    ps_pre += p1 - p0; ps_gemm += p2 - p1; ps_tr += p3 - p2; ps_sub += p4 - p3; ps_st += p5 - p4;
+#endif
+  }
+#undef GPG_PS_PREFETCH
+#ifdef GPG_STAMP
+  if (lane == 0 && blockIdx.x < 4096 && g_stamp_buf != nullptr) {
+    unsigned long long* o = g_stamp_buf + ((size_t)blockIdx.x * 4 + w) * 8;
+    o[0] = ps_pre; o[1] = ps_gemm; o[2] = ps_tr; o[3] = ps_sub; o[4] = ps_st;
+  }
+#endif
+}
+
 // ------------------------------------------------------------------------------------------------
 // gemm_nt_minus<BM, BN>:  C[M x Nc] -= A[M x K] * B[Nc x K]^T   (all column-major)
 //   M multiple of 64, Nc multiple of BN, K multiple of 8.  lower != 0: C's origin lies on the matrix
@@ -280,12 +476,6 @@ gemm_nt_minus_kernel(double* __restrict__ C, int ldc, const double* __restrict__
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
-#ifdef GPG_STAMP   // diagnostic build of tools/gemm_probe.hip only: per-wave cycle shares of the loop phases
-__device__ unsigned long long* g_stamp_buf;
-#define GPG_T(var) unsigned long long var; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0);
-#else
-#define GPG_T(var)
-#endif
 
 template <int S>
 __global__ void __launch_bounds__(256, 2)
@@ -530,11 +720,24 @@ static void factor_diag_block(gpg_ctx* c, int k0, int k1) {
   }
 }
 
+static void launch_panel_solve(gpg_ctx* c, const double* Lpp, int ldl, const double* dinv, double* X, int ldx, int rows,
+                               int nb) {
+  if (rows <= 0 || nb <= 0) return;
+  hipLaunchKernelGGL(panel_solve_kernel, dim3((rows + 63) / 64), dim3(256), 0, c->stream, Lpp, ldl, dinv, X, ldx, rows, nb);
+}
+
 static void solve_below_block(gpg_ctx* c, int k0, int k1) {
   const int ld = c->ld;
   double* A = c->A;
   const int rows = ld - k1;
   if (rows <= 0) return;
+  if (c->panel_impl == 1) {   // one fused launch per panel
+    gpg_prof_begin(c, GPG_PROF_TRSM, (double)rows * (double)(k1 - k0) * (double)(k1 - k0));
+    launch_panel_solve(c, A + (size_t)k0 + (size_t)k0 * ld, ld, c->dinv + k0, A + (size_t)k1 + (size_t)k0 * ld, ld, rows,
+                       k1 - k0);
+    gpg_prof_end(c);
+    return;
+  }
   for (int j0 = k0; j0 < k1; j0 += GPG_NBI) {
     const int j1 = j0 + GPG_NBI;
     gpg_prof_begin(c, GPG_PROF_TRSM, (double)rows * 64.0 * 64.0);
@@ -552,11 +755,20 @@ static void solve_below_block(gpg_ctx* c, int k0, int k1) {
 }
 
 void gpg_cholesky(gpg_ctx* c) {
-  const int ld = c->ld, Npad = c->Npad, NB = c->nb_outer;
+  const int ld = c->ld, Npad = c->Npad;
   double* A = c->A;
   hipStream_t sM = c->stream, sD = c->lookahead ? c->stream_upd : c->stream;
   const bool two = (sD != sM);
-  const int npanel = (Npad + NB - 1) / NB;
+  // panel boundaries: wide panels (nb_big) while at least big_rows columns remain -- the trailing update then
+  // streams the C tiles half as often -- and nb_outer afterwards, where the serial diagonal chain matters more
+  std::vector<int> kb;
+  for (int k = 0; k < Npad;) {
+    kb.push_back(k);
+    const int nbw = (c->nb_big > c->nb_outer && Npad - k >= c->big_rows) ? c->nb_big : c->nb_outer;
+    k = (k + nbw < Npad) ? k + nbw : Npad;
+  }
+  kb.push_back(Npad);
+  const int npanel = (int)kb.size() - 1;
   while ((int)c->ev_panel.size() < npanel + 1) {
     hipEvent_t e1, e2;
     (void)hipEventCreateWithFlags(&e1, hipEventDisableTiming);
@@ -566,14 +778,14 @@ void gpg_cholesky(gpg_ctx* c) {
   }
   // D_0 follows the assembly on the main stream
   c->stream = sM;
-  factor_diag_block(c, 0, NB < Npad ? NB : Npad);
-  for (int k0 = 0, p = 0; k0 < Npad; k0 += NB, ++p) {
-    const int k1 = (k0 + NB < Npad) ? k0 + NB : Npad;               // panel p = columns [k0, k1)
+  factor_diag_block(c, 0, kb[1]);
+  for (int p = 0; p < npanel; ++p) {
+    const int k0 = kb[p], k1 = kb[p + 1];                           // panel p = columns [k0, k1)
     c->stream = sM;
     if (two && p > 0) (void)hipStreamWaitEvent(sM, c->ev_panel[p], 0);
     solve_below_block(c, k0, k1);                                   // B_p (also carries the RHS rows)
     if (k1 >= Npad) break;
-    const int k2 = (k1 + NB < Npad) ? k1 + NB : Npad;               // next diagonal block = [k1, k2)
+    const int k2 = kb[p + 2];                                       // next diagonal block = [k1, k2)
     const int K = k1 - k0;
     const double* Ap = A + (size_t)k0 * ld;
     const double w = (double)(k2 - k1), nt = (double)(Npad - k1);

@@ -40,7 +40,10 @@ struct gpg_ctx {
   int ng = 0;                // gradient points in use (KernelSqExp.py:349-377: bvec_use_grad)
   int* gpos = nullptr;       // device [n]
   size_t A_elems = 0;        // allocated size of A (doubles), sized for all gradients
+  int panel_impl = 1;                // 1: fused panel_solve_kernel for B_p, 0: trsm64 + small gemm launches (A/B runs)
   int nb_outer = 256;   // panel width
+  int nb_big = 0;       // wide-panel width used while at least big_rows columns remain (0: off)
+  int big_rows = 0;
   // device buffers
   double* A = nullptr;       // [ld x Npad] column-major; lower triangle + RHS rows
   double* Xt = nullptr;      // [d x n]   (coordinate-major copy of x for coalesced loads)
