@@ -128,6 +128,12 @@ int gpg_create(gpg_ctx** out, int device, int n_eval, int dim, int use_grad, int
   c->R = GPG_RHS_ROWS;
   c->ld = c->Npad + c->R;
   c->nb_outer = c->Npad >= 8192 ? 512 : 256;   // wider panels amortise the C-tile traffic of the trailing update (measured)
+  // factorisation schedule (measured, profiles/r01_tile_probe.log): one dataflow launch, 64-tile kernel for small
+  // matrices (shorter dependency chain), 128-tile kernel above; chol_impl 0 = blocked right-looking (A/B runs)
+  c->chol_impl = 1;
+  c->tail_cols = 6144;
+  if (const char* e = getenv("GPG_CHOL_IMPL")) c->chol_impl = atoi(e);
+  if (const char* e = getenv("GPG_TAIL_COLS")) c->tail_cols = atoi(e);
   if (const char* e = getenv("GPG_NB_BIG")) c->nb_big = atoi(e);       // tuning knobs for measurements
   if (const char* e = getenv("GPG_BIG_ROWS")) c->big_rows = atoi(e);
 #define CREATE_OK(call)                                                              \
@@ -232,6 +238,18 @@ int gpg_set_data(gpg_ctx* c, const double* x, const double* data_vec, const doub
   return 0;
 }
 
+// A dependency wait of the dataflow factorisation timed out (never expected: it would mean a lost flag or a
+// dispatch-order assumption broken).  The kernel drains and marks info with GPG_INFO_INTERNAL.
+static int internal_failure(gpg_ctx* c, const int* infos, int m) {
+  for (int i = 0; i < m; ++i)
+    if (infos[i] == GPG_INFO_INTERNAL) {
+      c->err = "dataflow Cholesky: dependency wait timed out (internal error)";
+      c->factor_valid = c->eval_ready = false;
+      return -4;
+    }
+  return 0;
+}
+
 int gpg_lkd(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out) {
   int rc = check_hp(c, hp);
   if (rc) return rc;
@@ -243,6 +261,7 @@ int gpg_lkd(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out) {
   GPG_HIP_OK(c, hipMemcpyAsync(c->h_info, c->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
   GPG_HIP_OK(c, hipGetLastError());
+  if (internal_failure(c, c->h_info, 1)) return -4;
   c->factor_valid = (c->h_info[0] == 0);
   c->eval_ready = false;
   finish_lkd(c, hp, c->h_scal, c->h_info[0], out);
@@ -268,6 +287,7 @@ int gpg_lkd_grad(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out, double* g_aa, d
   GPG_HIP_OK(c, hipMemcpyAsync(c->h_info, c->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
   GPG_HIP_OK(c, hipGetLastError());
+  if (internal_failure(c, c->h_info, 1)) return -4;
   c->eval_ready = false;
   c->factor_valid = (c->h_info[0] == 0);
   finish_lkd(c, hp, c->h_scal, c->h_info[0], out);
@@ -313,6 +333,7 @@ int gpg_lkd_batch(gpg_ctx* c, int m, const double* hp_rows, int row_len, double 
   GPG_HIP_OK(c, hipMemcpyAsync(c->h_info, c->info, sizeof(int) * m, hipMemcpyDeviceToHost, c->stream));
   GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
   GPG_HIP_OK(c, hipGetLastError());
+  if (internal_failure(c, c->h_info, m)) return -4;
   for (int i = 0; i < m; ++i) finish_lkd(c, &hps[i], c->h_scal + (size_t)8 * i, c->h_info[i], &out[i]);
   c->factor_valid = c->eval_ready = false;
   return 0;
@@ -332,6 +353,7 @@ int gpg_setup_eval(gpg_ctx* c, const gpg_hp* hp, double beta, double* alpha_out)
   GPG_HIP_OK(c, hipMemcpyAsync(c->h_info, c->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
   GPG_HIP_OK(c, hipGetLastError());
+  if (internal_failure(c, c->h_info, 1)) return -4;
   if (c->h_info[0] != 0) { c->factor_valid = false; return c->h_info[0]; }
   c->factor_valid = true;
   gpg_backward_solve(c);

@@ -31,42 +31,88 @@ __device__ __forceinline__ double readlane_d(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
-__global__ void __launch_bounds__(64) potrf64_kernel(double* __restrict__ A, int ld, int j0, int N, int* __restrict__ info,
-                                                      double* __restrict__ dinv) {
-  __shared__ __attribute__((aligned(16))) double St[64][64];   // St[k][i] = L[i][k]
-  const int i = threadIdx.x;
-  double* blk = A + (size_t)j0 + (size_t)j0 * ld;
+// Wave-level core: `src` is the 64 x 64 block to factor (column-major, leading dimension sld; global memory
+// or an LDS tile), the factor goes to `blk` (global, leading dimension ld) and its reciprocal pivots to dinv.
+// St is a [64][64] LDS scratch private to the calling wave (St[k][i] = L[i][k]).  Returns the 1-based index
+// of the first non-positive / NaN pivot inside the block (0 = none), identical in every lane.
+// Per 16-column sub-block: (1) the update with the finished columns runs on MFMA (operands straight from the
+// St image; 4 row tiles x K/4 instructions) and is transposed into the lane = row layout through the part
+// of St that this sub-block is about to fill; (2) the 16 columns are factored in registers, pivot and
+// column broadcast by v_readlane.  The reciprocal pivot comes from v_rsq_f64 plus two coupled
+// Goldschmidt steps (sqrt and 1/sqrt to ~1 ulp in 7 dependent operations; the pivot chain is the critical
+// path of every factorisation in this file).
+__device__ __forceinline__ int potrf64_wave(const double* src, int sld, double (*St)[64], double* __restrict__ blk, int ld,
+                                            double* __restrict__ dinv) {
+  const int i = threadIdx.x & 63, l15 = i & 15, l4 = i >> 4;
   int bad = 0;
+  double myinv = 0.0;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     double a[16];
+    if (s == 0) {
 #pragma unroll
-    for (int c = 0; c < 16; ++c) a[c] = blk[i + (size_t)(16 * s + c) * ld];
-#pragma unroll 2
-    for (int k = 0; k < 16 * s; ++k) {
-      const double lik = St[k][i];
+      for (int c = 0; c < 16; ++c) a[c] = src[i + (size_t)c * sld];
+    } else {
+      d4 acc[4];
 #pragma unroll
-      for (int c = 0; c < 16; ++c) a[c] -= lik * St[k][16 * s + c];
+      for (int R = 0; R < 4; ++R)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[R][r] = src[(16 * R + l15) + (size_t)(16 * s + 4 * r + l4) * sld];
+#pragma unroll
+      for (int kk = 0; kk < 4 * s; ++kk) {
+        const double fn = St[4 * kk + l4][16 * s + l15];
+        double fm[4];
+#pragma unroll
+        for (int R = 0; R < 4; ++R) fm[R] = -St[4 * kk + l4][16 * R + l15];
+#pragma unroll
+        for (int R = 0; R < 4; ++R) acc[R] = __builtin_amdgcn_mfma_f64_16x16x4f64(fn, fm[R], acc[R], 0, 0, 0);
+      }
+#pragma unroll
+      for (int R = 0; R < 4; ++R)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) St[16 * s + 4 * r + l4][16 * R + l15] = acc[R][r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same wave writes and reads St: ordering only
+#pragma unroll
+      for (int c = 0; c < 16; ++c) a[c] = St[16 * s + c][i];
     }
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
       const double ajj = readlane_d(a[c], 16 * s + c);
       bad = (bad == 0 && !(ajj > 0.0)) ? 16 * s + c + 1 : bad;   // first non-positive / NaN pivot (LAPACK info)
-      const double inv = rsqrt(ajj);     // reciprocal pivot first: one short dependent chain per column
-      const double dj = ajj * inv;        // sqrt(ajj) to ~1 ulp
+      const double y0 = __builtin_amdgcn_rsq(ajj);
+      double g = ajj * y0, h = 0.5 * y0;
+      double r = __builtin_fma(-h, g, 0.5);
+      g = __builtin_fma(g, r, g);
+      h = __builtin_fma(h, r, h);
+      r = __builtin_fma(-h, g, 0.5);
+      const double dj = __builtin_fma(g, r, g);        // sqrt(ajj)
+      const double inv = 2.0 * __builtin_fma(h, r, h); // 1 / sqrt(ajj)
       a[c] = (i == 16 * s + c) ? dj : a[c] * inv;
-      if (i == 0) dinv[j0 + 16 * s + c] = inv;   // reciprocal pivots for the panel solves
+      myinv = (i == 16 * s + c) ? inv : myinv;   // reciprocal pivots for the panel solves: lane j keeps 1 / L_jj
 #pragma unroll
       for (int k2 = c + 1; k2 < 16; ++k2) a[k2] -= a[c] * readlane_d(a[c], 16 * s + k2);
+      // pin the updated columns here: left to itself the compiler defers these FMAs to their consumers and
+      // keeps all 120 broadcast multipliers of the sub-block alive in SGPRs (spilled through v_writelane)
+#pragma unroll
+      for (int k2 = c + 1; k2 < 16; ++k2) asm volatile("" : "+v"(a[k2]));
     }
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
       St[16 * s + c][i] = a[c];
       if (i >= 16 * s + c) blk[i + (size_t)(16 * s + c) * ld] = a[c];
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
-  if (bad && i == 0 && j0 + bad - 1 < N) atomicCAS(info, 0, j0 + bad);
+  dinv[i] = myinv;
+  return bad;
+}
+
+__global__ void __launch_bounds__(64) potrf64_kernel(double* __restrict__ A, int ld, int j0, int N, int* __restrict__ info,
+                                                      double* __restrict__ dinv) {
+  __shared__ __attribute__((aligned(16))) double St[64][64];   // St[k][i] = L[i][k]
+  double* blk = A + (size_t)j0 + (size_t)j0 * ld;
+  const int bad = potrf64_wave(blk, ld, St, blk, ld, dinv + j0);
+  if (bad && threadIdx.x == 0 && j0 + bad - 1 < N) atomicCAS(info, 0, j0 + bad);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -141,6 +187,128 @@ __global__ void __launch_bounds__(256) trsm64_kernel(const double* __restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// wave_tile_gemm: acc (wave tile 16 x 64 of a 64 x 64 workgroup tile) -= A[64 x K] B[64 x K]^T with
+// K = 16 nchunk (nchunk a positive multiple of 4).  Both operands are staged through LDS in 16-deep
+// chunks; the global loads run two chunks ahead in registers (one wave per SIMD: nothing else hides
+// the L2 latency).  ga / gb are this thread's staging sources (row pair sp, k-row sk of chunk 0).
+// Ends without a barrier: the caller synchronises before re-using sA / sB.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_tile_gemm(d4 (&acc)[4], const double* ga, int lda, const double* gb, int ldb, int nchunk,
+                                               double* sA, double* sB, int w, int l15, int l4, int sp, int sk) {
+  constexpr int KB = 16, SA = 80, BUF = KB * SA;
+  const size_t a8 = (size_t)8 * lda, b8 = (size_t)8 * ldb;
+  double2 ra0_a, ra0_b, rb0_a, rb0_b, ra1_a, ra1_b, rb1_a, rb1_b;
+#define GPG_PS_GLOAD(set)                                        \
+  ra##set##_a = *reinterpret_cast<const double2*>(ga);           \
+  ra##set##_b = *reinterpret_cast<const double2*>(ga + a8);      \
+  rb##set##_a = *reinterpret_cast<const double2*>(gb);           \
+  rb##set##_b = *reinterpret_cast<const double2*>(gb + b8);      \
+  ga += 2 * a8;                                                  \
+  gb += 2 * b8;
+#define GPG_PS_SSTORE(buf, set)                                                              \
+  {                                                                                          \
+    double2 v0, v1;                                                                          \
+    v0.x = -ra##set##_a.x; v0.y = -ra##set##_a.y; v1.x = -ra##set##_b.x; v1.y = -ra##set##_b.y;  \
+    *reinterpret_cast<double2*>(sA + (buf) * BUF + sk * SA + 2 * sp) = v0;                    \
+    *reinterpret_cast<double2*>(sA + (buf) * BUF + (sk + 8) * SA + 2 * sp) = v1;              \
+    *reinterpret_cast<double2*>(sB + (buf) * BUF + sk * SA + 2 * sp) = rb##set##_a;           \
+    *reinterpret_cast<double2*>(sB + (buf) * BUF + (sk + 8) * SA + 2 * sp) = rb##set##_b;     \
+  }
+#define GPG_PS_COMPUTE(buf)                                                                  \
+  _Pragma("unroll") for (int kk = 0; kk < KB; kk += 4) {                                      \
+    const double fm = sA[(buf) * BUF + (kk + l4) * SA + 16 * w + l15];                        \
+    double fn[4];                                                                            \
+    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) fn[ni] = sB[(buf) * BUF + (kk + l4) * SA + ni * 16 + l15]; \
+    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                          \
+      acc[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(fn[ni], fm, acc[ni], 0, 0, 0);           \
+  }
+  GPG_PS_GLOAD(0);            // chunk 0
+  GPG_PS_GLOAD(1);            // chunk 1
+  GPG_PS_SSTORE(0, 0);
+  __syncthreads();
+  for (int ch = 0; ch < nchunk; ch += 2) {   // unrolled by two so that the register sets are static
+    if (ch + 2 < nchunk) { GPG_PS_GLOAD(0); }      // chunk ch + 2
+    GPG_PS_COMPUTE(0);                             // chunk ch
+    GPG_PS_SSTORE(1, 1);                           // chunk ch + 1
+    __syncthreads();
+    if (ch + 3 < nchunk) { GPG_PS_GLOAD(1); }      // chunk ch + 3
+    GPG_PS_COMPUTE(1);                             // chunk ch + 1
+    if (ch + 2 < nchunk) { GPG_PS_SSTORE(0, 0); }  // chunk ch + 2
+    __syncthreads();
+  }
+#undef GPG_PS_GLOAD
+#undef GPG_PS_SSTORE
+#undef GPG_PS_COMPUTE
+}
+
+// quad-row substitution x <- x L^-T of one matrix row spread over a lane quad (see trsm64_kernel): x[m] is
+// column 4m + q; Ls is the LDS image Ls[j][q][m] = L[4m + q][j], sdinv the reciprocal pivots.
+#define GPG_QUAD_SUBST(x, Ls, sdinv, q)                                                      \
+  {                                                                                         \
+    double lv[2][16];                                                                       \
+    _Pragma("unroll") for (int m = 0; m < 16; ++m) lv[0][m] = Ls[0][q][m];                   \
+    _Pragma("unroll") for (int mj = 0; mj < 16; ++mj) {                                      \
+      GPG_QS_STEP(x, Ls, sdinv, q, 0)                                                        \
+      GPG_QS_STEP(x, Ls, sdinv, q, 1)                                                        \
+      GPG_QS_STEP(x, Ls, sdinv, q, 2)                                                        \
+      GPG_QS_STEP(x, Ls, sdinv, q, 3)                                                        \
+    }                                                                                       \
+  }
+#define GPG_QS_STEP(x, Ls, sdinv, q, QJ)                                                     \
+  {                                                                                         \
+    constexpr int cur = QJ & 1, nxt = cur ^ 1;                                               \
+    const int jc = 4 * mj + QJ;                                                             \
+    const int jn = jc + 1 < 64 ? jc + 1 : 63;                                               \
+    const int m0n = (jc + 1) >> 2;                                                          \
+    _Pragma("unroll") for (int m = 0; m < 16; ++m) if (m >= m0n) lv[nxt][m] = Ls[jn][q][m]; \
+    const double xs = x[mj] * sdinv[jc];                                                    \
+    x[mj] = (q == QJ) ? xs : x[mj];                                                         \
+    const double xj = quad_bcast<QJ>(x[mj]);                                                \
+    if (QJ < 3) {                                                                           \
+      const double t = x[mj] - xj * lv[cur][mj];                                            \
+      x[mj] = (q > QJ) ? t : x[mj];                                                         \
+    }                                                                                       \
+    _Pragma("unroll") for (int m = mj + 1; m < 16; ++m) x[m] -= xj * lv[cur][m];            \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+  }
+
+// two matrix rows per lane quad (x0, x1): the L values are read once for both rows
+#define GPG_QUAD_SUBST2(x0, x1, Ls, sdinv, q)                                                \
+  {                                                                                         \
+    double lv[2][16];                                                                       \
+    _Pragma("unroll") for (int m = 0; m < 16; ++m) lv[0][m] = Ls[0][q][m];                   \
+    _Pragma("unroll") for (int mj = 0; mj < 16; ++mj) {                                      \
+      GPG_QS2_STEP(x0, x1, Ls, sdinv, q, 0)                                                  \
+      GPG_QS2_STEP(x0, x1, Ls, sdinv, q, 1)                                                  \
+      GPG_QS2_STEP(x0, x1, Ls, sdinv, q, 2)                                                  \
+      GPG_QS2_STEP(x0, x1, Ls, sdinv, q, 3)                                                  \
+    }                                                                                       \
+  }
+#define GPG_QS2_STEP(x0, x1, Ls, sdinv, q, QJ)                                               \
+  {                                                                                         \
+    constexpr int cur = QJ & 1, nxt = cur ^ 1;                                               \
+    const int jc = 4 * mj + QJ;                                                             \
+    const int jn = jc + 1 < 64 ? jc + 1 : 63;                                               \
+    const int m0n = (jc + 1) >> 2;                                                          \
+    _Pragma("unroll") for (int m = 0; m < 16; ++m) if (m >= m0n) lv[nxt][m] = Ls[jn][q][m]; \
+    const double dv = sdinv[jc];                                                            \
+    const double xs0 = x0[mj] * dv, xs1 = x1[mj] * dv;                                      \
+    x0[mj] = (q == QJ) ? xs0 : x0[mj];                                                      \
+    x1[mj] = (q == QJ) ? xs1 : x1[mj];                                                      \
+    const double xj0 = quad_bcast<QJ>(x0[mj]), xj1 = quad_bcast<QJ>(x1[mj]);                \
+    if (QJ < 3) {                                                                           \
+      const double t0 = x0[mj] - xj0 * lv[cur][mj], t1 = x1[mj] - xj1 * lv[cur][mj];        \
+      x0[mj] = (q > QJ) ? t0 : x0[mj];                                                      \
+      x1[mj] = (q > QJ) ? t1 : x1[mj];                                                      \
+    }                                                                                       \
+    _Pragma("unroll") for (int m = mj + 1; m < 16; ++m) {                                    \
+      x0[m] -= xj0 * lv[cur][m];                                                            \
+      x1[m] -= xj1 * lv[cur][m];                                                            \
+    }                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+  }
+
 #ifdef GPG_STAMP   // diagnostic build of tools/gemm_probe.hip only: per-wave cycle shares of the loop phases
 __device__ unsigned long long* g_stamp_buf;
 #define GPG_T(var) unsigned long long var; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0);
@@ -159,32 +327,31 @@ __device__ unsigned long long* g_stamp_buf;
 // Replaces nb/64 trsm64 + nb/64 - 1 small-K gemm launches, whose ~15 us dependent-launch latency each
 // (not their flops) set the cost of B_p.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 2)
-panel_solve_kernel(const double* __restrict__ L, int ldl, const double* __restrict__ dinv, double* X, int ldx,
-                   int rows, int nb) {
+// Body shared with the dataflow kernels: solves the 64 rows starting at X (rows_left of them are real) with
+// the whole workgroup.  U = staging / transposition buffer (4 * 16 * 80 doubles), Ls / sdinv = image of the
+// current diagonal block.  Ends with a workgroup barrier.
+__device__ __forceinline__ void panel_solve_rows64(const double* __restrict__ L, int ldl, const double* __restrict__ dinv,
+                                                   double* X, int ldx, int rows, int nb, double* U, double (*Ls)[4][18],
+                                                   double* sdinv) {
   constexpr int KB = 16, SA = 80;                     // SA: +128 B pad keeps ds_read_b64 conflict-free
   constexpr int BUF = KB * SA;                        // doubles per staging buffer
-  __shared__ __attribute__((aligned(16))) double U[4 * BUF];   // sA[2] | sB[2]; re-used as the transposition tile Ts[64][SA]
-  __shared__ __attribute__((aligned(16))) double Ls[64][4][18];
-  __shared__ double sdinv[64];
   double* const sA = U;
   double* const sB = U + 2 * BUF;
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
-  const int m0 = blockIdx.x * 64;
   // MFMA-side row of this lane, substitution-side row of this lane (both inside the wave's 16 rows)
-  int rowc = m0 + 16 * w + l15;
+  int rowc = 16 * w + l15;
   const bool c_ok = rowc < rows;
   rowc = c_ok ? rowc : rows - 1;
   const int q = tid & 3;
-  int rowt = m0 + (tid >> 2);
+  int rowt = tid >> 2;
   const bool t_ok = rowt < rows;
   rowt = t_ok ? rowt : rows - 1;
 
   // staging: thread -> (row pair p, k) ; two double2 per operand per chunk
   const int sp = tid & 31, sk = tid >> 5;             // sk in 0..7, second load at sk + 8
-  int rowa = m0 + 2 * sp;
+  int rowa = 2 * sp;
   rowa = rowa + 1 < rows ? rowa : (rows >= 2 ? rows - 2 : 0);
 
   double cx[16], li[16];   // next block's X tile (MFMA layout) and L_jj (linear), prefetched
@@ -220,55 +387,9 @@ panel_solve_kernel(const double* __restrict__ L, int ldl, const double* __restri
     // ---- (1) MFMA phase -----------------------------------------------------------------------------------
     const int nchunk = 4 * j;                          // K = 64 j in chunks of 16
     GPG_T(p1)
-    if (nchunk > 0) {
-      const double* ga = X + rowa + (size_t)sk * ldx;
-      const double* gb = L + (size_t)(64 * j + 2 * sp) + (size_t)sk * ldl;
-      const size_t a8 = (size_t)8 * ldx, b8 = (size_t)8 * ldl;
-      // register prefetch two chunks ahead (one wave per SIMD: nothing else hides the L2 latency)
-      double2 ra0_a, ra0_b, rb0_a, rb0_b, ra1_a, ra1_b, rb1_a, rb1_b;
-#define GPG_PS_GLOAD(set)                                        \
-  ra##set##_a = *reinterpret_cast<const double2*>(ga);            \
-  ra##set##_b = *reinterpret_cast<const double2*>(ga + a8);       \
-  rb##set##_a = *reinterpret_cast<const double2*>(gb);            \
-  rb##set##_b = *reinterpret_cast<const double2*>(gb + b8);       \
-  ga += 2 * a8;                                                  \
-  gb += 2 * b8;
-#define GPG_PS_SSTORE(buf, set)                                                              \
-  {                                                                                          \
-    double2 v0, v1;                                                                          \
-    v0.x = -ra##set##_a.x; v0.y = -ra##set##_a.y; v1.x = -ra##set##_b.x; v1.y = -ra##set##_b.y;  \
-    *reinterpret_cast<double2*>(sA + (buf) * BUF + sk * SA + 2 * sp) = v0;                    \
-    *reinterpret_cast<double2*>(sA + (buf) * BUF + (sk + 8) * SA + 2 * sp) = v1;              \
-    *reinterpret_cast<double2*>(sB + (buf) * BUF + sk * SA + 2 * sp) = rb##set##_a;            \
-    *reinterpret_cast<double2*>(sB + (buf) * BUF + (sk + 8) * SA + 2 * sp) = rb##set##_b;      \
-  }
-#define GPG_PS_COMPUTE(buf)                                                                  \
-  _Pragma("unroll") for (int kk = 0; kk < KB; kk += 4) {                                      \
-    const double fm = sA[(buf) * BUF + (kk + l4) * SA + 16 * w + l15];                        \
-    double fn[4];                                                                            \
-    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) fn[ni] = sB[(buf) * BUF + (kk + l4) * SA + ni * 16 + l15]; \
-    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                          \
-      acc[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(fn[ni], fm, acc[ni], 0, 0, 0);           \
-  }
-      // nchunk is a multiple of 4: the loop is unrolled by two so that the register sets are static
-      GPG_PS_GLOAD(0);            // chunk 0
-      GPG_PS_GLOAD(1);            // chunk 1
-      GPG_PS_SSTORE(0, 0);
-      __syncthreads();
-      for (int ch = 0; ch < nchunk; ch += 2) {
-        if (ch + 2 < nchunk) { GPG_PS_GLOAD(0); }      // chunk ch + 2
-        GPG_PS_COMPUTE(0);                             // chunk ch
-        GPG_PS_SSTORE(1, 1);                           // chunk ch + 1
-        __syncthreads();
-        if (ch + 3 < nchunk) { GPG_PS_GLOAD(1); }      // chunk ch + 3
-        GPG_PS_COMPUTE(1);                             // chunk ch + 1
-        if (ch + 2 < nchunk) { GPG_PS_SSTORE(0, 0); }  // chunk ch + 2
-        __syncthreads();
-      }
-#undef GPG_PS_GLOAD
-#undef GPG_PS_SSTORE
-#undef GPG_PS_COMPUTE
-    }
+    if (nchunk > 0)
+      wave_tile_gemm(acc, X + rowa + (size_t)sk * ldx, ldx, L + (size_t)(64 * j + 2 * sp) + (size_t)sk * ldl, ldl, nchunk, sA, sB,
+                     w, l15, l4, sp, sk);
     __syncthreads();   // staging buffers free (they become Ts), L_jj image complete
     GPG_T(p2)
     // ---- (2) substitution phase: accumulators -> Ts[col][row] -> 4 lanes per row ---------------------------
@@ -288,34 +409,7 @@ panel_solve_kernel(const double* __restrict__ L, int ldl, const double* __restri
     }
     if (j + 1 < nb / 64) GPG_PS_PREFETCH(j + 1)
     GPG_T(p3)
-    double lv[2][16];
-#pragma unroll
-    for (int m = 0; m < 16; ++m) lv[0][m] = Ls[0][q][m];
-#define GPG_TRSM_STEP(QJ)                                                                   \
-  {                                                                                         \
-    constexpr int cur = QJ & 1, nxt = cur ^ 1;                                               \
-    const int jc = 4 * mj + QJ;                                                             \
-    const int jn = jc + 1 < 64 ? jc + 1 : 63;                                               \
-    const int m0n = (jc + 1) >> 2;                                                          \
-    _Pragma("unroll") for (int m = 0; m < 16; ++m) if (m >= m0n) lv[nxt][m] = Ls[jn][q][m]; \
-    const double xs = x[mj] * sdinv[jc];                                                    \
-    x[mj] = (q == QJ) ? xs : x[mj];                                                         \
-    const double xj = quad_bcast<QJ>(x[mj]);                                                \
-    if (QJ < 3) {                                                                           \
-      const double t = x[mj] - xj * lv[cur][mj];                                            \
-      x[mj] = (q > QJ) ? t : x[mj];                                                         \
-    }                                                                                       \
-    _Pragma("unroll") for (int m = mj + 1; m < 16; ++m) x[m] -= xj * lv[cur][m];            \
-    __builtin_amdgcn_sched_barrier(0);                                                      \
-  }
-#pragma unroll
-    for (int mj = 0; mj < 16; ++mj) {
-      GPG_TRSM_STEP(0)
-      GPG_TRSM_STEP(1)
-      GPG_TRSM_STEP(2)
-      GPG_TRSM_STEP(3)
-    }
-#undef GPG_TRSM_STEP
+    GPG_QUAD_SUBST(x, Ls, sdinv, q)
     GPG_T(p4)
     if (t_ok) {
       double* Xr = X + rowt + (size_t)(64 * j + q) * ldx;
@@ -335,6 +429,154 @@ panel_solve_kernel(const double* __restrict__ L, int ldl, const double* __restri
     o[0] = ps_pre; o[1] = ps_gemm; o[2] = ps_tr; o[3] = ps_sub; o[4] = ps_st;
   }
 #endif
+}
+
+__global__ void __launch_bounds__(256, 2)
+panel_solve_kernel(const double* __restrict__ L, int ldl, const double* __restrict__ dinv, double* X, int ldx,
+                   int rows, int nb) {
+  __shared__ __attribute__((aligned(16))) double U[4 * 16 * 80];   // sA[2] | sB[2]; re-used as the transposition tile Ts[64][80]
+  __shared__ __attribute__((aligned(16))) double Ls[64][4][18];
+  __shared__ double sdinv[64];
+  const int m0 = blockIdx.x * 64;
+  panel_solve_rows64(L, ldl, dinv, X + m0, ldx, rows - m0, nb, U, Ls, sdinv);
+}
+
+// ------------------------------------------------------------------------------------------------
+// tile_chol_kernel: dataflow (left-looking) Cholesky of the trailing block A[c0:, c0:] in 64 x 64 tiles,
+// ONE launch.  Used where the blocked algorithm is latency-bound: the last few thousand columns of a large
+// matrix and small matrices as a whole.  Workgroup b owns tile (i, j) = tasks[b] (column-major task order,
+// rows i >= j; the right-hand-side rows below the matrix are ordinary tile rows):
+//     acc  = A_ij - sum_{k<j} L_ik L_jk^T      MFMA, k-blocks consumed as soon as their flags are up
+//     i==j : L_jj = chol(acc) by wave 0 (potrf64_wave), reciprocal pivots to dinv
+//     i> j : L_ij = acc L_jj^-T by the quad-row substitution, once flag(j, j) is up
+//     publish: __threadfence, then flag(i, j) = 1 (agent-scope release)
+// A task only ever waits for tasks with a smaller index, and workgroups are dispatched in index order, so
+// the oldest unfinished workgroup can always run to completion (no deadlock whatever the residency).  As
+// a backstop every wait is bounded: on timeout the kernel raises the abort word, all workgroups drain, and
+// the host reports an internal error.  The serial chain per 64 columns is potrf -> substitution ->
+// one 64-deep MFMA block (~20 us) instead of three dependent launches per step plus B_p and U_p.
+// ------------------------------------------------------------------------------------------------
+#define GPG_TILE_SPIN_LIMIT 400000   // x ~0.5 us per poll: ~0.2 s
+__global__ void __launch_bounds__(256, 2)
+tile_chol_kernel(double* A, int ld, int c0, int Mt, const int* __restrict__ tasks, int* flags, int* abort_word,
+                 double* __restrict__ dinv, int* __restrict__ info, int N) {
+  constexpr int KB = 16, SA = 80, BUF = KB * SA;
+  __shared__ __attribute__((aligned(16))) double U[4 * BUF];      // staging sA[2] | sB[2]; later the tile Ts[64][SA]
+  __shared__ __attribute__((aligned(16))) double Ls[64][4][18];   // L_jj image (i > j) / potrf scratch St[64][64] (i == j)
+  __shared__ double sdinv[64];
+  __shared__ int sh_kr;
+  double* const sA = U;
+  double* const sB = U + 2 * BUF;
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int task = tasks[blockIdx.x];
+  const int ti = task & 0xffff, tj = task >> 16;
+  const size_t r0 = (size_t)c0 + 64 * (size_t)ti;        // first matrix row of the tile
+  const size_t cj = (size_t)c0 + 64 * (size_t)tj;        // first matrix column of the tile
+  const int q = tid & 3;
+  const int sp = tid & 31, sk = tid >> 5;
+  int* const frow_i = flags + (size_t)ti * Mt;           // flags of tile row i
+  int* const frow_j = flags + (size_t)tj * Mt;
+
+  // accumulators start as A_ij
+  d4 acc[4];
+  {
+    const double* Cw = A + r0 + 16 * w + l15 + (cj + l4) * (size_t)ld;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[ni][r] = Cw[(size_t)(ni * 16 + 4 * r) * ld];
+  }
+
+  // ---- (1) left-looking accumulation over the finished tile columns ------------------------------------------
+  int kdone = 0;
+  while (kdone < tj) {
+    if (tid == 0) {
+      int kr = kdone, spins = 0;
+      for (;;) {
+        while (kr < tj && __hip_atomic_load(frow_i + kr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 &&
+               __hip_atomic_load(frow_j + kr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+          ++kr;
+        if (kr > kdone) break;
+        if (++spins > GPG_TILE_SPIN_LIMIT || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+          __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          atomicMax(info, GPG_INFO_INTERNAL);
+          kr = -1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+      }
+      sh_kr = kr;
+    }
+    __syncthreads();
+    const int kr = sh_kr;
+    if (kr < 0) return;                                  // abort: drain
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the producers' tiles are visible from here on
+    const size_t ck = (size_t)c0 + 64 * (size_t)kdone;
+    wave_tile_gemm(acc, A + r0 + 2 * sp + (ck + sk) * (size_t)ld, ld, A + cj + 2 * sp + (ck + sk) * (size_t)ld, ld,
+                   4 * (kr - kdone), sA, sB, w, l15, l4, sp, sk);
+    __syncthreads();                                     // staging buffers free again; sh_kr may be rewritten
+    kdone = kr;
+  }
+
+  // ---- (2) accumulators -> LDS tile Ts[col][row] --------------------------------------------------------------
+  {
+    double* Ts = U;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Ts[(ni * 16 + 4 * r + l4) * SA + 16 * w + l15] = acc[ni][r];
+  }
+  if (ti == tj) {
+    __syncthreads();
+    if (w == 0) {   // diagonal tile: factor it (one wave; entries above the diagonal are garbage nobody reads)
+      double* blk = A + r0 + cj * (size_t)ld;
+      const int bad = potrf64_wave(U, SA, reinterpret_cast<double(*)[64]>(&Ls[0][0][0]), blk, ld, dinv + cj);
+      if (bad && lane == 0 && (int)cj + bad - 1 < N) atomicCAS(info, 0, (int)cj + bad);
+    }
+  } else {
+    // wait for the diagonal tile of this column, then substitute
+    if (tid == 0) {
+      int spins = 0, ok = 1;
+      while (__hip_atomic_load(frow_j + tj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        if (++spins > GPG_TILE_SPIN_LIMIT || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+          __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          atomicMax(info, GPG_INFO_INTERNAL);
+          ok = 0;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+      }
+      sh_kr = ok;
+    }
+    __syncthreads();
+    if (sh_kr == 0) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    {
+      const double* Ljj = A + cj + cj * (size_t)ld;
+      for (int t = tid; t < 64 * 64; t += 256) {
+        const int jj = t >> 6, k = t & 63;
+        Ls[jj][k & 3][k >> 2] = Ljj[k + (size_t)jj * ld];
+      }
+      if (tid < 64) sdinv[tid] = dinv[cj + tid];
+    }
+    __syncthreads();
+    double x[16];
+    {
+      const double* Tr = U + q * SA + (tid >> 2);
+#pragma unroll
+      for (int m = 0; m < 16; ++m) x[m] = Tr[(4 * m) * SA];
+    }
+    GPG_QUAD_SUBST(x, Ls, sdinv, q)
+    double* Xr = A + r0 + (tid >> 2) + (cj + q) * (size_t)ld;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) Xr[(size_t)(4 * m) * ld] = x[m];
+  }
+  // ---- (3) publish ----------------------------------------------------------------------------------------------
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(frow_i + tj, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -632,6 +874,480 @@ gemm_dma_kernel(double* __restrict__ C, int ldc, const double* __restrict__ A, i
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// gemm_direct_kernel: 128 x 128 tile update C -= A B^T with NO LDS: every wave loads its MFMA operand
+// fragments straight from global memory in fragment layout (lane&15 -> row of the slice: 128 contiguous
+// bytes; lane>>4 -> k: four segments per instruction), PF k-steps ahead in registers.  The two waves that
+// share a row slice hit in the vector L1.  No DMA issue stalls, no barriers: waves run independently.
+// ------------------------------------------------------------------------------------------------
+template <int PF>
+__global__ void __launch_bounds__(256, 2)
+gemm_direct_kernel(double* __restrict__ C, int ldc, const double* __restrict__ A, int lda, const double* __restrict__ B,
+                   int ldb, int M, int Nc, int K, int lower, int skipM, int skipN, const int* __restrict__ tilemap,
+                   int ntiles) {
+  constexpr int BM = 128, BN = 128;
+  int m0, n0;
+  if (tilemap) {
+    const int nwg = ntiles, b = blockIdx.x;
+    const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+    const int t = tilemap[v];
+    m0 = (t & 0xffff) * BM;
+    n0 = (t >> 16) * BN;
+  } else {
+    m0 = blockIdx.x * BM;
+    n0 = blockIdx.y * BN;
+    if (lower && m0 + BM <= n0) return;
+    if (m0 < skipM && n0 < skipN) return;
+  }
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w & 1, wn = w >> 1;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const bool wave_active = (m0 + wm * 64) < M;
+
+  d4 acc[4][4];
+  double* Cw = C + (size_t)(m0 + wm * 64 + l15) + (size_t)(n0 + wn * 64 + l4) * ldc;
+  if (wave_active) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[ni][mi][r] = Cw[mi * 16 + (size_t)(ni * 16 + 4 * r) * ldc];
+  } else {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = d4{0, 0, 0, 0};
+  }
+  int rowa = m0 + wm * 64 + l15;
+  rowa = wave_active ? rowa : m0 + l15;                    // inactive wave of a ragged tile: recompute valid rows, never store
+  const double* pa = A + rowa + (size_t)l4 * lda;
+  const double* pb = B + n0 + wn * 64 + l15 + (size_t)l4 * ldb;
+  const size_t sa = (size_t)4 * lda, sb = (size_t)4 * ldb;
+
+  double f[PF + 1][8];
+#define GPG_DR_LOAD(set)                                                              \
+  {                                                                                   \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) f[set][mi] = pa[mi * 16];         \
+    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) f[set][4 + ni] = pb[ni * 16];     \
+    pa += sa;                                                                         \
+    pb += sb;                                                                         \
+  }
+#define GPG_DR_MFMA(set)                                                              \
+  {                                                                                   \
+    double fm[4];                                                                     \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) fm[mi] = -f[set][mi];             \
+    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                   \
+      _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                 \
+        acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[set][4 + ni], fm[mi], acc[ni][mi], 0, 0, 0); \
+  }
+  const int nstep = K / 4;   // K is a multiple of 4 (PF + 1): the ring index stays static under the unroll
+#pragma unroll
+  for (int s = 0; s < PF; ++s) GPG_DR_LOAD(s)
+  for (int s0 = 0; s0 < nstep; s0 += PF + 1) {
+#pragma unroll
+    for (int u = 0; u <= PF; ++u) {
+      if (s0 + u + PF < nstep) GPG_DR_LOAD((u + PF) % (PF + 1))
+      __builtin_amdgcn_sched_barrier(0);
+      GPG_DR_MFMA(u)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#undef GPG_DR_LOAD
+#undef GPG_DR_MFMA
+  if (wave_active) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cw[mi * 16 + (size_t)(ni * 16 + 4 * r) * ldc] = acc[ni][mi][r];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dma_tile_gemm: the main loop of gemm_dma_kernel as a device function.  acc (wave tile 64 x 64 of a
+// 128 x 128 workgroup tile) -= A[128 x K] B[128 x K]^T, K = 8 nchunk (nchunk >= 3), both row slices
+// streamed by global_load_lds_dwordx4 into the 4-stage ring `ring`.  ga / gb: this lane's DMA sources for
+// k-row w of chunk 0 (row pair 2 * lane of the slice).  Returns with the ring drained and a barrier passed.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void dma_tile_gemm(d4 (&acc)[4][4], const double* ga, int lda, const double* gb, int ldb,
+                                              int nchunk, double* ring, int w, int wm, int wn, int l15, int l4) {
+  constexpr int S = 4, KB = 8, ROW = 144, STAGE = 2 * KB * ROW;
+  const size_t a4 = (size_t)4 * lda, b4 = (size_t)4 * ldb, aK = (size_t)KB * lda, bK = (size_t)KB * ldb;
+#define GPG_DT_ISSUE(stage)                                                                               \
+  {                                                                                                       \
+    double* sa = ring + (stage) * STAGE + w * ROW;                                                         \
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)ga, (lds_ptr_t)sa, 16, 0, 0);                              \
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(ga + a4), (lds_ptr_t)(sa + 4 * ROW), 16, 0, 0);          \
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)gb, (lds_ptr_t)(sa + KB * ROW), 16, 0, 0);                 \
+    __builtin_amdgcn_global_load_lds((glb_ptr_t)(gb + b4), (lds_ptr_t)(sa + (KB + 4) * ROW), 16, 0, 0);    \
+    ga += aK;                                                                                             \
+    gb += bK;                                                                                             \
+  }
+#define GPG_DT_COMPUTE(stage)                                                                             \
+  {                                                                                                       \
+    const double* pa = ring + (stage) * STAGE + l4 * ROW + wm * 64 + l15;                                  \
+    const double* pb = ring + (stage) * STAGE + (KB + l4) * ROW + wn * 64 + l15;                           \
+    _Pragma("unroll") for (int kk = 0; kk < KB; kk += 4) {                                                 \
+      double fm[4], fn[4];                                                                                \
+      _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) fm[mi] = -pa[kk * ROW + mi * 16];                    \
+      _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) fn[ni] = pb[kk * ROW + ni * 16];                     \
+      _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                     \
+        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                   \
+          acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fn[ni], fm[mi], acc[ni][mi], 0, 0, 0);        \
+    }                                                                                                     \
+  }
+#pragma unroll
+  for (int st = 0; st < S - 1; ++st) GPG_DT_ISSUE(st)
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  int stage = 0;
+  for (int i = 0; i < nchunk; ++i) {
+    const bool more = (i + S - 1) < nchunk;
+    if (more) {
+      int st = stage + S - 1;
+      st = st >= S ? st - S : st;
+      GPG_DT_ISSUE(st)
+    }
+    GPG_DT_COMPUTE(stage)
+    if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    stage = stage + 1 == S ? 0 : stage + 1;
+  }
+#undef GPG_DT_ISSUE
+#undef GPG_DT_COMPUTE
+}
+
+// direct_tile_gemm: main loop of gemm_direct_kernel as a device function.  acc (wave tile 64 x 64) -=
+// A[64 x 4 nstep] B[64 x 4 nstep]^T with operand fragments loaded straight from global memory, PF k-steps
+// ahead.  pa / pb: this lane's fragment sources of k-step 0 (row lane&15 of the wave's slice, k = lane>>4);
+// nstep a positive multiple of PF + 1.  No LDS, no barrier.
+template <int PF>
+__device__ __forceinline__ void direct_tile_gemm(d4 (&acc)[4][4], const double* pa, int lda, const double* pb, int ldb,
+                                                 int nstep) {
+  const size_t sa = (size_t)4 * lda, sb = (size_t)4 * ldb;
+  double f[PF + 1][8];
+#define GPG_DR_LOAD(set)                                                              \
+  {                                                                                   \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) f[set][mi] = pa[mi * 16];         \
+    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) f[set][4 + ni] = pb[ni * 16];     \
+    pa += sa;                                                                         \
+    pb += sb;                                                                         \
+  }
+#define GPG_DR_MFMA(set)                                                              \
+  {                                                                                   \
+    double fm[4];                                                                     \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) fm[mi] = -f[set][mi];             \
+    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                   \
+      _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                 \
+        acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[set][4 + ni], fm[mi], acc[ni][mi], 0, 0, 0); \
+  }
+#pragma unroll
+  for (int s = 0; s < PF; ++s) GPG_DR_LOAD(s)
+  for (int s0 = 0; s0 < nstep; s0 += PF + 1) {
+#pragma unroll
+    for (int u = 0; u <= PF; ++u) {
+      if (s0 + u + PF < nstep) GPG_DR_LOAD((u + PF) % (PF + 1))
+      __builtin_amdgcn_sched_barrier(0);
+      GPG_DR_MFMA(u)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#undef GPG_DR_LOAD
+#undef GPG_DR_MFMA
+}
+
+// ------------------------------------------------------------------------------------------------
+// tile128_chol_kernel: the whole factorisation as ONE dataflow launch over 128 x 128 tiles (left-looking).
+// Workgroup b owns tile (i, j) = tasks[b], column-major task order, rows i >= j (the right-hand-side rows
+// below the matrix are one more tile row):
+//     acc  = A_ij - sum_{k<j} L_ik L_jk^T   the direct-fragment MFMA loop of gemm_direct_kernel over every finished tile
+//                                          column, consumed in runs as the flags come up.  The C tile is read
+//                                          once and written once per factorisation (the right-looking update
+//                                          streams it once per panel) and there is no launch chain at all.
+//     i==j : potrf of the 128 x 128 tile inside the workgroup (potrf64, 64-row substitution, 64 x 64 MFMA
+//            update, potrf64)
+//     i> j : L_ij = acc L_jj^-T, two 64-row passes of panel_solve_rows64 against the 128-wide diagonal tile
+//     publish: __threadfence, flag(i, j) = 1 (agent-scope release)
+// Progress argument and bounded waits as in tile_chol_kernel.
+// ------------------------------------------------------------------------------------------------
+// X (128 rows x 128 columns, in place) <- X L^-T against a factorised 128 x 128 diagonal tile, whole workgroup.
+// Each lane quad carries TWO matrix rows (r and r + 64) through the substitution, so the 128 rows cost two
+// substitution sweeps instead of four and half the L-image traffic.  Column block 0 is read from memory
+// straight in the quad layout; block 1 first takes its update X1 L21^T on MFMA (two 64-row passes through
+// the LDS tile).  U: 4 * 16 * 80 doubles, Ls / sdinv: diagonal-block image.  Ends with a workgroup barrier.
+__device__ __forceinline__ void tile_solve_rows128(const double* __restrict__ L, int ldl, const double* __restrict__ dinv,
+                                                   double* X, int ldx, double* U, double (*Ls)[4][18], double* sdinv) {
+  constexpr int SA = 80, BUF = 16 * SA;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int q = tid & 3, rr = tid >> 2;
+  const int sp = tid & 31, sk = tid >> 5;
+  double x0[16], x1[16], li[16];
+  // ---- column block 0 ----------------------------------------------------------------------------------------
+  {
+    const double* Xr = X + rr + (size_t)q * ldx;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      x0[m] = Xr[(size_t)(4 * m) * ldx];
+      x1[m] = Xr[64 + (size_t)(4 * m) * ldx];
+    }
+    for (int t = tid; t < 64 * 64; t += 256) {
+      const int jj = t >> 6, k = t & 63;
+      Ls[jj][k & 3][k >> 2] = L[k + (size_t)jj * ldl];
+    }
+    if (tid < 64) sdinv[tid] = dinv[tid];
+  }
+  __syncthreads();
+  {   // image of L22 for block 1, fetched behind the first substitution
+    const double* L22 = L + 64 + (size_t)64 * ldl;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int t = tid + 256 * i;
+      li[i] = L22[(t & 63) + (size_t)(t >> 6) * ldl];
+    }
+  }
+  GPG_QUAD_SUBST2(x0, x1, Ls, sdinv, q)
+  {
+    double* Xr = X + rr + (size_t)q * ldx;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      Xr[(size_t)(4 * m) * ldx] = x0[m];
+      Xr[64 + (size_t)(4 * m) * ldx] = x1[m];
+    }
+  }
+  __syncthreads();   // X1 visible to the workgroup, Ls free
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int t = tid + 256 * i, jj = t >> 6, k = t & 63;
+    Ls[jj][k & 3][k >> 2] = li[i];
+  }
+  if (tid < 64) sdinv[tid] = dinv[64 + tid];
+  // ---- column block 1: T2 -= X1 L21^T for the two row halves, each transposed through the LDS tile ---------------
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    d4 acc[4];
+    const double* Cw = X + 64 * h + 16 * w + l15 + (size_t)(64 + l4) * ldx;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[ni][r] = Cw[(size_t)(ni * 16 + 4 * r) * ldx];
+    wave_tile_gemm(acc, X + 64 * h + 2 * sp + (size_t)sk * ldx, ldx, L + 64 + 2 * sp + (size_t)sk * ldl, ldl, 4, U, U + 2 * BUF,
+                   w, l15, l4, sp, sk);
+    __syncthreads();
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) U[(ni * 16 + 4 * r + l4) * SA + 16 * w + l15] = acc[ni][r];
+    __syncthreads();
+    const double* Tr = U + q * SA + rr;
+    if (h == 0) {
+#pragma unroll
+      for (int m = 0; m < 16; ++m) x0[m] = Tr[(4 * m) * SA];
+    } else {
+#pragma unroll
+      for (int m = 0; m < 16; ++m) x1[m] = Tr[(4 * m) * SA];
+    }
+    __syncthreads();   // tile consumed before the next pass stages into U again
+  }
+  GPG_QUAD_SUBST2(x0, x1, Ls, sdinv, q)
+  {
+    double* Xr = X + rr + (size_t)(64 + q) * ldx;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      Xr[(size_t)(4 * m) * ldx] = x0[m];
+      Xr[64 + (size_t)(4 * m) * ldx] = x1[m];
+    }
+  }
+  __syncthreads();
+}
+
+// Finalisation of a 128 x 128 tile that already sits updated in memory (kept out of line so that its register
+// needs do not leak into the MFMA loop of the kernel).  Returns 0 if the wait for the diagonal tile timed out.
+__shared__ __attribute__((aligned(16))) double t128_U[4 * 16 * 80];   // staging / transposition tile of the finalisation
+__shared__ __attribute__((aligned(16))) double t128_Ls[64][4][18];    // diagonal-block image / potrf scratch
+__shared__ double t128_sdinv[64];
+
+__device__ __noinline__ int tile128_finalize(double* A, int ld, size_t r0, size_t cj, int is_diag, int* flag_jj,
+                                             int* abort_word, double* __restrict__ dinv, int* __restrict__ info, int N) {
+  constexpr int SA = 80;
+  double* const U = t128_U;
+  double (*const Ls)[4][18] = t128_Ls;
+  double* const sdinv = t128_sdinv;
+  __shared__ int sh_ok;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+#ifdef GPG_STAMP
+  unsigned long long* fo = (g_stamp_buf != nullptr && blockIdx.x < 16384) ? g_stamp_buf + 16384 * 8 + (size_t)blockIdx.x * 8 : nullptr;
+#define GPG_FS(k) if (tid == 0 && fo) fo[k] = __builtin_amdgcn_s_memrealtime();
+#else
+#define GPG_FS(k)
+#endif
+  GPG_FS(0)
+  if (is_diag) {
+    double* blk = A + cj + cj * (size_t)ld;
+    double (*St)[64] = reinterpret_cast<double(*)[64]>(&Ls[0][0][0]);   // potrf scratch over the Ls region
+    if (w == 0) {   // A11 was left in the LDS tile by this same wave (no barrier, no trip through memory)
+      const int bad = potrf64_wave(U, SA, St, blk, ld, dinv + cj);
+      if (bad && lane == 0 && (int)cj + bad - 1 < N) atomicCAS(info, 0, (int)cj + bad);
+    }
+    __syncthreads();   // also drains the other waves' stores of A21 / A22
+    GPG_FS(1)
+    // L21 = A21 L11^-T
+    panel_solve_rows64(blk, ld, dinv + cj, blk + 64, ld, 64, 64, U, Ls, sdinv);
+    GPG_FS(2)
+    // A22 -= L21 L21^T on MFMA, then factor it from the LDS tile
+    const int sp = tid & 31, sk = tid >> 5;
+    d4 a2[4];
+    const double* C2 = blk + 64 + 16 * w + l15 + (size_t)(64 + l4) * ld;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a2[ni][r] = C2[(size_t)(ni * 16 + 4 * r) * ld];
+    const double* g21 = blk + 64 + 2 * sp + (size_t)sk * ld;
+    wave_tile_gemm(a2, g21, ld, g21, ld, 4, U, U + 2 * 16 * SA, w, l15, l4, sp, sk);
+    __syncthreads();
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) U[(ni * 16 + 4 * r + l4) * SA + 16 * w + l15] = a2[ni][r];
+    __syncthreads();
+    GPG_FS(3)
+    if (w == 0) {
+      const int bad = potrf64_wave(U, SA, St, blk + 64 + (size_t)64 * ld, ld, dinv + cj + 64);
+      if (bad && lane == 0 && (int)cj + 64 + bad - 1 < N) atomicCAS(info, 0, (int)cj + 64 + bad);
+    }
+    GPG_FS(4)
+    return 1;
+  }
+  if (tid == 0) {
+    int spins = 0, ok = 1;
+    while (__hip_atomic_load(flag_jj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+      if (++spins > GPG_TILE_SPIN_LIMIT || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          atomicMax(info, GPG_INFO_INTERNAL);
+        ok = 0;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    sh_ok = ok;
+  }
+  __syncthreads();
+  if (sh_ok == 0) return 0;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  GPG_FS(1)
+  const double* Ljj = A + cj + cj * (size_t)ld;
+  double* X = A + r0 + cj * (size_t)ld;
+  tile_solve_rows128(Ljj, ld, dinv + cj, X, ld, U, Ls, sdinv);
+  GPG_FS(2)
+  GPG_FS(3)
+  return 1;
+}
+
+__global__ void __launch_bounds__(256, 2)
+tile128_chol_kernel(double* A, int ld, int Mt, const int* __restrict__ tasks, int* flags, int* abort_word,
+                    double* __restrict__ dinv, int* __restrict__ info, int N) {
+  __shared__ int sh_kr;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w & 1, wn = w >> 1;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int task = tasks[blockIdx.x];
+  const int ti = task & 0xffff, tj = task >> 16;
+  const size_t r0 = 128 * (size_t)ti, cj = 128 * (size_t)tj;
+  int* const frow_i = flags + (size_t)ti * Mt;
+  int* const frow_j = flags + (size_t)tj * Mt;
+
+#ifdef GPG_STAMP
+  const unsigned long long tk_start = __builtin_amdgcn_s_memrealtime();
+  unsigned long long tk_spin = 0, tk_gemm = 0, tk_runs = 0;
+#endif
+  d4 acc[4][4];
+  double* Cw = A + r0 + wm * 64 + l15 + (cj + wn * 64 + l4) * (size_t)ld;
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[ni][mi][r] = Cw[mi * 16 + (size_t)(ni * 16 + 4 * r) * ld];
+
+  // ---- (1) left-looking accumulation ----------------------------------------------------------------------------
+  int kdone = 0;
+  while (kdone < tj) {
+    GPG_T(q0)
+    if (tid == 0) {
+      int kr = kdone, spins = 0;
+      for (;;) {
+        while (kr < tj && __hip_atomic_load(frow_i + kr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 &&
+               __hip_atomic_load(frow_j + kr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+          ++kr;
+        if (kr > kdone) break;
+        if (++spins > GPG_TILE_SPIN_LIMIT || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+          __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          atomicMax(info, GPG_INFO_INTERNAL);
+          kr = -1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+      sh_kr = kr;
+    }
+    __syncthreads();
+    const int kr = sh_kr;
+    if (kr < 0) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    GPG_T(q1)
+    const size_t ck = 128 * (size_t)kdone;
+    direct_tile_gemm<3>(acc, A + r0 + wm * 64 + l15 + (ck + l4) * (size_t)ld, ld, A + cj + wn * 64 + l15 + (ck + l4) * (size_t)ld,
+                        ld, 32 * (kr - kdone));
+    __syncthreads();   // sh_kr may be rewritten
+    GPG_T(q2)
+#ifdef GPG_STAMP
+    tk_spin += q1 - q0; tk_gemm += q2 - q1; ++tk_runs;
+#endif
+    kdone = kr;
+  }
+
+#ifdef GPG_STAMP
+  const unsigned long long tk_fin0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  // ---- (2) the updated tile goes back to memory; the finalisation works on it in place.  Diagonal tile: the
+  //      top-left 64 x 64 block goes straight into the LDS tile its own wave factors next, the strictly upper
+  //      block is dropped. ---------------------------------------------------------------------------------------
+  if (ti == tj && w == 0) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t128_U[(ni * 16 + 4 * r + l4) * 80 + mi * 16 + l15] = acc[ni][mi][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  } else if (!(ti == tj && wm == 0)) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Cw[mi * 16 + (size_t)(ni * 16 + 4 * r) * ld] = acc[ni][mi][r];
+  }
+  if (ti != tj) __syncthreads();
+  if (tile128_finalize(A, ld, r0, cj, ti == tj, frow_j + tj, abort_word, dinv, info, N) == 0) return;
+  // ---- (3) publish ----------------------------------------------------------------------------------------------
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(frow_i + tj, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef GPG_STAMP
+  if (tid == 0 && g_stamp_buf != nullptr && blockIdx.x < 16384) {
+    unsigned long long* o = g_stamp_buf + (size_t)blockIdx.x * 8;
+    o[0] = tk_start; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = tk_spin; o[3] = tk_gemm; o[4] = tk_runs;
+    o[5] = tk_fin0; o[6] = (unsigned long long)task;
+  }
+#endif
+}
+
 template <int BM, int BN>
 void launch_gemm(gpg_ctx* c, double* C, int ldc, const double* A, int lda, const double* B, int ldb, int M, int Nc,
                  int K, int lower, int skipM = 0, int skipN = 0) {
@@ -683,8 +1399,71 @@ void launch_gemm_trailing(gpg_ctx* c, double* C, int ldc, const double* A, int l
                        (const int*)tm.dev, tm.n);
     return;
   }
+  if (c->gemm_impl == 3) {
+    hipLaunchKernelGGL(gemm_direct_kernel<3>, dim3(tm.n), dim3(256), 0, c->stream, C, ldc, A, lda, B, ldb, M, Nc, K, 1, 0, 0,
+                       (const int*)tm.dev, tm.n);
+    return;
+  }
+  if (c->gemm_impl == 4) {
+    hipLaunchKernelGGL(gemm_direct_kernel<7>, dim3(tm.n), dim3(256), 0, c->stream, C, ldc, A, lda, B, ldb, M, Nc, K, 1, 0, 0,
+                       (const int*)tm.dev, tm.n);
+    return;
+  }
   hipLaunchKernelGGL((gemm_nt_minus_kernel<128, 128>), dim3(tm.n), dim3(256), 0, c->stream, C, ldc, A, lda, B, ldb, M, Nc,
                      K, 1, 0, 0, (const int*)tm.dev, tm.n);
+}
+
+// Column-major task list of the dataflow factorisation (Mt tile columns, Rt >= Mt tile rows), cached per shape.
+const TileMap& get_tile_tasks(gpg_ctx* c, int Mt, int Rt) {
+  const unsigned long long key = (1ull << 63) | ((unsigned long long)Mt << 20) | (unsigned)Rt;
+  auto it = c->tilemaps.find(key);
+  if (it != c->tilemaps.end()) return it->second;
+  std::vector<int> list;
+  for (int j = 0; j < Mt; ++j)
+    for (int i = j; i < Rt; ++i) list.push_back(i | (j << 16));
+  TileMap tm;
+  tm.n = (int)list.size();
+  tm.dev = nullptr;
+  (void)hipMalloc(&tm.dev, sizeof(int) * list.size());
+  (void)hipMemcpy(tm.dev, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice);
+  return c->tilemaps.emplace(key, tm).first->second;
+}
+
+// Factor A[c0:, c0:] (and carry the rows below the matrix) with the dataflow kernel, on c->stream.
+static void launch_tile_chol(gpg_ctx* c, int c0) {
+  const int Mt = (c->Npad - c0) / 64, Rt = (c->ld - c0) / 64;
+  if (Mt <= 0) return;
+  const TileMap& tm = get_tile_tasks(c, Mt, Rt);
+  const size_t nflag = (size_t)Mt * Rt + 1;
+  if (c->tile_flags_cap < nflag) {
+    if (c->tile_flags) (void)hipFree(c->tile_flags);
+    (void)hipMalloc(&c->tile_flags, sizeof(int) * nflag);
+    c->tile_flags_cap = nflag;
+  }
+  (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
+  const double m = (double)(c->Npad - c0);
+  gpg_prof_begin(c, GPG_PROF_POTRF, m * m * m / 3.0);
+  hipLaunchKernelGGL(tile_chol_kernel, dim3(tm.n), dim3(256), 0, c->stream, c->A, c->ld, c0, Mt, (const int*)tm.dev,
+                     c->tile_flags, c->tile_flags + (nflag - 1), c->dinv, c->info, c->N);
+  gpg_prof_end(c);
+}
+
+// The whole matrix with the 128-tile dataflow kernel, on c->stream.
+static void launch_tile128_chol(gpg_ctx* c) {
+  const int Mt = c->Npad / 128, Rt = c->ld / 128;
+  const TileMap& tm = get_tile_tasks(c, Mt, Rt);
+  const size_t nflag = (size_t)Mt * Rt + 1;
+  if (c->tile_flags_cap < nflag) {
+    if (c->tile_flags) (void)hipFree(c->tile_flags);
+    (void)hipMalloc(&c->tile_flags, sizeof(int) * nflag);
+    c->tile_flags_cap = nflag;
+  }
+  (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
+  const double m = (double)c->Npad;
+  gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, m * m * m / 3.0);
+  hipLaunchKernelGGL(tile128_chol_kernel, dim3(tm.n), dim3(256), 0, c->stream, c->A, c->ld, Mt, (const int*)tm.dev,
+                     c->tile_flags, c->tile_flags + (nflag - 1), c->dinv, c->info, c->N);
+  gpg_prof_end(c);
 }
 
 }  // namespace
@@ -778,6 +1557,14 @@ void gpg_cholesky(gpg_ctx* c) {
   }
   // D_0 follows the assembly on the main stream
   c->stream = sM;
+  if (c->tail_cols > 0 && Npad <= c->tail_cols) {   // small matrix: the dataflow kernel does all of it
+    launch_tile_chol(c, 0);
+    return;
+  }
+  if (c->chol_impl == 1) {
+    launch_tile128_chol(c);
+    return;
+  }
   factor_diag_block(c, 0, kb[1]);
   for (int p = 0; p < npanel; ++p) {
     const int k0 = kb[p], k1 = kb[p + 1];                           // panel p = columns [k0, k1)
@@ -785,6 +1572,16 @@ void gpg_cholesky(gpg_ctx* c) {
     if (two && p > 0) (void)hipStreamWaitEvent(sM, c->ev_panel[p], 0);
     solve_below_block(c, k0, k1);                                   // B_p (also carries the RHS rows)
     if (k1 >= Npad) break;
+    if (c->tail_cols > 0 && Npad - k1 <= c->tail_cols) {
+      // the rest is latency-bound: apply panel p to all of it, then hand over to the dataflow kernel
+      const double nt = (double)(Npad - k1);
+      gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, nt * (nt + 1.0) * (double)(k1 - k0));
+      launch_gemm_trailing(c, A + (size_t)k1 + (size_t)k1 * ld, ld, A + (size_t)k0 * ld + k1, ld, A + (size_t)k0 * ld + k1, ld,
+                           ld - k1, Npad - k1, k1 - k0, 0);
+      gpg_prof_end(c);
+      launch_tile_chol(c, k1);
+      break;
+    }
     const int k2 = kb[p + 2];                                       // next diagonal block = [k1, k2)
     const int K = k1 - k0;
     const double* Ap = A + (size_t)k0 * ld;
@@ -823,14 +1620,18 @@ void gpg_forward_rows(gpg_ctx* c, double* W, int ldw, int rows) {
   for (int k0 = 0; k0 < Npad; k0 += NB) {
     const int nbw = (Npad - k0) < NB ? (Npad - k0) : NB;
     const int k1 = k0 + nbw;
-    for (int j0 = k0; j0 < k1; j0 += GPG_NBI) {
-      const int j1 = j0 + GPG_NBI;
-      hipLaunchKernelGGL(trsm64_kernel, dim3((rows + 63) / 64), dim3(256), 0, c->stream,
-                         A + (size_t)j0 + (size_t)j0 * ld, ld, c->dinv + j0, W + (size_t)j0 * ldw, ldw, rows);
-      const int ncols = k1 - j1;
-      if (ncols > 0)
-        launch_gemm<128, 64>(c, W + (size_t)j1 * ldw, ldw, W + (size_t)j0 * ldw, ldw,
-                             A + (size_t)j1 + (size_t)j0 * ld, ld, rows, ncols, GPG_NBI, 0);
+    if (c->panel_impl == 1) {
+      launch_panel_solve(c, A + (size_t)k0 + (size_t)k0 * ld, ld, c->dinv + k0, W + (size_t)k0 * ldw, ldw, rows, nbw);
+    } else {
+      for (int j0 = k0; j0 < k1; j0 += GPG_NBI) {
+        const int j1 = j0 + GPG_NBI;
+        hipLaunchKernelGGL(trsm64_kernel, dim3((rows + 63) / 64), dim3(256), 0, c->stream,
+                           A + (size_t)j0 + (size_t)j0 * ld, ld, c->dinv + j0, W + (size_t)j0 * ldw, ldw, rows);
+        const int ncols = k1 - j1;
+        if (ncols > 0)
+          launch_gemm<128, 64>(c, W + (size_t)j1 * ldw, ldw, W + (size_t)j0 * ldw, ldw,
+                               A + (size_t)j1 + (size_t)j0 * ld, ld, rows, ncols, GPG_NBI, 0);
+      }
     }
     if (k1 < Npad)
       launch_gemm<128, 128>(c, W + (size_t)k1 * ldw, ldw, W + (size_t)k0 * ldw, ldw, A + (size_t)k1 + (size_t)k0 * ld,
@@ -851,14 +1652,18 @@ void gpg_inverse_from_factor(gpg_ctx* c, double* W, double* Minv) {
   (void)hipMemsetAsync(Minv, 0, sizeof(double) * (size_t)ldw * Npad, c->stream);
   for (int k0 = 0; k0 < Npad; k0 += NB) {
     const int k1 = (k0 + NB < Npad) ? k0 + NB : Npad;
-    for (int j0 = k0; j0 < k1; j0 += GPG_NBI) {
-      const int j1 = j0 + GPG_NBI;
-      hipLaunchKernelGGL(trsm64_kernel, dim3(j1 / 64), dim3(256), 0, c->stream, A + (size_t)j0 + (size_t)j0 * ld, ld,
-                         c->dinv + j0, W + (size_t)j0 * ldw, ldw, j1);
-      const int ncols = k1 - j1;
-      if (ncols > 0)
-        launch_gemm<128, 64>(c, W + (size_t)j1 * ldw, ldw, W + (size_t)j0 * ldw, ldw, A + (size_t)j1 + (size_t)j0 * ld, ld,
-                             j1, ncols, GPG_NBI, 0);
+    if (c->panel_impl == 1) {   // rows [j1, k1) of a column block are still zero when it is solved: harmless extra rows
+      launch_panel_solve(c, A + (size_t)k0 + (size_t)k0 * ld, ld, c->dinv + k0, W + (size_t)k0 * ldw, ldw, k1, k1 - k0);
+    } else {
+      for (int j0 = k0; j0 < k1; j0 += GPG_NBI) {
+        const int j1 = j0 + GPG_NBI;
+        hipLaunchKernelGGL(trsm64_kernel, dim3(j1 / 64), dim3(256), 0, c->stream, A + (size_t)j0 + (size_t)j0 * ld, ld,
+                           c->dinv + j0, W + (size_t)j0 * ldw, ldw, j1);
+        const int ncols = k1 - j1;
+        if (ncols > 0)
+          launch_gemm<128, 64>(c, W + (size_t)j1 * ldw, ldw, W + (size_t)j0 * ldw, ldw, A + (size_t)j1 + (size_t)j0 * ld, ld,
+                               j1, ncols, GPG_NBI, 0);
+      }
     }
     if (k1 < Npad)
       launch_gemm<128, 128>(c, W + (size_t)k1 * ldw, ldw, W + (size_t)k0 * ldw, ldw, A + (size_t)k1 + (size_t)k0 * ld, ld,

@@ -9,6 +9,7 @@
 #define GPG_MAX_DIM 16
 #define GPG_TILE 128      // padding / GEMM tile granularity
 #define GPG_NBI 64        // inner (diagonal block) width of the panel factorisation
+#define GPG_INFO_INTERNAL 0x7fffffff   // info value: dataflow factorisation aborted (dependency wait timed out)
 #define GPG_RHS_ROWS 128  // right-hand-side rows appended below the matrix (ride along the Cholesky)
 
 // Arguments of the fused assembly kernels (passed by value -> SGPRs / kernarg segment).
@@ -42,6 +43,10 @@ struct gpg_ctx {
   size_t A_elems = 0;        // allocated size of A (doubles), sized for all gradients
   int panel_impl = 1;                // 1: fused panel_solve_kernel for B_p, 0: trsm64 + small gemm launches (A/B runs)
   int nb_outer = 256;   // panel width
+  int chol_impl = 0;    // 1: whole factorisation by the 128-tile dataflow kernel
+  int tail_cols = 0;    // trailing block of at most this many columns goes to the dataflow tile kernel (0: off)
+  int* tile_flags = nullptr;   // device: completion flags of the dataflow kernel + abort word
+  size_t tile_flags_cap = 0;
   int nb_big = 0;       // wide-panel width used while at least big_rows columns remain (0: off)
   int big_rows = 0;
   // device buffers

@@ -9,7 +9,7 @@ void gpg_launch_identity(gpg_ctx*, double*, int) {}
 int main(int argc, char** argv) {
   int Nt = argc > 1 ? atoi(argv[1]) : 16384, K = argc > 2 ? atoi(argv[2]) : 256, impl = argc > 3 ? atoi(argv[3]) : 1;
   gpg_ctx c;
-  c.gemm_impl = impl & 1;
+  c.gemm_impl = impl;
   hipStreamCreate(&c.stream);
   int ld = Nt + 128;
   double *C, *P;
