@@ -110,7 +110,9 @@ def main():
     ap.add_argument("--n", type=int, default=0)
     ap.add_argument("--d", type=int, default=0)
     ap.add_argument("--panel", type=int, default=0, help="panel width override")
-    ap.add_argument("--lookahead", type=int, default=-1, help="1/0 force the two-stream look-ahead on/off")
+    ap.add_argument("--lookahead", type=int, default=-1, help="1/0 force the two-stream look-ahead on/off (blocked schedule)")
+    ap.add_argument("--factor-mode", default="auto", choices=["auto", "blocked", "tile64", "tile128"],
+                    help="Cholesky schedule (include/gpgrad.h gpg_factor_mode); default: one dataflow launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-all", action="store_true", help="time every kernel category (adds event overhead)")
     args = ap.parse_args()
@@ -156,6 +158,14 @@ def main():
         GP.set_panel(args.panel)
     if args.lookahead >= 0:
         GP.set_lookahead(args.lookahead)
+    GP.set_factor_mode(args.factor_mode)
+    Npad = -(-N // 128) * 128
+    if args.factor_mode == "blocked":
+        dom_kernel = "gemm_dma_kernel<4> (trailing update C -= A_p A_p^T of the blocked schedule, 128x128 tiles)"
+    elif args.factor_mode == "tile64" or (args.factor_mode == "auto" and Npad <= 6144):
+        dom_kernel = "tile_chol_kernel (whole Cholesky as one dataflow launch, 64x64 tiles, left-looking)"
+    else:
+        dom_kernel = "tile128_chol_kernel (whole Cholesky as one dataflow launch, 128x128 tiles, left-looking)"
 
     # rank r owns rows [8r, 8r+8) of the 64-row table (BASELINE cfg4), cycled when steps > 8
     def rows_for(k):
@@ -209,10 +219,10 @@ def main():
                                    "(rows of the BASELINE.md section 3 restart table, 8 per rank)",
                        "n": n, "d": d, "N": N, "kernel": kernel, "wellcond": "precon",
                        "evals_per_gpu": args.steps, "parallelism": f"restarts sharded over {world} rank(s), one all_gather ({backend if world > 1 else 'none'})"},
-            "roofline": {"bound": "mfma", "kernel": "gemm_dma_kernel<4> (Cholesky trailing update C -= A_p A_p^T, 128x128 tiles)",
+            "roofline": {"bound": "mfma", "kernel": dom_kernel,
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                         "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH_CFG3 if (n, d, args.config) == (2000, 8, "cfg3") else None,
+                         "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH_CFG3 if (n, d, args.config, args.factor_mode) == (2000, 8, "cfg3", "auto") else None,
                          "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_pmc_summary.txt)",
                          "launches": tr["count"], "avg_launch_ms": tr["ms"] / max(1, tr["count"]),
                          "algorithmic_flops": tr["work"],

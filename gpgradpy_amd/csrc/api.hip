@@ -132,10 +132,6 @@ int gpg_create(gpg_ctx** out, int device, int n_eval, int dim, int use_grad, int
   // matrices (shorter dependency chain), 128-tile kernel above; chol_impl 0 = blocked right-looking (A/B runs)
   c->chol_impl = 1;
   c->tail_cols = 6144;
-  if (const char* e = getenv("GPG_CHOL_IMPL")) c->chol_impl = atoi(e);
-  if (const char* e = getenv("GPG_TAIL_COLS")) c->tail_cols = atoi(e);
-  if (const char* e = getenv("GPG_NB_BIG")) c->nb_big = atoi(e);       // tuning knobs for measurements
-  if (const char* e = getenv("GPG_BIG_ROWS")) c->big_rows = atoi(e);
 #define CREATE_OK(call)                                                              \
   do {                                                                               \
     hipError_t e_ = (call);                                                          \
@@ -488,6 +484,18 @@ int gpg_prof_read(gpg_ctx* c, double ms[GPG_PROF_NCAT], long long count[GPG_PROF
     c->prof_pool.push_back({pe.e0, pe.e1});
   }
   c->prof_pending.clear();
+  return 0;
+}
+
+int gpg_set_factor_mode(gpg_ctx* c, int mode) {
+  if (!c) return -1;
+  switch (mode) {
+    case GPG_FACTOR_AUTO:    c->chol_impl = 1; c->tail_cols = 6144; break;
+    case GPG_FACTOR_BLOCKED: c->chol_impl = 0; c->tail_cols = 0; break;
+    case GPG_FACTOR_TILE64:  c->chol_impl = 0; c->tail_cols = 1 << 30; break;
+    case GPG_FACTOR_TILE128: c->chol_impl = 1; c->tail_cols = 0; break;
+    default: c->err = "unknown factor mode"; return -1;
+  }
   return 0;
 }
 

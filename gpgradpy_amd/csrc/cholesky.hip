@@ -1442,7 +1442,7 @@ static void launch_tile_chol(gpg_ctx* c, int c0) {
   }
   (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
   const double m = (double)(c->Npad - c0);
-  gpg_prof_begin(c, GPG_PROF_POTRF, m * m * m / 3.0);
+  gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, m * m * m / 3.0);
   hipLaunchKernelGGL(tile_chol_kernel, dim3(tm.n), dim3(256), 0, c->stream, c->A, c->ld, c0, Mt, (const int*)tm.dev,
                      c->tile_flags, c->tile_flags + (nflag - 1), c->dinv, c->info, c->N);
   gpg_prof_end(c);

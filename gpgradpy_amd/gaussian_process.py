@@ -646,6 +646,15 @@ class GaussianProcess:
     def set_lookahead(self, on):
         self._lib.gpg_set_lookahead(self._ctx, int(on))
 
+    FACTOR_MODES = {'auto': 0, 'blocked': 1, 'tile64': 2, 'tile128': 3}
+
+    def set_factor_mode(self, mode):
+        """Factorisation schedule of the device Cholesky (include/gpgrad.h: gpg_factor_mode): 'auto' (default,
+        one dataflow launch), 'blocked' (right-looking panels), 'tile64' / 'tile128' (force one dataflow kernel)."""
+        rc = self._lib.gpg_set_factor_mode(self._ctx, self.FACTOR_MODES[mode] if isinstance(mode, str) else int(mode))
+        if rc != 0:
+            raise _lib.GpgError(f'gpg_set_factor_mode failed ({rc}): {self._err()}')
+
     def download_chofac(self):
         """(P L, True) of the factor currently on the device (Kernel.py:252) as a SciPy cho_factor pair."""
         fac = np.empty((self.n_data, self.n_data))

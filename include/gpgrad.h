@@ -141,7 +141,8 @@ enum {
   GPG_PROF_POTRF = 1,      /* diagonal-block factorisations                                         */
   GPG_PROF_TRSM = 2,       /* panel triangular solves                                               */
   GPG_PROF_GEMM_PANEL = 3, /* updates inside a panel                                                */
-  GPG_PROF_GEMM_TRAIL = 4, /* trailing syrk/gemm update on fp64 MFMA: algorithmic flops             */
+  GPG_PROF_GEMM_TRAIL = 4, /* fp64 MFMA factorisation kernel (dataflow Cholesky launch, or the trailing
+                            * update of the blocked schedule): algorithmic flops                      */
   GPG_PROF_REDUCE = 5,     /* log-det / GLS reductions                                              */
   GPG_PROF_NCAT = 6
 };
@@ -158,6 +159,13 @@ int gpg_set_panel(gpg_ctx* ctx, int nb_outer);
  * high-priority stream under the trailing update); 0: single stream.  bit 1 = 1: register-staged
  * 128x128 update kernel instead of the LDS-DMA one (A/B measurements only). */
 int gpg_set_lookahead(gpg_ctx* ctx, int on);
+
+/* Factorisation schedule.  GPG_FACTOR_AUTO (default): one dataflow launch -- the 64 x 64-tile kernel up to
+ * 6144 padded columns, the 128 x 128-tile kernel above.  GPG_FACTOR_BLOCKED: right-looking blocked
+ * algorithm (panel solve + trailing update per panel, look-ahead on a second stream; A/B measurements and
+ * the reference point for the parity tests).  GPG_FACTOR_TILE64 / GPG_FACTOR_TILE128 force one kernel. */
+enum gpg_factor_mode { GPG_FACTOR_AUTO = 0, GPG_FACTOR_BLOCKED = 1, GPG_FACTOR_TILE64 = 2, GPG_FACTOR_TILE128 = 3 };
+int gpg_set_factor_mode(gpg_ctx* ctx, int mode);
 
 /* Library / device facts for logs: writes "gfx950 MI355X ..." style text. */
 int gpg_device_info(int device, char* buf, int buflen);

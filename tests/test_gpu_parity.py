@@ -154,10 +154,12 @@ def test_multistart_tables(name, noisy, kernel):
     assert idx2 == idx and np.allclose(ln2, ln, rtol=1e-12, equal_nan=True)
 
 
+@pytest.mark.parametrize("mode", ["auto", "blocked", "tile128"])
 @pytest.mark.parametrize("kernel,noise,n,d,panel", [("SqExp", "none", 300, 8, 256), ("Ma5f2", "known", 260, 7, 128),
                                                     ("SqExp", "unknown", 500, 4, 256), ("Ma5f2", "none", 150, 16, 512)])
-def test_against_oracle_multi_panel(kernel, noise, n, d, panel):
-    """Sizes spanning several outer panels, ragged tiles and every kernel template; oracle finishes in seconds."""
+def test_against_oracle_multi_panel(kernel, noise, n, d, panel, mode):
+    """Sizes spanning several outer panels / tile columns, ragged tiles and every kernel template, under each
+    factorisation schedule (auto = 64-tile dataflow kernel at these sizes); oracle finishes in seconds."""
     import gpgradpy_amd
     from oracle import gp_oracle as orc
     rng = np.random.default_rng(n + d)
@@ -176,6 +178,7 @@ def test_against_oracle_multi_panel(kernel, noise, n, d, panel):
     GP = gpgradpy_amd.GaussianProcess(d, True, kernel, 'precon')
     GP.set_data(X, f, std_f, g, std_g)
     GP.set_panel(panel)
+    GP.set_factor_mode(mode)
     hp = GP.make_hp_class(theta=theta, varK=varK, var_fval=vf, var_fgrad=vg)
     info, ok = GP.calc_lkd_all(hp)
     y = orc.make_data_vec(f, g)
@@ -224,6 +227,33 @@ def test_against_oracle_multi_panel(kernel, noise, n, d, panel):
         xm[k] -= eps
         fd[k] = (GP.eval_model(xp[None, :])[0][0] - GP.eval_model(xm[None, :])[0][0]) / (2 * eps)
     np.testing.assert_allclose(dmudx[0], fd, rtol=1e-4, atol=1e-6 * np.abs(fd).max())
+
+
+def test_factor_modes_agree_and_fail_alike():
+    """The four factorisation schedules give the same likelihood (to rounding x kappa) on a matrix of 22 tile
+    columns, and every one reports a non-positive pivot the way LAPACK does (Kernel.py:253-264 branch)."""
+    import gpgradpy_amd
+    from oracle import gp_oracle as orc
+    n, d = 310, 8
+    X, f, g = orc.synthetic_design(n, d, seed=3)
+    theta = 10.0 ** np.random.default_rng(5).uniform(-2.0, -0.5, d)
+    out = {}
+    for mode in ("auto", "blocked", "tile64", "tile128"):
+        GP = gpgradpy_amd.GaussianProcess(d, True, 'SqExp', 'precon')
+        GP.set_data(X, f, np.zeros(n), g, np.zeros((n, d)))
+        GP.set_factor_mode(mode)
+        info, ok = GP.calc_lkd_all(GP.make_hp_class(theta=theta))
+        assert ok
+        out[mode] = (info.ln_lkd, info.ln_det_Kmat, info.hp_varK, info.hp_beta[0])
+        # not positive definite: negative nugget on a near-singular matrix
+        GP._etaK = GP._eta_Kgrad = -0.5
+        info_bad, ok_bad = GP.calc_lkd_all(GP.make_hp_class(theta=theta * 1e-3))
+        assert not ok_bad
+    ref = out["blocked"]
+    for mode, v in out.items():
+        assert abs(v[0] - ref[0]) <= 1e-9 * abs(ref[0]), (mode, v, ref)
+        assert abs(v[1] - ref[1]) <= 1e-9 * n * (d + 1)
+        assert np.isclose(v[2], ref[2], rtol=1e-8) and np.isclose(v[3], ref[3], rtol=1e-8)
 
 
 def test_gradient_free_base():
