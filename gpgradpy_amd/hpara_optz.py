@@ -1,0 +1,277 @@
+"""Hyperparameter optimisation on top of the device likelihood.
+
+Host-side mirror of the reference's optimisation driver for the accelerated path:
+
+* history of the optimised hyperparameters        -- base/GpParaDef.py:20-65 (init), :219-284 (store)
+* start points + box constraints around the median of the recent history
+                                                  -- optz/GpHparaX0.py:16-65, :67-193
+* objective / gradient with the log10 chain rule   -- optz/OptzLkd.py:15-100
+* SLSQP multi-start and selection of the best run  -- optz/OptzLkd.py:185-333
+* `optz_hp` / `get_init_hp_vals`                    -- optz/GpHparaOptz.py:140-218
+
+Every likelihood value and gradient comes from the device (`calc_lkd_all` -> `gpg_lkd` / `gpg_lkd_grad`); the
+`hp_best` pre-selection (40 value-only evaluations in the reference's loop, GpHparaX0.py:39-45) is ONE
+`gpg_lkd_batch` call, sharded over ranks when `torch.distributed` is initialised.
+
+Differences from the reference, all outside the accelerated path: the condition-number constraint
+(`b_use_cond_cstr`, optz/GpHparaCon.py) and the final SVD condition number are not computed (`cond_val` is NaN);
+the rescale well-conditioning methods are not available; the Latin-hypercube source is SciPy's
+(`scipy.stats.qmc.LatinHypercube`, seed 1) because `smt` is not installed here -- its sample sequence differs
+from smt's, the bounds and everything downstream are the reference's.
+"""
+import time
+
+import numpy as np
+from scipy.optimize import Bounds, minimize
+
+
+def lhs_sample(xlimits, n, seed=1):
+    """n Latin-hypercube points inside xlimits[:, 0] .. xlimits[:, 1] (stand-in for smt.sampling_methods.LHS
+    with random_state=1, GpHparaX0.py:188-190)."""
+    from scipy.stats import qmc
+    xlimits = np.asarray(xlimits, dtype=float)
+    u = qmc.LatinHypercube(d=xlimits.shape[0], seed=seed).random(n)
+    return xlimits[:, 0] + u * (xlimits[:, 1] - xlimits[:, 0])
+
+
+class HparaOptz:
+    """Mixin for `gpgradpy_amd.GaussianProcess`."""
+
+    # ---- options (reference GaussianProcess.py:33-83) ---------------------------------------------------------
+    optz_mtd = 'SLSQP'
+    optz_n_x0 = 5
+    optz_iter_max = 250
+    optz_tol_obj = 1e-12
+    optz_tol_x = 1e-12
+    hp_const_n_eval = 1
+    hp_lhs_bound_factor = 1e3
+    hp_box_bound_factor = 1e5
+    hp_median_n_idx = 5
+    hp_theta_range = [1e-18, 1e24]
+    hp_varK_range = [1e-24, 1e14]
+    hp_var_fval_range = [1e-8, 1e8]
+    hp_var_fgrad_range = [1e-8, 1e8]
+    b_use_cond_cstr = False
+    _save_data = False
+    _lkd_val = _lkd_grad = None
+
+    # ---- history (GpParaDef.py:20-65, 67-113, 219-284) -----------------------------------------------------------
+    _HIST_1D = ('hp_varK_all', 'hp_var_fval_all', 'hp_var_fgrad_all', 'hp_kernel_all', 'min_nugget_all', 'Kcov_cond_all',
+                'eta_Kbase_all', 'eta_Kgrad_all', 'hp_optz_success', 'hp_optz_iter_mean', 'hp_optz_iter_max',
+                'hp_optz_con_good', 'optz_n_cho_fail_all', 'optz_n_cond2big_all', 'optz_max_init_cond_all',
+                'time_pick_hp0_all', 'time_hp_optz_all', 'time_chofac_all', 'var_fval', 'varK_var_fval')
+
+    def init_optz_surr(self, n_optz_max):
+        self._save_data = True
+        self.n_optz_max = n_optz_max
+        self.hp_beta_all = np.full((n_optz_max, self.n_beta_coeff), np.nan)
+        self.hp_theta_all = np.full((n_optz_max, self.dim), np.nan)
+        for name in self._HIST_1D:
+            setattr(self, name, np.full(n_optz_max, np.nan))
+        self.Kcov_cond_at_max_all = np.full(n_optz_max, False, dtype=bool)
+
+    def finish_optz_surr(self, n_optz_final):
+        assert self._save_data, 'If the method init_optz_surr has not been called, then finish_optz_surr cannot be used'
+        idx = n_optz_final
+        self.hp_beta_all = self.hp_beta_all[:idx, :]
+        self.hp_theta_all = self.hp_theta_all[:idx, :]
+        for name in self._HIST_1D + ('Kcov_cond_at_max_all',):
+            setattr(self, name, getattr(self, name)[:idx])
+
+    def store_new_para_surr(self, i_optz, hp_vals, surr_optz_info=None, cond_val=np.nan, time_hp_optz=np.nan,
+                            time_chofac=np.nan, time_pick_hp0=np.nan):
+        self.hp_vals = hp_vals
+        if self._save_data is False:
+            return
+        idx = i_optz
+        self.time_hp_optz_all[idx] = time_hp_optz
+        self.time_chofac_all[idx] = time_chofac
+        self.time_pick_hp0_all[idx] = time_pick_hp0
+        self.hp_beta_all[idx, :] = hp_vals.beta
+        self.hp_theta_all[idx, :] = hp_vals.theta
+        self.hp_kernel_all[idx] = np.nan if hp_vals.kernel is None else hp_vals.kernel
+        self.hp_varK_all[idx] = np.nan if hp_vals.varK is None else hp_vals.varK
+        self.hp_var_fval_all[idx] = np.nan if hp_vals.var_fval is None else hp_vals.var_fval
+        self.hp_var_fgrad_all[idx] = np.nan if hp_vals.var_fgrad is None else hp_vals.var_fgrad
+        self.min_nugget_all[idx] = self._eta_Kgrad if self.use_grad else self._eta_Kbase
+        self.Kcov_cond_all[idx] = cond_val
+        self.Kcov_cond_at_max_all[idx] = cond_val >= (0.99 * self.cond_max)
+        self.eta_Kbase_all[idx] = self._eta_Kbase
+        self.eta_Kgrad_all[idx] = self._eta_Kgrad
+        if surr_optz_info is not None:
+            for key in ('hp_optz_success', 'hp_optz_iter_mean', 'hp_optz_iter_max', 'hp_optz_con_good'):
+                if key in surr_optz_info:
+                    getattr(self, key)[idx] = surr_optz_info[key]
+            self.optz_n_cho_fail_all[idx] = surr_optz_info['optz_n_cho_fail']
+            self.optz_n_cond2big_all[idx] = surr_optz_info['optz_n_cond2big']
+            self.optz_max_init_cond_all[idx] = surr_optz_info['optz_max_init_cond']
+        self.var_fval[idx] = np.var(self._fval_in)
+        if self.var_fval[idx] > 0:
+            self.varK_var_fval[idx] = self.hp_varK_all[idx] / self.var_fval[idx]
+
+    def set_hp_from_idx(self, i_optz):
+        # GpHpara.py:33-54
+        assert self._save_data, 'no stored hyperparameters: call init_optz_surr first'
+        if np.isnan(self.hp_var_fval_all[i_optz]):
+            self.known_eps_fval, hp_var_fval = True, None
+        else:
+            self.known_eps_fval, hp_var_fval = False, self.hp_var_fval_all[i_optz]
+        if np.isnan(self.hp_var_fgrad_all[i_optz]):
+            self.known_eps_fgrad, hp_var_fgrad = True, None
+        else:
+            self.known_eps_fgrad, hp_var_fgrad = False, self.hp_var_fgrad_all[i_optz]
+        kern = None if np.isnan(self.hp_kernel_all[i_optz]) else self.hp_kernel_all[i_optz]
+        self.hp_vals = self.make_hp_class(self.hp_beta_all[i_optz, :], self.hp_theta_all[i_optz, :], kern,
+                                          self.hp_varK_all[i_optz], hp_var_fval, hp_var_fgrad)
+
+    # ---- start points and bounds (GpHparaX0.py) ------------------------------------------------------------------
+    def get_hp_x0_lhs_median(self, i_optz, hp_optz_info, n_x0):
+        idx_min = int(np.max((0, i_optz - self.hp_median_n_idx)))
+        idx_max = i_optz
+        lhs_factor, box_factor = self.hp_lhs_bound_factor, self.hp_box_bound_factor
+        n_hp = hp_optz_info.n_hp
+        lhs_lb, lhs_ub = np.full(n_hp, np.nan), np.full(n_hp, np.nan)
+        box_lb, box_ub = np.full(n_hp, np.nan), np.full(n_hp, np.nan)
+
+        def fill(idx, med, rng):
+            med = np.minimum(np.maximum(med, rng[0]), rng[1])
+            lhs_lb[idx] = np.maximum(med / lhs_factor, rng[0])
+            lhs_ub[idx] = np.minimum(med * lhs_factor, rng[1])
+            box_lb[idx] = np.maximum(med / box_factor, rng[0])
+            box_ub[idx] = np.minimum(med * box_factor, rng[1])
+
+        if hp_optz_info.has_theta:
+            fill(hp_optz_info.idx_theta, np.median(self.hp_theta_all[idx_min:idx_max, :], axis=0), self.hp_theta_range)
+        if hp_optz_info.has_kernel:
+            raise NotImplementedError('kernels with their own hyperparameter are outside the accelerated path')
+        if hp_optz_info.has_varK:
+            fill(hp_optz_info.idx_varK, np.median(self.hp_varK_all[idx_min:idx_max]), self.hp_varK_range)
+        if hp_optz_info.has_var_fval:
+            med = np.max((self.hp_var_fval_range[0], np.median(self.hp_var_fval_all[idx_min:idx_max])))
+            fill(hp_optz_info.idx_var_fval, med, self.hp_var_fval_range)
+        if hp_optz_info.has_var_fgrad:
+            med = np.max((self.hp_var_fgrad_range[0], np.median(self.hp_var_fgrad_all[idx_min:idx_max])))
+            fill(hp_optz_info.idx_var_fgrad, med, self.hp_var_fgrad_range)
+
+        bvec = hp_optz_info.bvec_log_optz
+        for v in (lhs_lb, lhs_ub, box_lb, box_ub):
+            v[bvec] = np.log10(v[bvec])
+        if np.any(lhs_lb > lhs_ub) or np.any(np.isnan(lhs_lb)):
+            raise Exception(f'Invalid bounds for lhs: lhs_lb = {lhs_lb}, lhs_ub = {lhs_ub}')
+        if np.any(box_lb > box_ub):
+            raise Exception(f'Invalid bounds for box: box_lb = {box_lb}, box_ub = {box_ub}')
+        hp_optz_bounds = Bounds(box_lb, box_ub, keep_feasible=True)
+        if lhs_lb.size == 1:
+            hp_x0 = np.linspace(lhs_lb[0], lhs_ub[0], n_x0 + 2)[1:-1, None]      # no nodes at the boundaries
+        else:
+            hp_x0 = lhs_sample(np.array([lhs_lb, lhs_ub]).T, n_x0, seed=1)
+        return hp_x0, hp_optz_bounds
+
+    def select_hp_optz_x0(self, i_optz, hp_optz_info):
+        start_time = time.time()
+        if self.lkd_optz_start_mtd == 'lhs':
+            n_x0 = self.optz_n_x0
+        elif self.lkd_optz_start_mtd == 'hp_best':
+            n_x0 = self.lkd_hp_best_n_eval
+        else:
+            raise Exception(f'Unknown lkd_optz_start_mtd: {self.lkd_optz_start_mtd}')
+        hp_x0, optz_bound = self.get_hp_x0_lhs_median(i_optz, hp_optz_info, n_x0)
+        if self.lkd_optz_start_mtd == 'hp_best':
+            if self.wellcond_mtd != 'precon':
+                raise NotImplementedError("lkd_optz_start_mtd = 'hp_best' needs the condition number unless wellcond_mtd = 'precon'")
+            # the reference's loop over calc_lkd_all (GpHparaX0.py:39-45) = one batched device call, sharded
+            # over ranks when torch.distributed is up; failed factorisations are NaN and drop out of nanargmax
+            from .multistart import select_best_restart
+            hp_x0 = select_best_restart(hp_x0, self.calc_lkd_batch)[0]
+        return hp_x0, optz_bound, time.time() - start_time
+
+    # ---- objective (OptzLkd.py:15-100) ------------------------------------------------------------------------
+    def calc_store_likelihood(self, hp_vec, always_calc_cond=False, calc_grad=True):
+        hp_vec = np.atleast_1d(hp_vec).ravel()
+        if not np.array_equal(hp_vec, self._last_hp_vec):
+            if self.b_use_cond_cstr or always_calc_cond:
+                raise NotImplementedError('the condition-number constraint is outside the accelerated path')
+            hp_vals = self.hp_vec2dataclass(self.hp_info_optz_lkd, hp_vec)
+            lkd_info, b_chofac_good = self.calc_lkd_all(hp_vals, calc_lkd=True, calc_cond=False, calc_grad=calc_grad)
+            if b_chofac_good:
+                ln_lkd_val = lkd_info.ln_lkd
+                ln_lkd_grad = lkd_info.ln_lkd_grad
+                if calc_grad:
+                    bvec = self.hp_info_optz_lkd.bvec_log_optz
+                    ln_lkd_grad[bvec] *= 10 ** hp_vec[bvec] * np.log(10)       # log10 chain rule, OptzLkd.py:65-70
+            else:
+                # the reference falls back on minus the SVD condition number here (OptzLkd.py:74-77), which it
+                # only has when calc_cond is on; with 'precon' that is NaN / None: reproduce as NaN, zero slope
+                ln_lkd_val = np.nan
+                ln_lkd_grad = np.zeros(self.hp_info_optz_lkd.n_hp)
+            self._last_hp_vec = hp_vec.copy()
+            self._lkd_val, self._lkd_grad = ln_lkd_val, ln_lkd_grad
+        return self._lkd_val, self._lkd_grad, np.nan, None
+
+    def return_optz_val(self, hp_vec):
+        return -self.calc_store_likelihood(np.atleast_1d(hp_vec).ravel())[0]
+
+    def return_optz_grad(self, hp_vec):
+        return -self.calc_store_likelihood(np.atleast_1d(hp_vec).ravel())[1]
+
+    # ---- multi-start SLSQP (OptzLkd.py:185-333) ------------------------------------------------------------------
+    def optz_hp_max_lkd(self, hp_x0_all, optz_bound):
+        if self.optz_mtd == 'SLSQP':
+            optz_opt = {'ftol': self.optz_tol_obj, 'eps': self.optz_tol_x, 'maxiter': self.optz_iter_max, 'disp': False}
+        elif self.optz_mtd == 'trust-constr':
+            optz_opt = {'initial_tr_radius': 0.1, 'xtol': self.optz_tol_x, 'gtol': self.optz_tol_obj,
+                        'maxiter': self.optz_iter_max, 'disp': False}
+        else:
+            raise Exception(f'Unknown optz_mtd: {self.optz_mtd}')
+        hp_x0_all = np.atleast_2d(np.asarray(hp_x0_all, dtype=float))
+        n_optz = hp_x0_all.shape[0]
+        all_optz_success = np.full(n_optz, False, dtype=bool)
+        all_total_fun_iter = np.full(n_optz, np.nan)
+        optz_obj_all = np.full(n_optz, np.nan)
+        optz_sol_all = np.full((n_optz, self.hp_info_optz_lkd.n_hp), np.nan)
+        for i in range(n_optz):
+            x0_i = hp_x0_all[i, :]
+            self._last_hp_vec = np.full((1, x0_i.size), np.nan)
+            res = minimize(self.return_optz_val, x0_i, method=self.optz_mtd, jac=self.return_optz_grad,
+                           bounds=optz_bound, constraints=[], options=optz_opt)
+            optz_sol_all[i, :] = res.x
+            optz_obj_all[i] = res.fun
+            all_optz_success[i] = res.success
+            all_total_fun_iter[i] = res.nit
+            if not res.success:
+                print(f'Surr hpara optz: Con GOOD, Optimizer: {res.message}')
+        idx_min = np.nanargmin(optz_obj_all)
+        best_hp = optz_sol_all[idx_min, :]
+        surr_optz_info = {'hp_optz_success': np.mean(all_optz_success), 'hp_optz_iter_mean': np.mean(all_total_fun_iter),
+                          'hp_optz_iter_max': np.max(all_total_fun_iter), 'hp_optz_con_good': 1.0,
+                          'optz_n_cho_fail': 0, 'optz_n_cond2big': 0, 'optz_max_init_cond': np.nan}
+        self.optz_obj_all_last, self.optz_sol_all_last = optz_obj_all, optz_sol_all
+        return best_hp, np.nan, surr_optz_info
+
+    # ---- driver (GpHparaOptz.py:140-218) -------------------------------------------------------------------------
+    def get_init_hp_vals(self):
+        theta = self.hp_theta_init * np.ones(self.dim)
+        beta = np.zeros(self.n_beta_coeff)
+        if self.n_beta_coeff > 0:
+            beta[0] = np.mean(self._fval_in)
+        hp_var_fval = None if self.known_eps_fval else self.hp_var_fval_init
+        hp_var_fgrad = None if (self.use_grad is False) or self.known_eps_fgrad else self.hp_var_fgrad_init
+        return self.make_hp_class(beta, theta, self.hp_kernel_default, self.hp_varK_init, hp_var_fval, hp_var_fgrad)
+
+    def optz_hp(self, i_optz):
+        if 'rescale' in self.wellcond_mtd:
+            raise NotImplementedError('rescale well-conditioning methods are outside the accelerated path')
+        if self.n_eval <= self.hp_const_n_eval:
+            hp_vals = self.get_init_hp_vals()
+            surr_optz_info, cond_val = None, np.nan
+            time_hp_optz = time_chofac = time_pick_hp0 = 0
+        else:
+            self._time_chofac = 0
+            hp_x0, optz_bound, time_pick_hp0 = self.select_hp_optz_x0(i_optz, self.hp_info_optz_lkd)
+            start_time = time.time()
+            hp_optz, cond_val, surr_optz_info = self.optz_hp_max_lkd(hp_x0, optz_bound)
+            time_hp_optz = time.time() - start_time
+            time_chofac = self._time_chofac
+            hp_vals = self.hp_vec2dataclass(self.hp_info_optz_lkd, hp_optz)
+            hp_vals = self.optz_closed_form_hp(hp_vals)
+        self.store_new_para_surr(i_optz, hp_vals, surr_optz_info, cond_val, time_hp_optz, time_chofac, time_pick_hp0)

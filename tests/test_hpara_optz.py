@@ -1,0 +1,115 @@
+"""Hyperparameter-optimisation driver against vectors captured from the reference
+(tests/golden/gen_golden_optz.py; the reference's smt.LHS was stubbed with the same SciPy Latin hypercube the
+product uses, see that script's header).
+
+CPU part: start rows and box bounds from a stored history (pure host logic, no device).
+GPU part: the whole `set_hpara('optz', i)` flow -- start-row selection with one batched device call, SLSQP on the
+device likelihood + adjoint gradient, closed-form (beta, varK) at the optimum."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_DIR
+
+OPTZ_CASES = sorted(glob.glob(os.path.join(GOLDEN_DIR, "optz_*.npz")))
+
+
+def _load(path):
+    with np.load(path, allow_pickle=False) as z:
+        return {k: (z[k].item() if z[k].ndim == 0 else z[k]) for k in z.files}
+
+
+def _noise_args(c, ni):
+    if c["noise"] == "unknown":
+        return None, None
+    return c["std_f"][:ni], c["std_g"][:ni]
+
+
+def _new_gp(c):
+    import gpgradpy_amd
+    GP = gpgradpy_amd.GaussianProcess(int(c["d"]), True, str(c["kernel"]), "precon")
+    GP.lkd_optz_start_mtd = str(c["start_mtd"])
+    GP.lkd_hp_best_n_eval = int(c["n_best"])
+    GP.optz_n_x0 = 3
+    GP.init_optz_surr(int(c["n_hist"]) + 2)
+    return GP
+
+
+@pytest.mark.parametrize("path", OPTZ_CASES, ids=lambda p: os.path.basename(p)[:-4])
+def test_start_rows_and_bounds_from_history(path):
+    """get_hp_x0_lhs_median (GpHparaX0.py:67-193) given the reference's own history."""
+    import gpgradpy_amd
+    from gpgradpy_amd import _lib
+    c = _load(path)
+    GP = _new_gp(c)
+    n_best = int(c["n_best"]) if c["start_mtd"] == "hp_best" else 3
+    # history row 0 as the reference stored it (initial hyperparameters), then one row per iteration
+    for it in range(1, int(c["n_hist"]) + 1):
+        ni = int(c[f"it{it}_n"])
+        sf, sg = _noise_args(c, ni)
+        try:
+            GP.set_data(c["x"][:ni], c["f"][:ni], sf, c["g"][:ni], sg)
+        except _lib.GpgError:
+            pass                                               # CPU-only box: host state is complete
+        GP.hp_theta_all[0] = c["theta_hist0"]
+        GP.hp_varK_all[0] = c["varK_hist0"]
+        if c["noise"] == "unknown":
+            GP.hp_var_fval_all[0] = GP.hp_var_fval_init
+            GP.hp_var_fgrad_all[0] = GP.hp_var_fgrad_init
+        hp_x0, bounds = GP.get_hp_x0_lhs_median(it, GP.hp_info_optz_lkd, n_best)
+        np.testing.assert_allclose(bounds.lb, c[f"it{it}_box_lb"], rtol=1e-13)
+        np.testing.assert_allclose(bounds.ub, c[f"it{it}_box_ub"], rtol=1e-13)
+        np.testing.assert_allclose(hp_x0, c[f"it{it}_hp_x0_all"], rtol=1e-12, atol=1e-13)
+        # feed the reference's optimum of this iteration into the history for the next one
+        GP.hp_theta_all[it] = c[f"it{it}_theta"]
+        GP.hp_varK_all[it] = c[f"it{it}_varK"]
+        GP.hp_var_fval_all[it] = c[f"it{it}_var_fval"]
+        GP.hp_var_fgrad_all[it] = c[f"it{it}_var_fgrad"]
+
+
+def test_lhs_sample_is_a_latin_hypercube():
+    from gpgradpy_amd.hpara_optz import lhs_sample
+    lim = np.array([[-3.0, 1.0], [0.0, 10.0], [2.0, 2.5]])
+    s = lhs_sample(lim, 8, seed=1)
+    assert s.shape == (8, 3)
+    for k in range(3):
+        cells = np.floor((s[:, k] - lim[k, 0]) / (lim[k, 1] - lim[k, 0]) * 8).astype(int)
+        assert sorted(cells) == list(range(8))                # one point per stratum
+    np.testing.assert_array_equal(s, lhs_sample(lim, 8, seed=1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", OPTZ_CASES, ids=lambda p: os.path.basename(p)[:-4])
+def test_optz_hp_flow_matches_reference(path):
+    c = _load(path)
+    GP = _new_gp(c)
+    sf, sg = _noise_args(c, 1)
+    GP.set_data(c["x"][:1], c["f"][:1], sf, c["g"][:1], sg)
+    GP.set_hpara('optz', 0)                                    # n_eval <= hp_const_n_eval: initial hyperparameters
+    np.testing.assert_allclose(GP.hp_theta_all[0], c["theta_hist0"], rtol=1e-14)
+    for it in range(1, int(c["n_hist"]) + 1):
+        ni = int(c[f"it{it}_n"])
+        sf, sg = _noise_args(c, ni)
+        GP.set_data(c["x"][:ni], c["f"][:ni], sf, c["g"][:ni], sg)
+        hp_x0_sel, bounds, _ = GP.select_hp_optz_x0(it, GP.hp_info_optz_lkd)
+        # iteration 1 starts from the shared initial history; later rows descend from this run's own optimum
+        np.testing.assert_allclose(hp_x0_sel, c[f"it{it}_hp_x0_sel"], rtol=1e-12 if it == 1 else 1e-5, atol=1e-13 if it == 1 else 1e-5)
+        GP.set_hpara('optz', it)
+        hv = GP.hp_vals
+        # the posterior is set up from the optimum (GaussianProcess.py:394-395)
+        mu, sig = GP.eval_model(c["x"][:2])[:2]
+        assert np.all(np.isfinite(mu)) and np.all(sig >= 0)
+        ln_ref = c[f"it{it}_ln_lkd"]
+        hp_final = GP.make_hp_class(theta=hv.theta, varK=hv.varK if GP.b_has_noisy_data else None,
+                                    var_fval=hv.var_fval, var_fgrad=hv.var_fgrad)
+        ln_here = GP.calc_lkd_all(hp_final)[0].ln_lkd
+        # the same local optimum: objective equal to 1e-6 relative, log10(theta) to 1e-3
+        assert abs(ln_here - ln_ref) <= 1e-6 * abs(ln_ref) + 1e-6, (it, ln_here, ln_ref)
+        np.testing.assert_allclose(np.log10(hv.theta), np.log10(c[f"it{it}_theta"]), atol=2e-3)
+        assert np.isclose(hv.varK, c[f"it{it}_varK"], rtol=5e-3)
+        assert np.isclose(hv.beta[0], c[f"it{it}_beta"][0], rtol=1e-3, atol=1e-6 * max(1.0, abs(c[f"it{it}_beta"][0])))
+        assert GP.hp_optz_success[it] == c[f"it{it}_success"]
+    GP.set_hpara('stored', 1)
+    np.testing.assert_allclose(GP.hp_vals.theta, GP.hp_theta_all[1])
