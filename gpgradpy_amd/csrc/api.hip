@@ -441,6 +441,40 @@ static int predict_impl(gpg_ctx* c, int nx, const double* xq, double varK, doubl
   return 0;
 }
 
+int gpg_predict_hess(gpg_ctx* c, const double* xq, double varK, double* mu, double* sig, double* dmudx, double* dsigdx,
+                     double* d2mudx2, double* d2sigdx2) {
+  if (c && (!d2mudx2 || !d2sigdx2 || !dmudx || !dsigdx)) { c->err = "Hessian / gradient output is NULL"; return -1; }
+  double s2 = 0.0;
+  int rc = predict_impl(c, 1, xq, varK, mu, sig, &s2, dmudx, dsigdx);   // leaves K^-1 Kyx in row 0 of Wt
+  if (rc) return rc;
+  const int d = c->d, nxp = 64;
+  AsmParams p = c->eval_params;
+  // gradbuf: [2 * nxp * 16] gradient reductions (consumed), then 3 * 256 doubles for H1, H2, T
+  double* h1 = c->gradbuf;
+  double* h2 = h1 + GPG_MAX_DIM * GPG_MAX_DIM;
+  double* T = h2 + GPG_MAX_DIM * GPG_MAX_DIM;
+  gpg_launch_hess_stage(c, p, nxp, h1, h2, T, 0);
+  GPG_HIP_OK(c, hipMemsetAsync(c->Wt, 0, sizeof(double) * (size_t)nxp * c->Npad, c->stream));
+  gpg_launch_hess_stage(c, p, nxp, h1, h2, T, 1);
+  gpg_forward_rows(c, c->Wt, nxp, nxp);
+  gpg_launch_hess_stage(c, p, nxp, h1, h2, T, 2);
+  std::vector<double> h(3 * GPG_MAX_DIM * GPG_MAX_DIM);
+  GPG_HIP_OK(c, hipMemcpyAsync(h.data(), h1, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream));
+  GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
+  GPG_HIP_OK(c, hipGetLastError());
+  const double* H1 = h.data();
+  const double* H2 = H1 + GPG_MAX_DIM * GPG_MAX_DIM;
+  const double* TT = H2 + GPG_MAX_DIM * GPG_MAX_DIM;
+  const double sg = sig[0];
+  for (int k = 0; k < d; ++k)
+    for (int i = 0; i < d; ++i) {
+      d2mudx2[k * d + i] = H1[k * d + i];                                               // GpEvalModel.py:355-363
+      const double d2s2 = -2.0 * varK * (H2[k * d + i] + TT[k * d + i]);                // :370-372
+      d2sigdx2[k * d + i] = sg != 0.0 ? (d2s2 - 2.0 * dsigdx[k] * dsigdx[i]) / (2.0 * sg) : NAN;   // :375-378
+    }
+  return 0;
+}
+
 int gpg_get_matrix(gpg_ctx* c, const gpg_hp* hp, int which, double* out) {
   if (!c) return -1;
   if (!out || which < 0 || which > 3) { c->err = "bad get_matrix arguments"; return -1; }

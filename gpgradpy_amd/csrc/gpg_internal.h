@@ -106,6 +106,7 @@ void gpg_launch_alpha(gpg_ctx* c, double* alpha_dev);                    // alph
 void gpg_launch_predict_reduce(gpg_ctx* c, int nx, int nxp, double beta, double varK, int phase);
 void gpg_backward_rows(gpg_ctx* c, double* Z, int ldz, int nrhs, double* tbuf);  // Z <- Z L^-1 (multi-RHS)
 void gpg_launch_cross_grad(gpg_ctx* c, const AsmParams& p, int nx, int nxp, double* g1, double* g2);
+void gpg_launch_hess_stage(gpg_ctx* c, const AsmParams& p, int nxp, double* h1, double* h2, double* T, int stage);
 void gpg_launch_combine_rows(gpg_ctx* c, int slot);                       // RHS row 0 <- L^-1 P^-1 (y - V beta)
 void gpg_launch_identity(gpg_ctx* c, double* W, int ldw);
 void gpg_inverse_from_factor(gpg_ctx* c, double* W, double* Minv);       // Minv <- -(L L^T)^-1 (lower)

@@ -252,6 +252,181 @@ void launch_cross_grad_d(gpg_ctx* c, const AsmParams& p, int nx, int nxp, double
 #undef CASE_D
 }
 
+// ------------------------------------------------------------------------------------------------
+// Posterior Hessians at ONE query point (reference GpEvalModel.py:355-382, kernel second / third derivatives
+// KernelSqExp.py:48-88,412-468, KernelMatern5f2.py:54-94,453-530).  With R = x_a - xq (this file's sign):
+//   base column a          : d2K[k,i] = (-2 th_i d_ik + 4 th_i th_k R_i R_k) E                     (SqExp)
+//                                       -th_k M1 d_ik + (25/3) th_i R_i th_k R_k E                 (Matern 5/2)
+//   gradient column (j, a) : d2K[k,i] = (4 th_i th_j (d_ik R_j + d_jk R_i) + 4 d_ij th_i th_k R_k
+//                                        - 8 th_i th_j th_k R_i R_j R_k) E                          (SqExp)
+//                                       (25/3) (th_i d_ik th_j R_j + th_j d_jk th_i R_i + th_i d_ij th_k R_k
+//                                        - sqrt5 / nu th_i R_i th_j R_j th_k R_k) E                 (Matern 5/2)
+// hess_contract_kernel: workgroup k -> row k of  H1 = sum_c d2K[k,:,c] alpha_c  and  H2 = sum_c d2K[k,:,c] v_c,
+// v = K^-1 Kyx (row 0 of Z).  Nothing of the [d, d, N] tensor is stored.
+// ------------------------------------------------------------------------------------------------
+template <int KERN, int D>
+__global__ void __launch_bounds__(256) hess_contract_kernel(AsmParams P, const double* __restrict__ Xt,
+                                                            const double* __restrict__ Xq, int nxp,
+                                                            const double* __restrict__ invp, const double* __restrict__ zvec,
+                                                            const double* __restrict__ Z, double* __restrict__ h1o,
+                                                            double* __restrict__ h2o) {
+  __shared__ double sh[2 * D * 16];
+  const int k = blockIdx.x, n = P.n, ng = P.ng;
+  const int nblk = P.use_grad ? D + 1 : 1;
+  double g[2 * D];
+#pragma unroll
+  for (int i = 0; i < 2 * D; ++i) g[i] = 0.0;
+  double xq[D], th[D];
+#pragma unroll
+  for (int i = 0; i < D; ++i) { xq[i] = Xq[(size_t)i * nxp]; th[i] = P.theta[i]; }
+  const double sqrt5 = sqrt(5.0);
+  for (int a = threadIdx.x; a < n; a += 256) {
+    double R[D], tR[D], E, M1 = 0.0, c3 = 0.0;
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) { R[i] = Xt[(size_t)i * n + a] - xq[i]; tR[i] = th[i] * R[i]; s += tR[i] * R[i]; }
+    if (KERN == GPG_KERNEL_SQEXP) {
+      E = exp(-s);
+    } else {
+      const double nu = sqrt(s);
+      E = exp(-sqrt5 * nu);
+      M1 = ((5.0 / 3.0) * (1.0 + sqrt5 * nu)) * E;
+      c3 = sqrt5 / fmax(nu, 1e-16);                      // KernelMatern5f2.py:500
+    }
+    const double tRk = tR[k];
+    {
+      const double wa = zvec[a] * invp[a], ws = Z[(size_t)a * nxp] * invp[a];
+#pragma unroll
+      for (int i = 0; i < D; ++i) {
+        double v;
+        if (KERN == GPG_KERNEL_SQEXP) v = (4.0 * tR[i] * tRk - (i == k ? 2.0 * th[i] : 0.0)) * E;
+        else v = (25.0 / 3.0) * tR[i] * tRk * E - (i == k ? th[k] * M1 : 0.0);
+        g[i] += v * wa;
+        g[D + i] += v * ws;
+      }
+    }
+    const int gpa = P.gpos[a];
+    if (nblk > 1 && gpa >= 0) {
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        const size_t c = (size_t)n + (size_t)j * ng + gpa;
+        const double ip = invp[c];
+        const double wa = zvec[c] * ip, ws = Z[c * nxp] * ip;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+          double v;
+          if (KERN == GPG_KERNEL_SQEXP) {
+            v = 4.0 * ((i == k ? th[i] * tR[j] : 0.0) + (j == k ? th[j] * tR[i] : 0.0) + (i == j ? th[i] * tRk : 0.0))
+                - 8.0 * tR[i] * tR[j] * tRk;
+            v *= E;
+          } else {
+            v = (i == k ? th[i] * tR[j] : 0.0) + (j == k ? th[j] * tR[i] : 0.0) + (i == j ? th[i] * tRk : 0.0)
+                - c3 * tR[i] * tR[j] * tRk;
+            v *= (25.0 / 3.0) * E;
+          }
+          g[i] += v * wa;
+          g[D + i] += v * ws;
+        }
+      }
+    }
+  }
+  block_sum<2 * D>(g, sh);
+  if (threadIdx.x < D) {
+    h1o[(size_t)k * D + threadIdx.x] = g[threadIdx.x];
+    h2o[(size_t)k * D + threadIdx.x] = g[D + threadIdx.x];
+  }
+}
+
+// Rows 1 .. d of Wt (RHS-rows layout, leading dimension nxp) <- P^-1 dKxy_dx[(j', q=0), :]: the d derivative rows
+// of the cross-covariance at the query point (same entries as cross_grad_kernel), for the forward sweep that gives
+// dKxy_dx K^-1 dKxy_dx^T (GpEvalModel.py:367).  Row 0 is cleared.
+template <int KERN, int D>
+__global__ void __launch_bounds__(256) cross_dx_rows_kernel(AsmParams P, const double* __restrict__ Xt,
+                                                            const double* __restrict__ Xq, int nxp,
+                                                            const double* __restrict__ invp, double* __restrict__ Wt) {
+  const int a = blockIdx.x * 256 + threadIdx.x, n = P.n, ng = P.ng;
+  if (a >= n) return;
+  const int nblk = P.use_grad ? D + 1 : 1;
+  double R[D], th[D], E, M1 = 0.0, s = 0.0;
+  const double sqrt5 = sqrt(5.0);
+#pragma unroll
+  for (int i = 0; i < D; ++i) { th[i] = P.theta[i]; R[i] = Xt[(size_t)i * n + a] - Xq[(size_t)i * nxp]; s += th[i] * (R[i] * R[i]); }
+  if (KERN == GPG_KERNEL_SQEXP) {
+    E = exp(-s);
+  } else {
+    const double nu = sqrt(s);
+    E = exp(-sqrt5 * nu);
+    M1 = ((5.0 / 3.0) * (1.0 + sqrt5 * nu)) * E;
+  }
+  {
+    const double ip = invp[a];
+    Wt[(size_t)a * nxp] = 0.0;
+#pragma unroll
+    for (int jp = 0; jp < D; ++jp)
+      Wt[(size_t)a * nxp + 1 + jp] = ip * (KERN == GPG_KERNEL_SQEXP ? ((2.0 * th[jp]) * R[jp]) * E : (th[jp] * R[jp]) * M1);
+  }
+  const int gpa = P.gpos[a];
+  if (nblk > 1 && gpa >= 0) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+      const size_t c = (size_t)n + (size_t)i * ng + gpa;
+      const double ip = invp[c];
+      Wt[c * nxp] = 0.0;
+#pragma unroll
+      for (int jp = 0; jp < D; ++jp) {
+        double v;
+        if (KERN == GPG_KERNEL_SQEXP) {
+          v = (i == jp) ? (2.0 * th[i] - (4.0 * (th[i] * th[i])) * (R[i] * R[i])) * E
+                        : ((-4.0 * th[i]) * th[jp]) * ((R[i] * R[jp]) * E);
+        } else {
+          v = (i == jp) ? th[i] * M1 - (((25.0 / 3.0) * (th[i] * th[i])) * (R[i] * R[i])) * E
+                        : (((((-(25.0 / 3.0)) * th[i]) * th[jp]) * R[i]) * R[jp]) * E;
+        }
+        Wt[c * nxp + 1 + jp] = ip * v;
+      }
+    }
+  }
+}
+
+// T[i, i'] = sum_c W[1 + i, c] W[1 + i', c]  (workgroup i; rows of the RHS-rows layout after the forward sweep)
+template <int D>
+__global__ void __launch_bounds__(256) rows_gram_kernel(const double* __restrict__ Wt, int nxp, int Npad,
+                                                        double* __restrict__ T) {
+  __shared__ double sh[D * 16];
+  const int i = blockIdx.x;
+  double g[D];
+#pragma unroll
+  for (int q = 0; q < D; ++q) g[q] = 0.0;
+  for (int c = threadIdx.x; c < Npad; c += 256) {
+    const double* w = Wt + (size_t)c * nxp + 1;
+    const double wi = w[i];
+#pragma unroll
+    for (int q = 0; q < D; ++q) g[q] += wi * w[q];
+  }
+  block_sum<D>(g, sh);
+  if (threadIdx.x < D) T[(size_t)i * D + threadIdx.x] = g[threadIdx.x];
+}
+
+template <int KERN>
+void launch_hess_d(gpg_ctx* c, const AsmParams& p, int nxp, double* h1, double* h2, double* T, int stage) {
+#define CASE_D(DD)                                                                                                   \
+  case DD:                                                                                                           \
+    if (stage == 0)                                                                                                  \
+      hipLaunchKernelGGL((hess_contract_kernel<KERN, DD>), dim3(DD), dim3(256), 0, c->stream, p, c->Xt, c->xq_dev, nxp,  \
+                         c->invp, c->zvec, c->Wt, h1, h2);                                                           \
+    else if (stage == 1)                                                                                             \
+      hipLaunchKernelGGL((cross_dx_rows_kernel<KERN, DD>), dim3((p.n + 255) / 256), dim3(256), 0, c->stream, p, c->Xt,   \
+                         c->xq_dev, nxp, c->invp, c->Wt);                                                            \
+    else                                                                                                             \
+      hipLaunchKernelGGL((rows_gram_kernel<DD>), dim3(DD), dim3(256), 0, c->stream, c->Wt, nxp, c->Npad, T);          \
+    break;
+  switch (p.d) {
+    CASE_D(1) CASE_D(2) CASE_D(3) CASE_D(4) CASE_D(5) CASE_D(6) CASE_D(7) CASE_D(8)
+    CASE_D(9) CASE_D(10) CASE_D(11) CASE_D(12) CASE_D(13) CASE_D(14) CASE_D(15) CASE_D(16)
+  }
+#undef CASE_D
+}
+
 // which 0..2: symmetric copy of the lower triangle; which 3: P L (lower), zeros above
 __global__ void extract_kernel(const double* __restrict__ A, int ld, int N, const double* __restrict__ dvec,
                                int precon, int which, double* __restrict__ out) {
@@ -300,6 +475,12 @@ void gpg_backward_rows(gpg_ctx* c, double* Z, int ldz, int nrhs, double* tbuf) {
 void gpg_launch_cross_grad(gpg_ctx* c, const AsmParams& p, int nx, int nxp, double* g1, double* g2) {
   if (p.kernel == GPG_KERNEL_SQEXP) launch_cross_grad_d<GPG_KERNEL_SQEXP>(c, p, nx, nxp, g1, g2);
   else launch_cross_grad_d<GPG_KERNEL_MA5F2>(c, p, nx, nxp, g1, g2);
+}
+
+// stage 0: H1 / H2 contraction, 1: derivative rows into Wt rows 1..d, 2: Gram of those rows after the forward sweep
+void gpg_launch_hess_stage(gpg_ctx* c, const AsmParams& p, int nxp, double* h1, double* h2, double* T, int stage) {
+  if (p.kernel == GPG_KERNEL_SQEXP) launch_hess_d<GPG_KERNEL_SQEXP>(c, p, nxp, h1, h2, T, stage);
+  else launch_hess_d<GPG_KERNEL_MA5F2>(c, p, nxp, h1, h2, T, stage);
 }
 
 void gpg_launch_alpha(gpg_ctx* c, double* alpha_dev) {

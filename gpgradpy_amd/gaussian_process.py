@@ -588,11 +588,14 @@ class GaussianProcess(HparaOptz):
             self._eval_ready = True
 
     def eval_model(self, x2model_in, calc_grad=False, calc_hess=False, squeeze_nx=False):
-        """GpEvalModel.py:59-198: returns (mu, sig, dmudx, dsigdx, None, None); Hessians are not built."""
+        """GpEvalModel.py:59-198: returns (mu, sig, dmudx, dsigdx, d2mudx2, d2sigdx2); the Hessians are
+        evaluated one point per call, as in the reference (GpEvalModel.py:358,369)."""
         assert self.KernEta_chofac is not None, 'To evaluate the surr the Cholesky decomposition is required'
         if calc_hess:
             assert calc_grad, 'To return the hessian calc_grad must also be set to True'      # GpEvalModel.py:126-127
-            raise NotImplementedError('posterior Hessians are not on the accelerated path yet (SURVEY.md 8f3)')
+            if self.bvec_use_grad is not None and not np.all(self.bvec_use_grad):
+                # reference shape bug with masks in calc_KernGrad_grad_x (KernelSqExp.py:451-452): nothing to pin against
+                raise NotImplementedError('posterior Hessians with a bvec_use_grad mask are not supported')
         if x2model_in.ndim == 1:
             x2model = x2model_in[None, :]
         elif x2model_in.ndim == 2:
@@ -608,8 +611,16 @@ class GaussianProcess(HparaOptz):
             raise Exception('setup_eval_model() must be called again: the device factor was overwritten by a likelihood evaluation')
         xq = np.ascontiguousarray(x2model, dtype=np.float64)
         mu, sig, s2 = np.empty(nx), np.empty(nx), np.empty(nx)
-        dmudx = dsigdx = None
-        if calc_grad:
+        dmudx = dsigdx = d2mudx2 = d2sigdx2 = None
+        if calc_hess:
+            assert nx == 1, 'calc_d2mudx2 can only be used on one point per call'          # GpEvalModel.py:358
+            dmudx, dsigdx = np.empty((1, self.dim)), np.empty((1, self.dim))
+            d2mudx2, d2sigdx2 = np.empty((1, self.dim, self.dim)), np.empty((1, self.dim, self.dim))
+            rc = self._lib.gpg_predict_hess(self._ctx, _lib.as_dp(xq), float(self.hp_vals.varK), _lib.as_dp(mu),
+                                            _lib.as_dp(sig), _lib.as_dp(dmudx), _lib.as_dp(dsigdx), _lib.as_dp(d2mudx2),
+                                            _lib.as_dp(d2sigdx2))
+            s2[:] = (sig / np.sqrt(self.hp_vals.varK)) ** 2
+        elif calc_grad:
             dmudx, dsigdx = np.empty((nx, self.dim)), np.empty((nx, self.dim))
             rc = self._lib.gpg_predict_grad(self._ctx, nx, _lib.as_dp(xq), float(self.hp_vals.varK), _lib.as_dp(mu),
                                             _lib.as_dp(sig), _lib.as_dp(s2), _lib.as_dp(dmudx), _lib.as_dp(dsigdx))
@@ -621,10 +632,12 @@ class GaussianProcess(HparaOptz):
         assert np.min(s2) >= 0, \
             f'The variance of the surr should be non-negative but min(sig2_wo_sigK) = {np.min(s2)}'   # GpEvalModel.py:163
         if squeeze_nx:
+            if calc_hess:
+                return mu[0], sig[0], dmudx[0, :], dsigdx[0, :], d2mudx2[0], d2sigdx2[0]  # GpEvalModel.py:186-196
             if calc_grad:
-                return mu[0], sig[0], dmudx[0, :], dsigdx[0, :], None, None                 # GpEvalModel.py:186-192
+                return mu[0], sig[0], dmudx[0, :], dsigdx[0, :], None, None
             return mu[0], sig[0], None, None, None, None
-        return mu, sig, dmudx, dsigdx, None, None
+        return mu, sig, dmudx, dsigdx, d2mudx2, d2sigdx2
 
     # ---- instrumentation -------------------------------------------------------------------------------
     def prof_enable(self, cats):

@@ -125,6 +125,14 @@ int gpg_predict(gpg_ctx* ctx, int nx, const double* xq, double varK, double* mu,
 int gpg_predict_grad(gpg_ctx* ctx, int nx, const double* xq, double varK, double* mu, double* sig,
                      double* sig2_raw, double* dmudx, double* dsigdx);
 
+/* Posterior Hessians at ONE query point xq[d] (the reference evaluates them one point per call):
+ * d2mudx2[d*d], d2sigdx2[d*d] row-major, plus everything gpg_predict_grad returns for that point.
+ * Replaces eval_model(calc_grad=True, calc_hess=True) -- GpEvalModel.py:170-181, calc_d2mudx2 :355-363,
+ * calc_d2sigdx2 :365-380, calc_Kern_hess_x (KernelSqExp.py:48-88,412-468, KernelMatern5f2.py:54-94,453-530).
+ * d2sigdx2 is NaN where sig == 0, as in the reference. */
+int gpg_predict_hess(gpg_ctx* ctx, const double* xq, double varK, double* mu, double* sig, double* dmudx,
+                     double* dsigdx, double* d2mudx2, double* d2sigdx2);
+
 /* Materialisation on request (the 7-tuple of Kernel.py:307 carries N x N arrays; the fast path never
  * copies them).  out is [N, N] column-major == row-major (symmetric) for which = 0..2:
  *   0 Kern (Kernel.py:213-216), 1 Kcov (Kernel.py:237 / 277), 2 the matrix that is factorised

@@ -354,6 +354,68 @@ def eval_model_grad(m: EvalModel, xq):
     return mu, sig, dmudx, dsigdx
 
 
+def kern_hess_x(x, Y, theta, kernel, use_grad):
+    """Second derivatives of the cross-covariance row K(x, [Y, dY]) with respect to the query point x:
+    [d, d, N] -- reference KernelSqExp.py:48-88 (base columns), :412-468 (gradient columns),
+    KernelMatern5f2.py:54-94, :453-530; r = x - y as in calc_Rtensor(x2model, x_eval)."""
+    x = np.asarray(x, dtype=float).ravel()
+    n, d = Y.shape
+    R = x[None, :] - Y                                   # [n, d]
+    N = n * (d + 1) if use_grad else n
+    H = np.zeros((d, d, N))
+    if kernel == "SqExp":
+        K = np.exp(-np.sum(theta * R ** 2, axis=1))
+        for k in range(d):
+            for i in range(d):
+                H[k, i, :n] = (-2 * theta[i] * (i == k) + 4 * theta[i] * theta[k] * R[:, i] * R[:, k]) * K
+                if use_grad:
+                    for j in range(d):
+                        c0 = n + j * n
+                        H[k, i, c0:c0 + n] = (-4 * theta[i] * theta[j] * ((i == k) * R[:, j] + (j == k) * R[:, i])
+                                              - 4 * (i == j) * theta[i] * theta[k] * R[:, k]
+                                              + 8 * theta[i] * theta[j] * theta[k] * R[:, i] * R[:, j] * R[:, k]) * K
+    elif kernel == "Ma5f2":
+        nu = np.sqrt(np.sum(theta * R ** 2, axis=1))
+        base = np.exp(-np.sqrt(5) * nu)
+        A = (5 / 3) * (1 + np.sqrt(5) * nu) * base
+        inv_nu = 1 / np.maximum(nu, 1e-16)
+        Rt = R * theta
+        for k in range(d):
+            for i in range(d):
+                H[k, i, :n] = (25 / 3) * Rt[:, i] * Rt[:, k] * base - (i == k) * theta[k] * A
+                if use_grad:
+                    for j in range(d):
+                        c0 = n + j * n
+                        H[k, i, c0:c0 + n] = -(25 / 3) * (theta[i] * (i == k) * Rt[:, j] + theta[j] * (j == k) * Rt[:, i]
+                                                        + theta[i] * (i == j) * Rt[:, k]
+                                                        - np.sqrt(5) * inv_nu * Rt[:, i] * Rt[:, j] * Rt[:, k]) * base
+    else:
+        raise ValueError(kernel)
+    return H
+
+
+def eval_model_hess(m: EvalModel, xq):
+    """(mu, sig, dmudx, dsigdx, d2mudx2, d2sigdx2) at ONE point -- reference GpEvalModel.py:59-198 with
+    calc_hess=True (:148-150, :176-178), calc_d2mudx2 :355-363, calc_d2sigdx2 :365-380.  No gradient masks."""
+    xq = np.atleast_2d(np.asarray(xq, dtype=float))
+    assert xq.shape[0] == 1 and m.grad_mask is None
+    mu, sig, dmudx, dsigdx = eval_model_grad(m, xq)
+    d = xq.shape[1]
+    Kg = kern_grad(m.X, xq, m.theta, m.kernel, grad_cols=True)
+    if not m.use_grad:
+        Kg = Kg[:m.X.shape[0], :]
+    Kyx, dKxy_dx = Kg[:, :1], Kg[:, 1:].T
+    H = kern_hess_x(xq[0], m.X, m.theta, m.kernel, m.use_grad)
+    sol = cho_solve(m.chofac, Kyx)                                        # K^-1 Kyx  [N, 1]
+    d2mudx2 = H @ m.alpha
+    term1 = H @ sol[:, 0]
+    term2 = dKxy_dx @ cho_solve(m.chofac, dKxy_dx.T)
+    d2sig2 = -2 * m.varK * (term1 + term2)
+    sig_mod = sig[0] if sig[0] != 0 else np.nan
+    d2sigdx2 = (1 / (2 * sig_mod)) * (d2sig2 - 2 * np.outer(dsigdx[0], dsigdx[0]))
+    return mu, sig, dmudx, dsigdx, d2mudx2[None], d2sigdx2[None]
+
+
 def eval_model(m: EvalModel, xq):
     """Posterior mean and standard deviation -- reference GpEvalModel.py:59-198 (calc_grad=False)."""
     xq = np.atleast_2d(np.asarray(xq, dtype=float))

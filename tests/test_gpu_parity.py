@@ -108,7 +108,7 @@ def test_golden_case(path):
     # squeeze_nx contract
     m1, s1, dm1, ds1 = GP.eval_model(c["xq"][0], calc_grad=True, squeeze_nx=True)[:4]
     assert np.isclose(m1, mu[0]) and np.isclose(s1, sig[0]) and dm1.shape == (c["d"],) and np.allclose(dm1, dmudx[0])
-    with pytest.raises(NotImplementedError):
+    with pytest.raises((AssertionError, NotImplementedError)):      # Hessians: one point per call, no gradient masks
         GP.eval_model(c["xq"], calc_grad=True, calc_hess=True)
 
 
