@@ -75,9 +75,12 @@ __device__ __forceinline__ int potrf64_wave(const double* src, int sld, double (
 #pragma unroll
       for (int c = 0; c < 16; ++c) a[c] = St[16 * s + c][i];
     }
+    // Pivot chain, software-pipelined: the next pivot a[c+1][c+1] - L[c+1][c]^2 only needs the diagonal lane's own
+    // scaled entry, so it is formed and broadcast BEFORE column c is applied to the other columns; the 15 - c
+    // broadcast-FMA updates then fill the latency of the next v_rsq_f64 + Goldschmidt chain.
+    double ajj = readlane_d(a[0], 16 * s);
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
-      const double ajj = readlane_d(a[c], 16 * s + c);
       bad = (bad == 0 && !(ajj > 0.0)) ? 16 * s + c + 1 : bad;   // first non-positive / NaN pivot (LAPACK info)
       const double y0 = __builtin_amdgcn_rsq(ajj);
       double g = ajj * y0, h = 0.5 * y0;
@@ -87,7 +90,12 @@ __device__ __forceinline__ int potrf64_wave(const double* src, int sld, double (
       r = __builtin_fma(-h, g, 0.5);
       const double dj = __builtin_fma(g, r, g);        // sqrt(ajj)
       const double inv = 2.0 * __builtin_fma(h, r, h); // 1 / sqrt(ajj)
-      a[c] = (i == 16 * s + c) ? dj : a[c] * inv;
+      const double lc = a[c] * inv;
+      if (c < 15) {
+        const double t = __builtin_fma(-lc, lc, a[c + 1]);     // exact in the lane of row 16 s + c + 1
+        ajj = readlane_d(t, 16 * s + c + 1);
+      }
+      a[c] = (i == 16 * s + c) ? dj : lc;
       myinv = (i == 16 * s + c) ? inv : myinv;   // reciprocal pivots for the panel solves: lane j keeps 1 / L_jj
 #pragma unroll
       for (int k2 = c + 1; k2 < 16; ++k2) a[k2] -= a[c] * readlane_d(a[c], 16 * s + k2);
@@ -1074,13 +1082,39 @@ __device__ __forceinline__ void direct_tile_gemm(d4 (&acc)[4][4], const double* 
 //     publish: __threadfence, flag(i, j) = 1 (agent-scope release)
 // Progress argument and bounded waits as in tile_chol_kernel.
 // ------------------------------------------------------------------------------------------------
+// Whole-workgroup wait on a completion flag (thread 0 polls, result shared through `sh`); 0 = timed out / aborted.
+__device__ __forceinline__ int wg_wait_flag(int* flag, int* abort_word, int* info, int* sh) {
+  if (threadIdx.x == 0) {
+    int spins = 0, ok = 1;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+      if (++spins > GPG_TILE_SPIN_LIMIT || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicMax(info, GPG_INFO_INTERNAL);
+        ok = 0;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    *sh = ok;
+  }
+  __syncthreads();
+  const int ok = *sh;
+  __syncthreads();   // sh may be rewritten by the next wait
+  if (ok) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return ok;
+}
+
 // X (128 rows x 128 columns, in place) <- X L^-T against a factorised 128 x 128 diagonal tile, whole workgroup.
 // Each lane quad carries TWO matrix rows (r and r + 64) through the substitution, so the 128 rows cost two
 // substitution sweeps instead of four and half the L-image traffic.  Column block 0 is read from memory
 // straight in the quad layout; block 1 first takes its update X1 L21^T on MFMA (two 64-row passes through
 // the LDS tile).  U: 4 * 16 * 80 doubles, Ls / sdinv: diagonal-block image.  Ends with a workgroup barrier.
-__device__ __forceinline__ void tile_solve_rows128(const double* __restrict__ L, int ldl, const double* __restrict__ dinv,
-                                                   double* X, int ldx, double* U, double (*Ls)[4][18], double* sdinv) {
+// The diagonal tile publishes its pieces as they are final -- L11 (flag_a, after the first potrf64), L21 (flag_c,
+// after its 64-row solve), L22 (flag_b = the tile's completion flag): column block 0 of this tile is solved and the
+// MFMA update of block 1 runs while the diagonal tile is still in its second potrf64.
+__device__ __forceinline__ int tile_solve_rows128(const double* L, int ldl, const double* dinv, double* X, int ldx, double* U,
+                                                  double (*Ls)[4][18], double* sdinv, int* flag_a, int* flag_c, int* flag_b,
+                                                  int* abort_word, int* info, int* sh) {
   constexpr int SA = 80, BUF = 16 * SA;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
@@ -1089,12 +1123,13 @@ __device__ __forceinline__ void tile_solve_rows128(const double* __restrict__ L,
   double x0[16], x1[16], li[16];
   // ---- column block 0 ----------------------------------------------------------------------------------------
   {
-    const double* Xr = X + rr + (size_t)q * ldx;
+    const double* Xr = X + rr + (size_t)q * ldx;     // own rows: in flight while the flag is polled
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
       x0[m] = Xr[(size_t)(4 * m) * ldx];
       x1[m] = Xr[64 + (size_t)(4 * m) * ldx];
     }
+    if (!wg_wait_flag(flag_a, abort_word, info, sh)) return 0;
     for (int t = tid; t < 64 * 64; t += 256) {
       const int jj = t >> 6, k = t & 63;
       Ls[jj][k & 3][k >> 2] = L[k + (size_t)jj * ldl];
@@ -1102,14 +1137,6 @@ __device__ __forceinline__ void tile_solve_rows128(const double* __restrict__ L,
     if (tid < 64) sdinv[tid] = dinv[tid];
   }
   __syncthreads();
-  {   // image of L22 for block 1, fetched behind the first substitution
-    const double* L22 = L + 64 + (size_t)64 * ldl;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int t = tid + 256 * i;
-      li[i] = L22[(t & 63) + (size_t)(t >> 6) * ldl];
-    }
-  }
   GPG_QUAD_SUBST2(x0, x1, Ls, sdinv, q)
   {
     double* Xr = X + rr + (size_t)q * ldx;
@@ -1119,13 +1146,7 @@ __device__ __forceinline__ void tile_solve_rows128(const double* __restrict__ L,
       Xr[64 + (size_t)(4 * m) * ldx] = x1[m];
     }
   }
-  __syncthreads();   // X1 visible to the workgroup, Ls free
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int t = tid + 256 * i, jj = t >> 6, k = t & 63;
-    Ls[jj][k & 3][k >> 2] = li[i];
-  }
-  if (tid < 64) sdinv[tid] = dinv[64 + tid];
+  if (!wg_wait_flag(flag_c, abort_word, info, sh)) return 0;   // barrier inside: X1 visible to the workgroup, Ls free
   // ---- column block 1: T2 -= X1 L21^T for the two row halves, each transposed through the LDS tile ---------------
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -1153,6 +1174,22 @@ __device__ __forceinline__ void tile_solve_rows128(const double* __restrict__ L,
     }
     __syncthreads();   // tile consumed before the next pass stages into U again
   }
+  if (!wg_wait_flag(flag_b, abort_word, info, sh)) return 0;
+  {   // image of L22
+    const double* L22 = L + 64 + (size_t)64 * ldl;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int t = tid + 256 * i;
+      li[i] = L22[(t & 63) + (size_t)(t >> 6) * ldl];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int t = tid + 256 * i, jj = t >> 6, k = t & 63;
+      Ls[jj][k & 3][k >> 2] = li[i];
+    }
+    if (tid < 64) sdinv[tid] = dinv[64 + tid];
+  }
+  __syncthreads();
   GPG_QUAD_SUBST2(x0, x1, Ls, sdinv, q)
   {
     double* Xr = X + rr + (size_t)(64 + q) * ldx;
@@ -1163,6 +1200,7 @@ __device__ __forceinline__ void tile_solve_rows128(const double* __restrict__ L,
     }
   }
   __syncthreads();
+  return 1;
 }
 
 // Finalisation of a 128 x 128 tile that already sits updated in memory (kept out of line so that its register
@@ -1171,8 +1209,8 @@ __shared__ __attribute__((aligned(16))) double t128_U[4 * 16 * 80];   // staging
 __shared__ __attribute__((aligned(16))) double t128_Ls[64][4][18];    // diagonal-block image / potrf scratch
 __shared__ double t128_sdinv[64];
 
-__device__ __noinline__ int tile128_finalize(double* A, int ld, size_t r0, size_t cj, int is_diag, int* flag_jj,
-                                             int* abort_word, double* __restrict__ dinv, int* __restrict__ info, int N) {
+__device__ __noinline__ int tile128_finalize(double* A, int ld, size_t r0, size_t cj, int is_diag, int* flag_jj, int* flag_a,
+                                             int* flag_c, int* abort_word, double* dinv, int* info, int N) {
   constexpr int SA = 80;
   double* const U = t128_U;
   double (*const Ls)[4][18] = t128_Ls;
@@ -1193,11 +1231,16 @@ __device__ __noinline__ int tile128_finalize(double* A, int ld, size_t r0, size_
     if (w == 0) {   // A11 was left in the LDS tile by this same wave (no barrier, no trip through memory)
       const int bad = potrf64_wave(U, SA, St, blk, ld, dinv + cj);
       if (bad && lane == 0 && (int)cj + bad - 1 < N) atomicCAS(info, 0, (int)cj + bad);
+      __threadfence();   // L11 and its reciprocal pivots (all written by this wave) are published early
+      if (lane == 0) __hip_atomic_store(flag_a, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();   // also drains the other waves' stores of A21 / A22
     GPG_FS(1)
     // L21 = A21 L11^-T
     panel_solve_rows64(blk, ld, dinv + cj, blk + 64, ld, 64, 64, U, Ls, sdinv);
+    __threadfence();   // L21 is final (every thread stored part of it; the solve ended with a barrier)
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(flag_c, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     GPG_FS(2)
     // A22 -= L21 L21^T on MFMA, then factor it from the LDS tile
     const int sp = tid & 31, sk = tid >> 5;
@@ -1223,33 +1266,17 @@ __device__ __noinline__ int tile128_finalize(double* A, int ld, size_t r0, size_
     GPG_FS(4)
     return 1;
   }
-  if (tid == 0) {
-    int spins = 0, ok = 1;
-    while (__hip_atomic_load(flag_jj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-      if (++spins > GPG_TILE_SPIN_LIMIT || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-        __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          atomicMax(info, GPG_INFO_INTERNAL);
-        ok = 0;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(8);
-    }
-    sh_ok = ok;
-  }
-  __syncthreads();
-  if (sh_ok == 0) return 0;
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   GPG_FS(1)
   const double* Ljj = A + cj + cj * (size_t)ld;
   double* X = A + r0 + cj * (size_t)ld;
-  tile_solve_rows128(Ljj, ld, dinv + cj, X, ld, U, Ls, sdinv);
+  if (!tile_solve_rows128(Ljj, ld, dinv + cj, X, ld, U, Ls, sdinv, flag_a, flag_c, flag_jj, abort_word, info, &sh_ok)) return 0;
   GPG_FS(2)
   GPG_FS(3)
   return 1;
 }
 
 __global__ void __launch_bounds__(256, 2)
-tile128_chol_kernel(double* A, int ld, int Mt, const int* __restrict__ tasks, int* flags, int* abort_word,
+tile128_chol_kernel(double* A, int ld, int Mt, const int* __restrict__ tasks, int* flags, int* flag_a, int* abort_word,
                     double* __restrict__ dinv, int* __restrict__ info, int N) {
   __shared__ int sh_kr;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -1334,7 +1361,7 @@ tile128_chol_kernel(double* A, int ld, int Mt, const int* __restrict__ tasks, in
         for (int r = 0; r < 4; ++r) Cw[mi * 16 + (size_t)(ni * 16 + 4 * r) * ld] = acc[ni][mi][r];
   }
   if (ti != tj) __syncthreads();
-  if (tile128_finalize(A, ld, r0, cj, ti == tj, frow_j + tj, abort_word, dinv, info, N) == 0) return;
+  if (tile128_finalize(A, ld, r0, cj, ti == tj, frow_j + tj, flag_a + tj, flag_a + Mt + tj, abort_word, dinv, info, N) == 0) return;
   // ---- (3) publish ----------------------------------------------------------------------------------------------
   __threadfence();
   __syncthreads();
@@ -1452,7 +1479,7 @@ static void launch_tile_chol(gpg_ctx* c, int c0) {
 static void launch_tile128_chol(gpg_ctx* c) {
   const int Mt = c->Npad / 128, Rt = c->ld / 128;
   const TileMap& tm = get_tile_tasks(c, Mt, Rt);
-  const size_t nflag = (size_t)Mt * Rt + 1;
+  const size_t nflag = (size_t)Mt * Rt + 1 + 2 * Mt;   // tile flags, abort word, two early flags per diagonal tile
   if (c->tile_flags_cap < nflag) {
     if (c->tile_flags) (void)hipFree(c->tile_flags);
     (void)hipMalloc(&c->tile_flags, sizeof(int) * nflag);
@@ -1461,8 +1488,9 @@ static void launch_tile128_chol(gpg_ctx* c) {
   (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
   const double m = (double)c->Npad;
   gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, m * m * m / 3.0);
+  int* abort_word = c->tile_flags + (size_t)Mt * Rt;
   hipLaunchKernelGGL(tile128_chol_kernel, dim3(tm.n), dim3(256), 0, c->stream, c->A, c->ld, Mt, (const int*)tm.dev,
-                     c->tile_flags, c->tile_flags + (nflag - 1), c->dinv, c->info, c->N);
+                     c->tile_flags, abort_word + 1, abort_word, c->dinv, c->info, c->N);
   gpg_prof_end(c);
 }
 

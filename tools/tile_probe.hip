@@ -53,7 +53,10 @@ int main(int argc, char** argv) {
   }
   int info = -1, ab = -1;
   hipMemcpy(&info, c.info, sizeof(int), hipMemcpyDeviceToHost);
-  if (c.tile_flags) hipMemcpy(&ab, c.tile_flags + (c.tile_flags_cap - 1), sizeof(int), hipMemcpyDeviceToHost);
+  if (c.tile_flags) {   // abort word: after the Mt x Rt tile flags
+    const int T = impl == 1 ? 128 : 64;
+    hipMemcpy(&ab, c.tile_flags + (size_t)(c.Npad / T) * (c.ld / T), sizeof(int), hipMemcpyDeviceToHost);
+  }
   printf("n=%d impl=%d: %.3f ms, %.2f TFLOP/s (n^3/3), info=%d abort=%d\n", n, impl, best, (double)n * n * n / 3.0 / best * 1e-9, info, ab);
 #ifdef GPG_STAMP
   {
