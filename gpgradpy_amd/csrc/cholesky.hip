@@ -974,61 +974,6 @@ gemm_direct_kernel(double* __restrict__ C, int ldc, const double* __restrict__ A
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// dma_tile_gemm: the main loop of gemm_dma_kernel as a device function.  acc (wave tile 64 x 64 of a
-// 128 x 128 workgroup tile) -= A[128 x K] B[128 x K]^T, K = 8 nchunk (nchunk >= 3), both row slices
-// streamed by global_load_lds_dwordx4 into the 4-stage ring `ring`.  ga / gb: this lane's DMA sources for
-// k-row w of chunk 0 (row pair 2 * lane of the slice).  Returns with the ring drained and a barrier passed.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void dma_tile_gemm(d4 (&acc)[4][4], const double* ga, int lda, const double* gb, int ldb,
-                                              int nchunk, double* ring, int w, int wm, int wn, int l15, int l4) {
-  constexpr int S = 4, KB = 8, ROW = 144, STAGE = 2 * KB * ROW;
-  const size_t a4 = (size_t)4 * lda, b4 = (size_t)4 * ldb, aK = (size_t)KB * lda, bK = (size_t)KB * ldb;
-#define GPG_DT_ISSUE(stage)                                                                               \
-  {                                                                                                       \
-    double* sa = ring + (stage) * STAGE + w * ROW;                                                         \
-    __builtin_amdgcn_global_load_lds((glb_ptr_t)ga, (lds_ptr_t)sa, 16, 0, 0);                              \
-    __builtin_amdgcn_global_load_lds((glb_ptr_t)(ga + a4), (lds_ptr_t)(sa + 4 * ROW), 16, 0, 0);          \
-    __builtin_amdgcn_global_load_lds((glb_ptr_t)gb, (lds_ptr_t)(sa + KB * ROW), 16, 0, 0);                 \
-    __builtin_amdgcn_global_load_lds((glb_ptr_t)(gb + b4), (lds_ptr_t)(sa + (KB + 4) * ROW), 16, 0, 0);    \
-    ga += aK;                                                                                             \
-    gb += bK;                                                                                             \
-  }
-#define GPG_DT_COMPUTE(stage)                                                                             \
-  {                                                                                                       \
-    const double* pa = ring + (stage) * STAGE + l4 * ROW + wm * 64 + l15;                                  \
-    const double* pb = ring + (stage) * STAGE + (KB + l4) * ROW + wn * 64 + l15;                           \
-    _Pragma("unroll") for (int kk = 0; kk < KB; kk += 4) {                                                 \
-      double fm[4], fn[4];                                                                                \
-      _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) fm[mi] = -pa[kk * ROW + mi * 16];                    \
-      _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) fn[ni] = pb[kk * ROW + ni * 16];                     \
-      _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                     \
-        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                   \
-          acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fn[ni], fm[mi], acc[ni][mi], 0, 0, 0);        \
-    }                                                                                                     \
-  }
-#pragma unroll
-  for (int st = 0; st < S - 1; ++st) GPG_DT_ISSUE(st)
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  int stage = 0;
-  for (int i = 0; i < nchunk; ++i) {
-    const bool more = (i + S - 1) < nchunk;
-    if (more) {
-      int st = stage + S - 1;
-      st = st >= S ? st - S : st;
-      GPG_DT_ISSUE(st)
-    }
-    GPG_DT_COMPUTE(stage)
-    if (more) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    stage = stage + 1 == S ? 0 : stage + 1;
-  }
-#undef GPG_DT_ISSUE
-#undef GPG_DT_COMPUTE
-}
-
 // direct_tile_gemm: main loop of gemm_direct_kernel as a device function.  acc (wave tile 64 x 64) -=
 // A[64 x 4 nstep] B[64 x 4 nstep]^T with operand fragments loaded straight from global memory, PF k-steps
 // ahead.  pa / pb: this lane's fragment sources of k-step 0 (row lane&15 of the wave's slice, k = lane>>4);
@@ -1428,11 +1373,6 @@ void launch_gemm_trailing(gpg_ctx* c, double* C, int ldc, const double* A, int l
   }
   if (c->gemm_impl == 3) {
     hipLaunchKernelGGL(gemm_direct_kernel<3>, dim3(tm.n), dim3(256), 0, c->stream, C, ldc, A, lda, B, ldb, M, Nc, K, 1, 0, 0,
-                       (const int*)tm.dev, tm.n);
-    return;
-  }
-  if (c->gemm_impl == 4) {
-    hipLaunchKernelGGL(gemm_direct_kernel<7>, dim3(tm.n), dim3(256), 0, c->stream, C, ldc, A, lda, B, ldb, M, Nc, K, 1, 0, 0,
                        (const int*)tm.dev, tm.n);
     return;
   }
