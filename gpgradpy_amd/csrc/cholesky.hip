@@ -42,7 +42,7 @@ __device__ __forceinline__ double readlane_d(double v, int lane) {
 // Goldschmidt steps (sqrt and 1/sqrt to ~1 ulp in 7 dependent operations; the pivot chain is the critical
 // path of every factorisation in this file).
 __device__ __forceinline__ int potrf64_wave(const double* src, int sld, double (*St)[64], double* __restrict__ blk, int ld,
-                                            double* __restrict__ dinv) {
+                                            double* __restrict__ dinv, int* piece_flags = nullptr) {
   const int i = threadIdx.x & 63, l15 = i & 15, l4 = i >> 4;
   int bad = 0;
   double myinv = 0.0;
@@ -110,8 +110,12 @@ __device__ __forceinline__ int potrf64_wave(const double* src, int sld, double (
       if (i >= 16 * s + c) blk[i + (size_t)(16 * s + c) * ld] = a[c];
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (i >= 16 * s && i < 16 * s + 16) dinv[i] = myinv;
+    if (piece_flags) {   // dataflow kernels: these 16 columns (and their reciprocal pivots) are final -- publish them
+      __threadfence();
+      if (i == 0) __hip_atomic_store(piece_flags + s, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
-  dinv[i] = myinv;
   return bad;
 }
 
@@ -281,6 +285,19 @@ __device__ __forceinline__ void wave_tile_gemm(d4 (&acc)[4], const double* ga, i
     __builtin_amdgcn_sched_barrier(0);                                                      \
   }
 
+// one 16-column piece (columns 16 s .. 16 s + 15) of GPG_QUAD_SUBST: the dataflow kernels substitute against the
+// diagonal block while it is still being factored, piece by piece as its columns are published
+#define GPG_QUAD_SUBST_PIECE(x, Ls, sdinv, q, s)                                             \
+  {                                                                                         \
+    double lv[2][16];                                                                       \
+    _Pragma("unroll") for (int m = 0; m < 16; ++m) lv[0][m] = Ls[16 * (s)][q][m];            \
+    _Pragma("unroll") for (int mj = 4 * (s); mj < 4 * (s) + 4; ++mj) {                       \
+      GPG_QS_STEP(x, Ls, sdinv, q, 0)                                                        \
+      GPG_QS_STEP(x, Ls, sdinv, q, 1)                                                        \
+      GPG_QS_STEP(x, Ls, sdinv, q, 2)                                                        \
+      GPG_QS_STEP(x, Ls, sdinv, q, 3)                                                        \
+    }                                                                                       \
+  }
 // two matrix rows per lane quad (x0, x1): the L values are read once for both rows
 #define GPG_QUAD_SUBST2(x0, x1, Ls, sdinv, q)                                                \
   {                                                                                         \
@@ -465,8 +482,35 @@ panel_solve_kernel(const double* __restrict__ L, int ldl, const double* __restri
 // one 64-deep MFMA block (~20 us) instead of three dependent launches per step plus B_p and U_p.
 // ------------------------------------------------------------------------------------------------
 #define GPG_TILE_SPIN_LIMIT 400000   // x ~0.5 us per poll: ~0.2 s
+// Whole-workgroup wait on a completion flag (thread 0 polls, result shared through `sh`); 0 = timed out / aborted.
+__device__ __forceinline__ int wg_wait_flag(int* flag, int* abort_word, int* info, int* sh) {
+  if (threadIdx.x == 0) {
+    int spins = 0, ok = 1;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+      if (++spins > GPG_TILE_SPIN_LIMIT || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicMax(info, GPG_INFO_INTERNAL);
+        ok = 0;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    *sh = ok;
+  }
+  __syncthreads();
+  const int ok = *sh;
+  __syncthreads();   // sh may be rewritten by the next wait
+  if (ok) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return ok;
+}
+
+// X (128 rows x 128 columns, in place) <- X L^-T against a factorised 128 x 128 diagonal tile, whole workgroup.
+// Each lane quad carries TWO matrix rows (r and r + 64) through the substitution, so the 128 rows cost two
+// substitution sweeps instead of four and half the L-image traffic.  Column block 0 is read from memory
+// straight in the quad layout; block 1 first takes its update X1 L21^T on MFMA (two 64-row passes through
+// the LDS tile).  U: 4 * 16 * 80 doubles, Ls / sdinv: diagonal-block image.  Ends with a workgroup barrier.
 __global__ void __launch_bounds__(256, 2)
-tile_chol_kernel(double* A, int ld, int c0, int Mt, const int* __restrict__ tasks, int* flags, int* abort_word,
+tile_chol_kernel(double* A, int ld, int c0, int Mt, const int* __restrict__ tasks, int* flags, int* pieces, int* abort_word,
                  double* __restrict__ dinv, int* __restrict__ info, int N) {
   constexpr int KB = 16, SA = 80, BUF = KB * SA;
   __shared__ __attribute__((aligned(16))) double U[4 * BUF];      // staging sA[2] | sB[2]; later the tile Ts[64][SA]
@@ -540,35 +584,11 @@ tile_chol_kernel(double* A, int ld, int c0, int Mt, const int* __restrict__ task
     __syncthreads();
     if (w == 0) {   // diagonal tile: factor it (one wave; entries above the diagonal are garbage nobody reads)
       double* blk = A + r0 + cj * (size_t)ld;
-      const int bad = potrf64_wave(U, SA, reinterpret_cast<double(*)[64]>(&Ls[0][0][0]), blk, ld, dinv + cj);
+      const int bad = potrf64_wave(U, SA, reinterpret_cast<double(*)[64]>(&Ls[0][0][0]), blk, ld, dinv + cj, pieces + 4 * tj);
       if (bad && lane == 0 && (int)cj + bad - 1 < N) atomicCAS(info, 0, (int)cj + bad);
     }
   } else {
-    // wait for the diagonal tile of this column, then substitute
-    if (tid == 0) {
-      int spins = 0, ok = 1;
-      while (__hip_atomic_load(frow_j + tj, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-        if (++spins > GPG_TILE_SPIN_LIMIT || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-          __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          atomicMax(info, GPG_INFO_INTERNAL);
-          ok = 0;
-          break;
-        }
-        __builtin_amdgcn_s_sleep(4);
-      }
-      sh_kr = ok;
-    }
-    __syncthreads();
-    if (sh_kr == 0) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    {
-      const double* Ljj = A + cj + cj * (size_t)ld;
-      for (int t = tid; t < 64 * 64; t += 256) {
-        const int jj = t >> 6, k = t & 63;
-        Ls[jj][k & 3][k >> 2] = Ljj[k + (size_t)jj * ld];
-      }
-      if (tid < 64) sdinv[tid] = dinv[cj + tid];
-    }
+    // substitute against the diagonal tile of this column piece by piece, as its 16-column pieces are published
     __syncthreads();
     double x[16];
     {
@@ -576,7 +596,25 @@ tile_chol_kernel(double* A, int ld, int c0, int Mt, const int* __restrict__ task
 #pragma unroll
       for (int m = 0; m < 16; ++m) x[m] = Tr[(4 * m) * SA];
     }
-    GPG_QUAD_SUBST(x, Ls, sdinv, q)
+    const double* Ljj = A + cj + cj * (size_t)ld;
+#define GPG_TC_PIECE(S)                                                                      \
+    {                                                                                       \
+      if (!wg_wait_flag(pieces + 4 * tj + (S), abort_word, info, &sh_kr)) return;            \
+      _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                        \
+        const int t = tid + 256 * u, jj = 16 * (S) + (t >> 6), k = t & 63;                   \
+        Ls[jj][k & 3][k >> 2] = Ljj[k + (size_t)jj * ld];                                    \
+      }                                                                                     \
+      if (tid < 16) sdinv[16 * (S) + tid] = dinv[cj + 16 * (S) + tid];                       \
+      __syncthreads();                                                                      \
+      GPG_QUAD_SUBST_PIECE(x, Ls, sdinv, q, S)                                               \
+      /* pin x: otherwise the FMAs of a piece are deferred into the next ones and everything spills */ \
+      _Pragma("unroll") for (int m = 0; m < 16; ++m) asm volatile("" : "+v"(x[m]));              \
+    }
+    GPG_TC_PIECE(0)
+    GPG_TC_PIECE(1)
+    GPG_TC_PIECE(2)
+    GPG_TC_PIECE(3)
+#undef GPG_TC_PIECE
     double* Xr = A + r0 + (tid >> 2) + (cj + q) * (size_t)ld;
 #pragma unroll
     for (int m = 0; m < 16; ++m) Xr[(size_t)(4 * m) * ld] = x[m];
@@ -1027,33 +1065,6 @@ __device__ __forceinline__ void direct_tile_gemm(d4 (&acc)[4][4], const double* 
 //     publish: __threadfence, flag(i, j) = 1 (agent-scope release)
 // Progress argument and bounded waits as in tile_chol_kernel.
 // ------------------------------------------------------------------------------------------------
-// Whole-workgroup wait on a completion flag (thread 0 polls, result shared through `sh`); 0 = timed out / aborted.
-__device__ __forceinline__ int wg_wait_flag(int* flag, int* abort_word, int* info, int* sh) {
-  if (threadIdx.x == 0) {
-    int spins = 0, ok = 1;
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-      if (++spins > GPG_TILE_SPIN_LIMIT || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-        __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        atomicMax(info, GPG_INFO_INTERNAL);
-        ok = 0;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(8);
-    }
-    *sh = ok;
-  }
-  __syncthreads();
-  const int ok = *sh;
-  __syncthreads();   // sh may be rewritten by the next wait
-  if (ok) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  return ok;
-}
-
-// X (128 rows x 128 columns, in place) <- X L^-T against a factorised 128 x 128 diagonal tile, whole workgroup.
-// Each lane quad carries TWO matrix rows (r and r + 64) through the substitution, so the 128 rows cost two
-// substitution sweeps instead of four and half the L-image traffic.  Column block 0 is read from memory
-// straight in the quad layout; block 1 first takes its update X1 L21^T on MFMA (two 64-row passes through
-// the LDS tile).  U: 4 * 16 * 80 doubles, Ls / sdinv: diagonal-block image.  Ends with a workgroup barrier.
 // The diagonal tile publishes its pieces as they are final -- L11 (flag_a, after the first potrf64), L21 (flag_c,
 // after its 64-row solve), L22 (flag_b = the tile's completion flag): column block 0 of this tile is solved and the
 // MFMA update of block 1 runs while the diagonal tile is still in its second potrf64.
@@ -1401,7 +1412,7 @@ static void launch_tile_chol(gpg_ctx* c, int c0) {
   const int Mt = (c->Npad - c0) / 64, Rt = (c->ld - c0) / 64;
   if (Mt <= 0) return;
   const TileMap& tm = get_tile_tasks(c, Mt, Rt);
-  const size_t nflag = (size_t)Mt * Rt + 1;
+  const size_t nflag = (size_t)Mt * Rt + 1 + 4 * (size_t)Mt;   // tile flags, abort word, four piece flags per diagonal tile
   if (c->tile_flags_cap < nflag) {
     if (c->tile_flags) (void)hipFree(c->tile_flags);
     (void)hipMalloc(&c->tile_flags, sizeof(int) * nflag);
@@ -1410,8 +1421,9 @@ static void launch_tile_chol(gpg_ctx* c, int c0) {
   (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
   const double m = (double)(c->Npad - c0);
   gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, m * m * m / 3.0);
+  int* abort_word = c->tile_flags + (size_t)Mt * Rt;
   hipLaunchKernelGGL(tile_chol_kernel, dim3(tm.n), dim3(256), 0, c->stream, c->A, c->ld, c0, Mt, (const int*)tm.dev,
-                     c->tile_flags, c->tile_flags + (nflag - 1), c->dinv, c->info, c->N);
+                     c->tile_flags, abort_word + 1, abort_word, c->dinv, c->info, c->N);
   gpg_prof_end(c);
 }
 
