@@ -164,7 +164,7 @@ def main():
     Npad = -(-N // 128) * 128
     if args.factor_mode == "blocked":
         dom_kernel = "gemm_dma_kernel<4> (trailing update C -= A_p A_p^T of the blocked schedule, 128x128 tiles)"
-    elif args.factor_mode == "tile64" or (args.factor_mode == "auto" and Npad <= 6144):
+    elif args.factor_mode == "tile64" or (args.factor_mode == "auto" and Npad <= 9216):
         dom_kernel = "tile_chol_kernel (whole Cholesky as one dataflow launch, 64x64 tiles, left-looking)"
     else:
         dom_kernel = "tile128_chol_kernel (whole Cholesky as one dataflow launch, 128x128 tiles, left-looking)"

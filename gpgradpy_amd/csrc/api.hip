@@ -131,7 +131,7 @@ int gpg_create(gpg_ctx** out, int device, int n_eval, int dim, int use_grad, int
   // factorisation schedule (measured, profiles/r01_tile_probe.log): one dataflow launch, 64-tile kernel for small
   // matrices (shorter dependency chain), 128-tile kernel above; chol_impl 0 = blocked right-looking (A/B runs)
   c->chol_impl = 1;
-  c->tail_cols = 6144;
+  c->tail_cols = 9216;
 #define CREATE_OK(call)                                                              \
   do {                                                                               \
     hipError_t e_ = (call);                                                          \
@@ -524,7 +524,7 @@ int gpg_prof_read(gpg_ctx* c, double ms[GPG_PROF_NCAT], long long count[GPG_PROF
 int gpg_set_factor_mode(gpg_ctx* c, int mode) {
   if (!c) return -1;
   switch (mode) {
-    case GPG_FACTOR_AUTO:    c->chol_impl = 1; c->tail_cols = 6144; break;
+    case GPG_FACTOR_AUTO:    c->chol_impl = 1; c->tail_cols = 9216; break;
     case GPG_FACTOR_BLOCKED: c->chol_impl = 0; c->tail_cols = 0; break;
     case GPG_FACTOR_TILE64:  c->chol_impl = 0; c->tail_cols = 1 << 30; break;
     case GPG_FACTOR_TILE128: c->chol_impl = 1; c->tail_cols = 0; break;

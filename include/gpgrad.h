@@ -169,7 +169,7 @@ int gpg_set_panel(gpg_ctx* ctx, int nb_outer);
 int gpg_set_lookahead(gpg_ctx* ctx, int on);
 
 /* Factorisation schedule.  GPG_FACTOR_AUTO (default): one dataflow launch -- the 64 x 64-tile kernel up to
- * 6144 padded columns, the 128 x 128-tile kernel above.  GPG_FACTOR_BLOCKED: right-looking blocked
+ * 9216 padded columns, the 128 x 128-tile kernel above.  GPG_FACTOR_BLOCKED: right-looking blocked
  * algorithm (panel solve + trailing update per panel, look-ahead on a second stream; A/B measurements and
  * the reference point for the parity tests).  GPG_FACTOR_TILE64 / GPG_FACTOR_TILE128 force one kernel. */
 enum gpg_factor_mode { GPG_FACTOR_AUTO = 0, GPG_FACTOR_BLOCKED = 1, GPG_FACTOR_TILE64 = 2, GPG_FACTOR_TILE128 = 3 };
