@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include "gpg_internal.h"
 
@@ -239,14 +240,14 @@ int gpg_set_data(gpg_ctx* c, const double* x, const double* data_vec, const doub
 static int internal_failure(gpg_ctx* c, const int* infos, int m) {
   for (int i = 0; i < m; ++i)
     if (infos[i] == GPG_INFO_INTERNAL) {
-      c->err = "dataflow Cholesky: dependency wait timed out (internal error)";
+      c->err = "dataflow Cholesky: a dependency wait timed out (another dataflow launch on this device?)";
       c->factor_valid = c->eval_ready = false;
       return -4;
     }
   return 0;
 }
 
-int gpg_lkd(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out) {
+static int gpg_lkd_once(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out) {
   int rc = check_hp(c, hp);
   if (rc) return rc;
   if (!out) { c->err = "out is NULL"; return -1; }
@@ -264,7 +265,7 @@ int gpg_lkd(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out) {
   return out->info;
 }
 
-int gpg_lkd_grad(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out, double* g_aa, double* g_inv) {
+static int gpg_lkd_grad_once(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out, double* g_aa, double* g_inv) {
   int rc = check_hp(c, hp);
   if (rc) return rc;
   if (!out || !g_aa || !g_inv) { c->err = "out / g_aa / g_inv is NULL"; return -1; }
@@ -303,8 +304,8 @@ int gpg_lkd_grad(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out, double* g_aa, d
   return 0;
 }
 
-int gpg_lkd_batch(gpg_ctx* c, int m, const double* hp_rows, int row_len, double eta, int wellcond,
-                  int closed_form_varK, gpg_lkd_out* out) {
+static int gpg_lkd_batch_once(gpg_ctx* c, int m, const double* hp_rows, int row_len, double eta, int wellcond,
+                              int closed_form_varK, gpg_lkd_out* out) {
   if (!c) return -1;
   if (m < 1 || !hp_rows || !out || row_len < c->d + 3) { c->err = "bad batch arguments (row_len >= d + 3)"; return -1; }
   GPG_HIP_OK(c, hipSetDevice(c->device));
@@ -335,7 +336,7 @@ int gpg_lkd_batch(gpg_ctx* c, int m, const double* hp_rows, int row_len, double 
   return 0;
 }
 
-int gpg_setup_eval(gpg_ctx* c, const gpg_hp* hp, double beta, double* alpha_out) {
+static int gpg_setup_eval_once(gpg_ctx* c, const gpg_hp* hp, double beta, double* alpha_out) {
   int rc = check_hp(c, hp);
   if (rc) return rc;
   GPG_HIP_OK(c, hipSetDevice(c->device));
@@ -365,6 +366,36 @@ int gpg_setup_eval(gpg_ctx* c, const gpg_hp* hp, double beta, double* alpha_out)
   c->err.clear();
   return 0;
 }
+
+// Dataflow launches that share the GPU with another such launch (another process / context on the same device) can
+// starve each other: every wait inside them is bounded, the launch drains and reports GPG_INFO_INTERNAL.  The call
+// is then repeated once with the blocked schedule, which has no inter-workgroup waits, and the context stays on it
+// (gpg_set_factor_mode re-arms the dataflow schedule; gpg_factor_fallbacks counts the switches).
+static int with_fallback(gpg_ctx* c, const std::function<int()>& f) {
+  int rc = f();
+  if (rc == -4 && c && (c->chol_impl != 0 || c->tail_cols != 0)) {
+    c->chol_impl = 0;
+    c->tail_cols = 0;
+    c->factor_fallbacks += 1;
+    rc = f();
+  }
+  return rc;
+}
+
+int gpg_lkd(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out) {
+  return with_fallback(c, [&] { return gpg_lkd_once(c, hp, out); });
+}
+int gpg_lkd_grad(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out, double* g_aa, double* g_inv) {
+  return with_fallback(c, [&] { return gpg_lkd_grad_once(c, hp, out, g_aa, g_inv); });
+}
+int gpg_lkd_batch(gpg_ctx* c, int m, const double* hp_rows, int row_len, double eta, int wellcond, int closed_form_varK,
+                  gpg_lkd_out* out) {
+  return with_fallback(c, [&] { return gpg_lkd_batch_once(c, m, hp_rows, row_len, eta, wellcond, closed_form_varK, out); });
+}
+int gpg_setup_eval(gpg_ctx* c, const gpg_hp* hp, double beta, double* alpha_out) {
+  return with_fallback(c, [&] { return gpg_setup_eval_once(c, hp, beta, alpha_out); });
+}
+int gpg_factor_fallbacks(gpg_ctx* c) { return c ? c->factor_fallbacks : -1; }
 
 static int predict_impl(gpg_ctx* c, int nx, const double* xq, double varK, double* mu, double* sig, double* sig2_raw,
                         double* dmudx, double* dsigdx);

@@ -477,17 +477,20 @@ panel_solve_kernel(const double* __restrict__ L, int ldl, const double* __restri
 //     publish: __threadfence, then flag(i, j) = 1 (agent-scope release)
 // A task only ever waits for tasks with a smaller index, and workgroups are dispatched in index order, so
 // the oldest unfinished workgroup can always run to completion (no deadlock whatever the residency).  As
-// a backstop every wait is bounded: on timeout the kernel raises the abort word, all workgroups drain, and
-// the host reports an internal error.  The serial chain per 64 columns is potrf -> substitution ->
+// a backstop every wait is bounded in time: on timeout the kernel raises the abort word, all workgroups drain, and
+// the host falls back on the blocked schedule.  (That does happen when two such launches share the GPU, e.g.
+// two processes on one device: each launch's waiting workgroups can hold the slots the other one's oldest
+// pending workgroup needs.)  The serial chain per 64 columns is potrf -> substitution ->
 // one 64-deep MFMA block (~20 us) instead of three dependent launches per step plus B_p and U_p.
 // ------------------------------------------------------------------------------------------------
-#define GPG_TILE_SPIN_LIMIT 400000   // x ~0.5 us per poll: ~0.2 s
+#define GPG_TILE_WAIT_TICKS 25000000ull   // bound of every dependency wait: 0.25 s of the 100 MHz s_memrealtime clock
 // Whole-workgroup wait on a completion flag (thread 0 polls, result shared through `sh`); 0 = timed out / aborted.
 __device__ __forceinline__ int wg_wait_flag(int* flag, int* abort_word, int* info, int* sh) {
   if (threadIdx.x == 0) {
-    int spins = 0, ok = 1;
+    int ok = 1;
+    const unsigned long long t_wait = __builtin_amdgcn_s_memrealtime();
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-      if (++spins > GPG_TILE_SPIN_LIMIT || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+      if (__builtin_amdgcn_s_memrealtime() - t_wait > GPG_TILE_WAIT_TICKS || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
         __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         atomicMax(info, GPG_INFO_INTERNAL);
         ok = 0;
@@ -545,13 +548,14 @@ tile_chol_kernel(double* A, int ld, int c0, int Mt, const int* __restrict__ task
   int kdone = 0;
   while (kdone < tj) {
     if (tid == 0) {
-      int kr = kdone, spins = 0;
+      int kr = kdone;
+      const unsigned long long t_wait = __builtin_amdgcn_s_memrealtime();
       for (;;) {
         while (kr < tj && __hip_atomic_load(frow_i + kr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 &&
                __hip_atomic_load(frow_j + kr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
           ++kr;
         if (kr > kdone) break;
-        if (++spins > GPG_TILE_SPIN_LIMIT || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        if (__builtin_amdgcn_s_memrealtime() - t_wait > GPG_TILE_WAIT_TICKS || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
           __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           atomicMax(info, GPG_INFO_INTERNAL);
           kr = -1;
@@ -1262,13 +1266,14 @@ tile128_chol_kernel(double* A, int ld, int Mt, const int* __restrict__ tasks, in
   while (kdone < tj) {
     GPG_T(q0)
     if (tid == 0) {
-      int kr = kdone, spins = 0;
+      int kr = kdone;
+      const unsigned long long t_wait = __builtin_amdgcn_s_memrealtime();
       for (;;) {
         while (kr < tj && __hip_atomic_load(frow_i + kr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 &&
                __hip_atomic_load(frow_j + kr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
           ++kr;
         if (kr > kdone) break;
-        if (++spins > GPG_TILE_SPIN_LIMIT || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        if (__builtin_amdgcn_s_memrealtime() - t_wait > GPG_TILE_WAIT_TICKS || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
           __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           atomicMax(info, GPG_INFO_INTERNAL);
           kr = -1;

@@ -672,6 +672,11 @@ class GaussianProcess(HparaOptz):
         if rc != 0:
             raise _lib.GpgError(f'gpg_set_factor_mode failed ({rc}): {self._err()}')
 
+    def factor_fallbacks(self):
+        """How often a dataflow factorisation timed out (device shared with another such launch) and the call was
+        repeated with the blocked schedule; the context stays on 'blocked' until set_factor_mode is called."""
+        return int(self._lib.gpg_factor_fallbacks(self._ctx)) if self._ctx else 0
+
     def download_chofac(self):
         """(P L, True) of the factor currently on the device (Kernel.py:252) as a SciPy cho_factor pair."""
         fac = np.empty((self.n_data, self.n_data))

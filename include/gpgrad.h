@@ -174,6 +174,11 @@ int gpg_set_lookahead(gpg_ctx* ctx, int on);
  * the reference point for the parity tests).  GPG_FACTOR_TILE64 / GPG_FACTOR_TILE128 force one kernel. */
 enum gpg_factor_mode { GPG_FACTOR_AUTO = 0, GPG_FACTOR_BLOCKED = 1, GPG_FACTOR_TILE64 = 2, GPG_FACTOR_TILE128 = 3 };
 int gpg_set_factor_mode(gpg_ctx* ctx, int mode);
+/* Two dataflow launches sharing one device (two processes / contexts on the same GPU) can starve each other: every
+ * wait inside the launch is bounded (0.25 s), the launch then drains, and the library repeats the call with the
+ * blocked schedule and keeps the context on it until gpg_set_factor_mode is called again.  Returns how often that
+ * happened (results are unaffected; rc -4 is only returned if the blocked repeat fails too). */
+int gpg_factor_fallbacks(gpg_ctx* ctx);
 
 /* Library / device facts for logs: writes "gfx950 MI355X ..." style text. */
 int gpg_device_info(int device, char* buf, int buflen);

@@ -5,3 +5,43 @@ import pytest
 def test_graft_entry_smoke():
     import __graft_entry__ as g
     g.smoke()
+
+
+def _shared_gpu_worker(rank, q):
+    import numpy as np
+    import gpgradpy_amd
+    from oracle import gp_oracle as orc
+    n, d = 1100, 8                                    # N = 9900 > 9216: the 128-tile dataflow kernel
+    X, f, g = orc.synthetic_design(n, d, seed=11)
+    GP = gpgradpy_amd.GaussianProcess(d, True, 'SqExp', 'precon')
+    GP.set_data(X, f, np.zeros(n), g, np.zeros((n, d)))
+    hp_x0 = np.random.default_rng(3).uniform(-2.0, -0.7, (6, d))
+    ln = GP.calc_lkd_batch(hp_x0)
+    q.put((rank, ln, GP.factor_fallbacks()))
+
+
+@pytest.mark.gpu
+def test_two_processes_share_one_gpu():
+    """Two dataflow factorisations on the same device can starve each other (each launch's waiting workgroups may hold
+    the slots the other one's oldest pending workgroup needs).  Every wait is bounded; the library then repeats the
+    call with the blocked schedule.  Either way both processes must get the single-process numbers."""
+    import multiprocessing as mp
+    import numpy as np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_shared_gpu_worker, args=(r, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=300) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    q1 = ctx.Queue()
+    p = ctx.Process(target=_shared_gpu_worker, args=(0, q1))
+    p.start()
+    _, ref, fb = q1.get(timeout=300)
+    p.join(timeout=60)
+    assert fb == 0                                     # alone on the device: no fallback
+    for _, ln, _ in res:
+        assert np.all(np.isfinite(ln))
+        np.testing.assert_allclose(ln, ref, rtol=1e-9)
