@@ -1016,43 +1016,48 @@ gemm_direct_kernel(double* __restrict__ C, int ldc, const double* __restrict__ A
   }
 }
 
-// direct_tile_gemm: main loop of gemm_direct_kernel as a device function.  acc (wave tile 64 x 64) -=
-// A[64 x 4 nstep] B[64 x 4 nstep]^T with operand fragments loaded straight from global memory, PF k-steps
-// ahead.  pa / pb: this lane's fragment sources of k-step 0 (row lane&15 of the wave's slice, k = lane>>4);
-// nstep a positive multiple of PF + 1.  No LDS, no barrier.
+// direct_tile_gemm_x2: the MFMA loop of gemm_direct_kernel as a device function, with 16-byte fragment loads:
+// acc (wave tile 64 x 64) -= A[64 x 4 nstep] B[64 x 4 nstep]^T, operand fragments straight from global memory,
+// PF k-steps ahead, no LDS, no barrier; nstep a positive multiple of PF + 1.  Lane lane&15 = t owns the two
+// adjacent rows 2t, 2t+1 of each 32-row group of its 64-row slices, so one global_load_dwordx4 feeds two MFMA
+// operand blocks: 4 load instructions per k-step instead of 8 (the texture-address unit handles ~4 lanes per
+// clock whatever the access width; measured +1.5 %).  acc[2p + e][2g + m][r] of lane (t, l4) <-> tile row 32 g + 2 t + m, tile column
+// 32 p + 2 (4 r + l4) + e.  pa / pb: slice + 2 t, k = l4.
 template <int PF>
-__device__ __forceinline__ void direct_tile_gemm(d4 (&acc)[4][4], const double* pa, int lda, const double* pb, int ldb,
-                                                 int nstep) {
+__device__ __forceinline__ void direct_tile_gemm_x2(d4 (&acc)[4][4], const double* pa, int lda, const double* pb, int ldb,
+                                                    int nstep) {
   const size_t sa = (size_t)4 * lda, sb = (size_t)4 * ldb;
-  double f[PF + 1][8];
-#define GPG_DR_LOAD(set)                                                              \
+  double2 fa0[PF + 1], fa1[PF + 1], fb0[PF + 1], fb1[PF + 1];
+#define GPG_DX_LOAD(set)                                                              \
   {                                                                                   \
-    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) f[set][mi] = pa[mi * 16];         \
-    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) f[set][4 + ni] = pb[ni * 16];     \
+    fa0[set] = *reinterpret_cast<const double2*>(pa);                                 \
+    fa1[set] = *reinterpret_cast<const double2*>(pa + 32);                            \
+    fb0[set] = *reinterpret_cast<const double2*>(pb);                                 \
+    fb1[set] = *reinterpret_cast<const double2*>(pb + 32);                            \
     pa += sa;                                                                         \
     pb += sb;                                                                         \
   }
-#define GPG_DR_MFMA(set)                                                              \
+#define GPG_DX_MFMA(set)                                                              \
   {                                                                                   \
-    double fm[4];                                                                     \
-    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) fm[mi] = -f[set][mi];             \
+    const double fm[4] = {-fa0[set].x, -fa0[set].y, -fa1[set].x, -fa1[set].y};        \
+    const double fn[4] = {fb0[set].x, fb0[set].y, fb1[set].x, fb1[set].y};            \
     _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                   \
       _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                 \
-        acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(f[set][4 + ni], fm[mi], acc[ni][mi], 0, 0, 0); \
+        acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fn[ni], fm[mi], acc[ni][mi], 0, 0, 0); \
   }
 #pragma unroll
-  for (int s = 0; s < PF; ++s) GPG_DR_LOAD(s)
+  for (int s = 0; s < PF; ++s) GPG_DX_LOAD(s)
   for (int s0 = 0; s0 < nstep; s0 += PF + 1) {
 #pragma unroll
     for (int u = 0; u <= PF; ++u) {
-      if (s0 + u + PF < nstep) GPG_DR_LOAD((u + PF) % (PF + 1))
+      if (s0 + u + PF < nstep) GPG_DX_LOAD((u + PF) % (PF + 1))
       __builtin_amdgcn_sched_barrier(0);
-      GPG_DR_MFMA(u)
+      GPG_DX_MFMA(u)
       __builtin_amdgcn_sched_barrier(0);
     }
   }
-#undef GPG_DR_LOAD
-#undef GPG_DR_MFMA
+#undef GPG_DX_LOAD
+#undef GPG_DX_MFMA
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1252,14 +1257,19 @@ tile128_chol_kernel(double* A, int ld, int Mt, const int* __restrict__ tasks, in
   const unsigned long long tk_start = __builtin_amdgcn_s_memrealtime();
   unsigned long long tk_spin = 0, tk_gemm = 0, tk_runs = 0;
 #endif
+  // accumulator layout of direct_tile_gemm_x2: acc[2p + e][2g + m][r] <-> row 32 g + 2 l15 + m, column 32 p + 2 (4 r + l4) + e
   d4 acc[4][4];
-  double* Cw = A + r0 + wm * 64 + l15 + (cj + wn * 64 + l4) * (size_t)ld;
+  double* Cw = A + r0 + wm * 64 + 2 * l15 + (cj + wn * 64 + 2 * l4) * (size_t)ld;
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int g = 0; g < 2; ++g)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[ni][mi][r] = Cw[mi * 16 + (size_t)(ni * 16 + 4 * r) * ld];
+      for (int r = 0; r < 4; ++r) {
+        const double2 v = *reinterpret_cast<const double2*>(Cw + 32 * g + (size_t)(32 * (ni >> 1) + 8 * r + (ni & 1)) * ld);
+        acc[ni][2 * g][r] = v.x;
+        acc[ni][2 * g + 1][r] = v.y;
+      }
 
   // ---- (1) left-looking accumulation ----------------------------------------------------------------------------
   int kdone = 0;
@@ -1289,8 +1299,8 @@ tile128_chol_kernel(double* A, int ld, int Mt, const int* __restrict__ tasks, in
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     GPG_T(q1)
     const size_t ck = 128 * (size_t)kdone;
-    direct_tile_gemm<3>(acc, A + r0 + wm * 64 + l15 + (ck + l4) * (size_t)ld, ld, A + cj + wn * 64 + l15 + (ck + l4) * (size_t)ld,
-                        ld, 32 * (kr - kdone));
+    direct_tile_gemm_x2<3>(acc, A + r0 + wm * 64 + 2 * l15 + (ck + l4) * (size_t)ld, ld,
+                           A + cj + wn * 64 + 2 * l15 + (ck + l4) * (size_t)ld, ld, 32 * (kr - kdone));
     __syncthreads();   // sh_kr may be rewritten
     GPG_T(q2)
 #ifdef GPG_STAMP
@@ -1311,15 +1321,21 @@ tile128_chol_kernel(double* A, int ld, int Mt, const int* __restrict__ tasks, in
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) t128_U[(ni * 16 + 4 * r + l4) * 80 + mi * 16 + l15] = acc[ni][mi][r];
+        for (int r = 0; r < 4; ++r)
+          t128_U[(32 * (ni >> 1) + 8 * r + 2 * l4 + (ni & 1)) * 80 + 32 * (mi >> 1) + 2 * l15 + (mi & 1)] = acc[ni][mi][r];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   } else if (!(ti == tj && wm == 0)) {
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int g = 0; g < 2; ++g)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Cw[mi * 16 + (size_t)(ni * 16 + 4 * r) * ld] = acc[ni][mi][r];
+        for (int r = 0; r < 4; ++r) {
+          double2 v;
+          v.x = acc[ni][2 * g][r];
+          v.y = acc[ni][2 * g + 1][r];
+          *reinterpret_cast<double2*>(Cw + 32 * g + (size_t)(32 * (ni >> 1) + 8 * r + (ni & 1)) * ld) = v;
+        }
   }
   if (ti != tj) __syncthreads();
   if (tile128_finalize(A, ld, r0, cj, ti == tj, frow_j + tj, flag_a + tj, flag_a + Mt + tj, abort_word, dinv, info, N) == 0) return;
