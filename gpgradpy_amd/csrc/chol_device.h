@@ -1,0 +1,458 @@
+// Device-side building blocks shared by the blocked (cholesky.hip) and the dataflow (cholesky_dataflow.hip)
+// factorisations: potrf64 core, quad-row substitution, MFMA tile loops, flag wait.  gfx950 only.
+#pragma once
+#include "gpg_internal.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// potrf64: Cholesky of one 64 x 64 diagonal block by ONE wave, lane i <-> matrix row i.
+// Left-looking over four 16-column sub-blocks: (1) update the sub-block's 16 entries of every row with
+// the finished columns (LDS image, column-major: own entry per lane + wave-uniform broadcast reads),
+// (2) factor the 16 columns in registers (pivot / column broadcast by v_readlane; rows below the
+// diagonal sub-block are scaled in the same sweep), (3) publish to LDS and to global memory.
+// Entries above the diagonal carry garbage that never feeds a valid entry.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, lane);
+  hi = __builtin_amdgcn_readlane(hi, lane);
+  return __hiloint2double(hi, lo);
+}
+
+// Wave-level core: `src` is the 64 x 64 block to factor (column-major, leading dimension sld; global memory
+// or an LDS tile), the factor goes to `blk` (global, leading dimension ld) and its reciprocal pivots to dinv.
+// St is a [64][64] LDS scratch private to the calling wave (St[k][i] = L[i][k]).  Returns the 1-based index
+// of the first non-positive / NaN pivot inside the block (0 = none), identical in every lane.
+// Per 16-column sub-block: (1) the update with the finished columns runs on MFMA (operands straight from the
+// St image; 4 row tiles x K/4 instructions) and is transposed into the lane = row layout through the part
+// of St that this sub-block is about to fill; (2) the 16 columns are factored in registers, pivot and
+// column broadcast by v_readlane.  The reciprocal pivot comes from v_rsq_f64 plus two coupled
+// Goldschmidt steps (sqrt and 1/sqrt to ~1 ulp in 7 dependent operations; the pivot chain is the critical
+// path of every factorisation in this file).
+__device__ __forceinline__ int potrf64_wave(const double* src, int sld, double (*St)[64], double* __restrict__ blk, int ld,
+                                            double* __restrict__ dinv, int* piece_flags = nullptr) {
+  const int i = threadIdx.x & 63, l15 = i & 15, l4 = i >> 4;
+  int bad = 0;
+  double myinv = 0.0;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    double a[16];
+    if (s == 0) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) a[c] = src[i + (size_t)c * sld];
+    } else {
+      d4 acc[4];
+#pragma unroll
+      for (int R = 0; R < 4; ++R)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[R][r] = src[(16 * R + l15) + (size_t)(16 * s + 4 * r + l4) * sld];
+#pragma unroll
+      for (int kk = 0; kk < 4 * s; ++kk) {
+        const double fn = St[4 * kk + l4][16 * s + l15];
+        double fm[4];
+#pragma unroll
+        for (int R = 0; R < 4; ++R) fm[R] = -St[4 * kk + l4][16 * R + l15];
+#pragma unroll
+        for (int R = 0; R < 4; ++R) acc[R] = __builtin_amdgcn_mfma_f64_16x16x4f64(fn, fm[R], acc[R], 0, 0, 0);
+      }
+#pragma unroll
+      for (int R = 0; R < 4; ++R)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) St[16 * s + 4 * r + l4][16 * R + l15] = acc[R][r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same wave writes and reads St: ordering only
+#pragma unroll
+      for (int c = 0; c < 16; ++c) a[c] = St[16 * s + c][i];
+    }
+    // Pivot chain, software-pipelined: the next pivot a[c+1][c+1] - L[c+1][c]^2 only needs the diagonal lane's own
+    // scaled entry, so it is formed and broadcast BEFORE column c is applied to the other columns; the 15 - c
+    // broadcast-FMA updates then fill the latency of the next v_rsq_f64 + Goldschmidt chain.
+    double ajj = readlane_d(a[0], 16 * s);
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      bad = (bad == 0 && !(ajj > 0.0)) ? 16 * s + c + 1 : bad;   // first non-positive / NaN pivot (LAPACK info)
+      const double y0 = __builtin_amdgcn_rsq(ajj);
+      double g = ajj * y0, h = 0.5 * y0;
+      double r = __builtin_fma(-h, g, 0.5);
+      g = __builtin_fma(g, r, g);
+      h = __builtin_fma(h, r, h);
+      r = __builtin_fma(-h, g, 0.5);
+      const double dj = __builtin_fma(g, r, g);        // sqrt(ajj)
+      const double inv = 2.0 * __builtin_fma(h, r, h); // 1 / sqrt(ajj)
+      const double lc = a[c] * inv;
+      if (c < 15) {
+        const double t = __builtin_fma(-lc, lc, a[c + 1]);     // exact in the lane of row 16 s + c + 1
+        ajj = readlane_d(t, 16 * s + c + 1);
+      }
+      a[c] = (i == 16 * s + c) ? dj : lc;
+      myinv = (i == 16 * s + c) ? inv : myinv;   // reciprocal pivots for the panel solves: lane j keeps 1 / L_jj
+#pragma unroll
+      for (int k2 = c + 1; k2 < 16; ++k2) a[k2] -= a[c] * readlane_d(a[c], 16 * s + k2);
+      // pin the updated columns here: left to itself the compiler defers these FMAs to their consumers and
+      // keeps all 120 broadcast multipliers of the sub-block alive in SGPRs (spilled through v_writelane)
+#pragma unroll
+      for (int k2 = c + 1; k2 < 16; ++k2) asm volatile("" : "+v"(a[k2]));
+    }
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      St[16 * s + c][i] = a[c];
+      if (i >= 16 * s + c) blk[i + (size_t)(16 * s + c) * ld] = a[c];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (i >= 16 * s && i < 16 * s + 16) dinv[i] = myinv;
+    if (piece_flags) {   // dataflow kernels: these 16 columns (and their reciprocal pivots) are final -- publish them
+      __threadfence();
+      if (i == 0) __hip_atomic_store(piece_flags + s, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  return bad;
+}
+
+
+// DPP quad_perm broadcast of lane Q of every lane quad (see trsm64_kernel / GPG_QUAD_SUBST)
+template <int Q>
+__device__ __forceinline__ double quad_bcast(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, Q * 0x55, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, Q * 0x55, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// wave_tile_gemm: acc (wave tile 16 x 64 of a 64 x 64 workgroup tile) -= A[64 x K] B[64 x K]^T with
+// K = 16 nchunk (nchunk a positive multiple of 4).  Both operands are staged through LDS in 16-deep
+// chunks; the global loads run two chunks ahead in registers (one wave per SIMD: nothing else hides
+// the L2 latency).  ga / gb are this thread's staging sources (row pair sp, k-row sk of chunk 0).
+// Ends without a barrier: the caller synchronises before re-using sA / sB.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_tile_gemm(d4 (&acc)[4], const double* ga, int lda, const double* gb, int ldb, int nchunk,
+                                               double* sA, double* sB, int w, int l15, int l4, int sp, int sk) {
+  constexpr int KB = 16, SA = 80, BUF = KB * SA;
+  const size_t a8 = (size_t)8 * lda, b8 = (size_t)8 * ldb;
+  double2 ra0_a, ra0_b, rb0_a, rb0_b, ra1_a, ra1_b, rb1_a, rb1_b;
+#define GPG_PS_GLOAD(set)                                        \
+  ra##set##_a = *reinterpret_cast<const double2*>(ga);           \
+  ra##set##_b = *reinterpret_cast<const double2*>(ga + a8);      \
+  rb##set##_a = *reinterpret_cast<const double2*>(gb);           \
+  rb##set##_b = *reinterpret_cast<const double2*>(gb + b8);      \
+  ga += 2 * a8;                                                  \
+  gb += 2 * b8;
+#define GPG_PS_SSTORE(buf, set)                                                              \
+  {                                                                                          \
+    double2 v0, v1;                                                                          \
+    v0.x = -ra##set##_a.x; v0.y = -ra##set##_a.y; v1.x = -ra##set##_b.x; v1.y = -ra##set##_b.y;  \
+    *reinterpret_cast<double2*>(sA + (buf) * BUF + sk * SA + 2 * sp) = v0;                    \
+    *reinterpret_cast<double2*>(sA + (buf) * BUF + (sk + 8) * SA + 2 * sp) = v1;              \
+    *reinterpret_cast<double2*>(sB + (buf) * BUF + sk * SA + 2 * sp) = rb##set##_a;           \
+    *reinterpret_cast<double2*>(sB + (buf) * BUF + (sk + 8) * SA + 2 * sp) = rb##set##_b;     \
+  }
+#define GPG_PS_COMPUTE(buf)                                                                  \
+  _Pragma("unroll") for (int kk = 0; kk < KB; kk += 4) {                                      \
+    const double fm = sA[(buf) * BUF + (kk + l4) * SA + 16 * w + l15];                        \
+    double fn[4];                                                                            \
+    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) fn[ni] = sB[(buf) * BUF + (kk + l4) * SA + ni * 16 + l15]; \
+    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                          \
+      acc[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(fn[ni], fm, acc[ni], 0, 0, 0);           \
+  }
+  GPG_PS_GLOAD(0);            // chunk 0
+  GPG_PS_GLOAD(1);            // chunk 1
+  GPG_PS_SSTORE(0, 0);
+  __syncthreads();
+  for (int ch = 0; ch < nchunk; ch += 2) {   // unrolled by two so that the register sets are static
+    if (ch + 2 < nchunk) { GPG_PS_GLOAD(0); }      // chunk ch + 2
+    GPG_PS_COMPUTE(0);                             // chunk ch
+    GPG_PS_SSTORE(1, 1);                           // chunk ch + 1
+    __syncthreads();
+    if (ch + 3 < nchunk) { GPG_PS_GLOAD(1); }      // chunk ch + 3
+    GPG_PS_COMPUTE(1);                             // chunk ch + 1
+    if (ch + 2 < nchunk) { GPG_PS_SSTORE(0, 0); }  // chunk ch + 2
+    __syncthreads();
+  }
+#undef GPG_PS_GLOAD
+#undef GPG_PS_SSTORE
+#undef GPG_PS_COMPUTE
+}
+
+// quad-row substitution x <- x L^-T of one matrix row spread over a lane quad (see trsm64_kernel): x[m] is
+// column 4m + q; Ls is the LDS image Ls[j][q][m] = L[4m + q][j], sdinv the reciprocal pivots.
+#define GPG_QUAD_SUBST(x, Ls, sdinv, q)                                                      \
+  {                                                                                         \
+    double lv[2][16];                                                                       \
+    _Pragma("unroll") for (int m = 0; m < 16; ++m) lv[0][m] = Ls[0][q][m];                   \
+    _Pragma("unroll") for (int mj = 0; mj < 16; ++mj) {                                      \
+      GPG_QS_STEP(x, Ls, sdinv, q, 0)                                                        \
+      GPG_QS_STEP(x, Ls, sdinv, q, 1)                                                        \
+      GPG_QS_STEP(x, Ls, sdinv, q, 2)                                                        \
+      GPG_QS_STEP(x, Ls, sdinv, q, 3)                                                        \
+    }                                                                                       \
+  }
+#define GPG_QS_STEP(x, Ls, sdinv, q, QJ)                                                     \
+  {                                                                                         \
+    constexpr int cur = QJ & 1, nxt = cur ^ 1;                                               \
+    const int jc = 4 * mj + QJ;                                                             \
+    const int jn = jc + 1 < 64 ? jc + 1 : 63;                                               \
+    const int m0n = (jc + 1) >> 2;                                                          \
+    _Pragma("unroll") for (int m = 0; m < 16; ++m) if (m >= m0n) lv[nxt][m] = Ls[jn][q][m]; \
+    const double xs = x[mj] * sdinv[jc];                                                    \
+    x[mj] = (q == QJ) ? xs : x[mj];                                                         \
+    const double xj = quad_bcast<QJ>(x[mj]);                                                \
+    if (QJ < 3) {                                                                           \
+      const double t = x[mj] - xj * lv[cur][mj];                                            \
+      x[mj] = (q > QJ) ? t : x[mj];                                                         \
+    }                                                                                       \
+    _Pragma("unroll") for (int m = mj + 1; m < 16; ++m) x[m] -= xj * lv[cur][m];            \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+  }
+
+// one 16-column piece (columns 16 s .. 16 s + 15) of GPG_QUAD_SUBST: the dataflow kernels substitute against the
+// diagonal block while it is still being factored, piece by piece as its columns are published
+#define GPG_QUAD_SUBST_PIECE(x, Ls, sdinv, q, s)                                             \
+  {                                                                                         \
+    double lv[2][16];                                                                       \
+    _Pragma("unroll") for (int m = 0; m < 16; ++m) lv[0][m] = Ls[16 * (s)][q][m];            \
+    _Pragma("unroll") for (int mj = 4 * (s); mj < 4 * (s) + 4; ++mj) {                       \
+      GPG_QS_STEP(x, Ls, sdinv, q, 0)                                                        \
+      GPG_QS_STEP(x, Ls, sdinv, q, 1)                                                        \
+      GPG_QS_STEP(x, Ls, sdinv, q, 2)                                                        \
+      GPG_QS_STEP(x, Ls, sdinv, q, 3)                                                        \
+    }                                                                                       \
+  }
+// two matrix rows per lane quad (x0, x1): the L values are read once for both rows
+#define GPG_QUAD_SUBST2(x0, x1, Ls, sdinv, q)                                                \
+  {                                                                                         \
+    double lv[2][16];                                                                       \
+    _Pragma("unroll") for (int m = 0; m < 16; ++m) lv[0][m] = Ls[0][q][m];                   \
+    _Pragma("unroll") for (int mj = 0; mj < 16; ++mj) {                                      \
+      GPG_QS2_STEP(x0, x1, Ls, sdinv, q, 0)                                                  \
+      GPG_QS2_STEP(x0, x1, Ls, sdinv, q, 1)                                                  \
+      GPG_QS2_STEP(x0, x1, Ls, sdinv, q, 2)                                                  \
+      GPG_QS2_STEP(x0, x1, Ls, sdinv, q, 3)                                                  \
+    }                                                                                       \
+  }
+#define GPG_QS2_STEP(x0, x1, Ls, sdinv, q, QJ)                                               \
+  {                                                                                         \
+    constexpr int cur = QJ & 1, nxt = cur ^ 1;                                               \
+    const int jc = 4 * mj + QJ;                                                             \
+    const int jn = jc + 1 < 64 ? jc + 1 : 63;                                               \
+    const int m0n = (jc + 1) >> 2;                                                          \
+    _Pragma("unroll") for (int m = 0; m < 16; ++m) if (m >= m0n) lv[nxt][m] = Ls[jn][q][m]; \
+    const double dv = sdinv[jc];                                                            \
+    const double xs0 = x0[mj] * dv, xs1 = x1[mj] * dv;                                      \
+    x0[mj] = (q == QJ) ? xs0 : x0[mj];                                                      \
+    x1[mj] = (q == QJ) ? xs1 : x1[mj];                                                      \
+    const double xj0 = quad_bcast<QJ>(x0[mj]), xj1 = quad_bcast<QJ>(x1[mj]);                \
+    if (QJ < 3) {                                                                           \
+      const double t0 = x0[mj] - xj0 * lv[cur][mj], t1 = x1[mj] - xj1 * lv[cur][mj];        \
+      x0[mj] = (q > QJ) ? t0 : x0[mj];                                                      \
+      x1[mj] = (q > QJ) ? t1 : x1[mj];                                                      \
+    }                                                                                       \
+    _Pragma("unroll") for (int m = mj + 1; m < 16; ++m) {                                    \
+      x0[m] -= xj0 * lv[cur][m];                                                            \
+      x1[m] -= xj1 * lv[cur][m];                                                            \
+    }                                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+  }
+
+#ifdef GPG_STAMP   // diagnostic build of tools/gemm_probe.hip only: per-wave cycle shares of the loop phases
+__device__ unsigned long long* g_stamp_buf;
+#define GPG_T(var) unsigned long long var; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0);
+#else
+#define GPG_T(var)
+#endif
+
+// ------------------------------------------------------------------------------------------------
+// panel_solve_kernel: X <- X L^-T for `rows` rows against a factorised nb x nb diagonal block
+// (nb a multiple of 64) in ONE launch.  A workgroup owns 64 rows; wave w owns rows 16w .. 16w+15.
+// Left-looking over the 64-column blocks j of the panel:
+//   (1) T_j = X_j - sum_{k<j} X_k L_jk^T   on MFMA (wave tile 16 x 64, K = 64 j; X_k is the workgroup's own
+//       earlier output re-read through L1/L2, L_jk comes from L2; both staged through LDS, 16-deep chunks)
+//   (2) X_j = T_j L_jj^-T by the quad-row substitution of trsm64_kernel (the accumulators are transposed
+//       through a wave-private LDS tile into the 4-lanes-per-row layout)
+// Replaces nb/64 trsm64 + nb/64 - 1 small-K gemm launches, whose ~15 us dependent-launch latency each
+// (not their flops) set the cost of B_p.
+// ------------------------------------------------------------------------------------------------
+// Body shared with the dataflow kernels: solves the 64 rows starting at X (rows_left of them are real) with
+// the whole workgroup.  U = staging / transposition buffer (4 * 16 * 80 doubles), Ls / sdinv = image of the
+// current diagonal block.  Ends with a workgroup barrier.
+__device__ __forceinline__ void panel_solve_rows64(const double* __restrict__ L, int ldl, const double* __restrict__ dinv,
+                                                   double* X, int ldx, int rows, int nb, double* U, double (*Ls)[4][18],
+                                                   double* sdinv) {
+  constexpr int KB = 16, SA = 80;                     // SA: +128 B pad keeps ds_read_b64 conflict-free
+  constexpr int BUF = KB * SA;                        // doubles per staging buffer
+  double* const sA = U;
+  double* const sB = U + 2 * BUF;
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  // MFMA-side row of this lane, substitution-side row of this lane (both inside the wave's 16 rows)
+  int rowc = 16 * w + l15;
+  const bool c_ok = rowc < rows;
+  rowc = c_ok ? rowc : rows - 1;
+  const int q = tid & 3;
+  int rowt = tid >> 2;
+  const bool t_ok = rowt < rows;
+  rowt = t_ok ? rowt : rows - 1;
+
+  // staging: thread -> (row pair p, k) ; two double2 per operand per chunk
+  const int sp = tid & 31, sk = tid >> 5;             // sk in 0..7, second load at sk + 8
+  int rowa = 2 * sp;
+  rowa = rowa + 1 < rows ? rowa : (rows >= 2 ? rows - 2 : 0);
+
+  double cx[16], li[16];   // next block's X tile (MFMA layout) and L_jj (linear), prefetched
+#define GPG_PS_PREFETCH(jb)                                                                   \
+  {                                                                                          \
+    const double* Cw = X + rowc + (size_t)(64 * (jb) + l4) * ldx;                             \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) cx[i] = Cw[(size_t)((i >> 2) * 16 + 4 * (i & 3)) * ldx]; \
+    const double* Ljj = L + (size_t)(64 * (jb)) + (size_t)(64 * (jb)) * ldl;                   \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                          \
+      const int t = tid + 256 * i;                                                           \
+      li[i] = Ljj[(t & 63) + (size_t)(t >> 6) * ldl];                                         \
+    }                                                                                        \
+  }
+  GPG_PS_PREFETCH(0)
+#ifdef GPG_STAMP
+  unsigned long long ps_pre = 0, ps_gemm = 0, ps_tr = 0, ps_sub = 0, ps_st = 0;
+#endif
+  for (int j = 0; j < nb / 64; ++j) {
+    GPG_T(p0)
+    // ---- accumulators start as X_j; LDS image of L_jj for the substitution (nobody reads Ls during the MFMA
+    //      phase).  Both were fetched into registers one block ahead, behind the previous substitution. ----------
+    d4 acc[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[ni][r] = cx[4 * ni + r];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int t = tid + 256 * i, jj = t >> 6, k = t & 63;
+      Ls[jj][k & 3][k >> 2] = li[i];
+    }
+    if (tid < 64) sdinv[tid] = dinv[64 * j + tid];
+    // ---- (1) MFMA phase -----------------------------------------------------------------------------------
+    const int nchunk = 4 * j;                          // K = 64 j in chunks of 16
+    GPG_T(p1)
+    if (nchunk > 0)
+      wave_tile_gemm(acc, X + rowa + (size_t)sk * ldx, ldx, L + (size_t)(64 * j + 2 * sp) + (size_t)sk * ldl, ldl, nchunk, sA, sB,
+                     w, l15, l4, sp, sk);
+    __syncthreads();   // staging buffers free (they become Ts), L_jj image complete
+    GPG_T(p2)
+    // ---- (2) substitution phase: accumulators -> Ts[col][row] -> 4 lanes per row ---------------------------
+    {
+      double* Ts = U;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ts[(ni * 16 + 4 * r + l4) * SA + 16 * w + l15] = acc[ni][r];
+    }
+    __syncthreads();
+    double x[16];
+    {
+      const double* Tr = U + q * SA + (tid >> 2);
+#pragma unroll
+      for (int m = 0; m < 16; ++m) x[m] = Tr[(4 * m) * SA];
+    }
+    if (j + 1 < nb / 64) GPG_PS_PREFETCH(j + 1)
+    GPG_T(p3)
+    GPG_QUAD_SUBST(x, Ls, sdinv, q)
+    GPG_T(p4)
+    if (t_ok) {
+      double* Xr = X + rowt + (size_t)(64 * j + q) * ldx;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) Xr[(size_t)(4 * m) * ldx] = x[m];
+    }
+    __syncthreads();   // X_j visible to the whole workgroup (vmcnt(0) + barrier), Ts / Ls free again
+    GPG_T(p5)
+#ifdef GPG_STAMP
+    ps_pre += p1 - p0; ps_gemm += p2 - p1; ps_tr += p3 - p2; ps_sub += p4 - p3; ps_st += p5 - p4;
+#endif
+  }
+#undef GPG_PS_PREFETCH
+#ifdef GPG_STAMP
+  if (lane == 0 && blockIdx.x < 4096 && g_stamp_buf != nullptr) {
+    unsigned long long* o = g_stamp_buf + ((size_t)blockIdx.x * 4 + w) * 8;
+    o[0] = ps_pre; o[1] = ps_gemm; o[2] = ps_tr; o[3] = ps_sub; o[4] = ps_st;
+  }
+#endif
+}
+
+
+// ------------------------------------------------------------------------------------------------
+#define GPG_TILE_WAIT_TICKS 25000000ull   // bound of every dependency wait: 0.25 s of the 100 MHz s_memrealtime clock
+// Whole-workgroup wait on a completion flag (thread 0 polls, result shared through `sh`); 0 = timed out / aborted.
+__device__ __forceinline__ int wg_wait_flag(int* flag, int* abort_word, int* info, int* sh) {
+  if (threadIdx.x == 0) {
+    int ok = 1;
+    const unsigned long long t_wait = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+      if (__builtin_amdgcn_s_memrealtime() - t_wait > GPG_TILE_WAIT_TICKS || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicMax(info, GPG_INFO_INTERNAL);
+        ok = 0;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    *sh = ok;
+  }
+  __syncthreads();
+  const int ok = *sh;
+  __syncthreads();   // sh may be rewritten by the next wait
+  if (ok) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return ok;
+}
+
+// X (128 rows x 128 columns, in place) <- X L^-T against a factorised 128 x 128 diagonal tile, whole workgroup.
+// Each lane quad carries TWO matrix rows (r and r + 64) through the substitution, so the 128 rows cost two
+// substitution sweeps instead of four and half the L-image traffic.  Column block 0 is read from memory
+// straight in the quad layout; block 1 first takes its update X1 L21^T on MFMA (two 64-row passes through
+// the LDS tile).  U: 4 * 16 * 80 doubles, Ls / sdinv: diagonal-block image.  Ends with a workgroup barrier.
+
+// direct_tile_gemm_x2: the MFMA loop of gemm_direct_kernel as a device function, with 16-byte fragment loads:
+// acc (wave tile 64 x 64) -= A[64 x 4 nstep] B[64 x 4 nstep]^T, operand fragments straight from global memory,
+// PF k-steps ahead, no LDS, no barrier; nstep a positive multiple of PF + 1.  Lane lane&15 = t owns the two
+// adjacent rows 2t, 2t+1 of each 32-row group of its 64-row slices, so one global_load_dwordx4 feeds two MFMA
+// operand blocks: 4 load instructions per k-step instead of 8 (the texture-address unit handles ~4 lanes per
+// clock whatever the access width; measured +1.5 %).  acc[2p + e][2g + m][r] of lane (t, l4) <-> tile row 32 g + 2 t + m, tile column
+// 32 p + 2 (4 r + l4) + e.  pa / pb: slice + 2 t, k = l4.
+template <int PF>
+__device__ __forceinline__ void direct_tile_gemm_x2(d4 (&acc)[4][4], const double* pa, int lda, const double* pb, int ldb,
+                                                    int nstep) {
+  const size_t sa = (size_t)4 * lda, sb = (size_t)4 * ldb;
+  double2 fa0[PF + 1], fa1[PF + 1], fb0[PF + 1], fb1[PF + 1];
+#define GPG_DX_LOAD(set)                                                              \
+  {                                                                                   \
+    fa0[set] = *reinterpret_cast<const double2*>(pa);                                 \
+    fa1[set] = *reinterpret_cast<const double2*>(pa + 32);                            \
+    fb0[set] = *reinterpret_cast<const double2*>(pb);                                 \
+    fb1[set] = *reinterpret_cast<const double2*>(pb + 32);                            \
+    pa += sa;                                                                         \
+    pb += sb;                                                                         \
+  }
+#define GPG_DX_MFMA(set)                                                              \
+  {                                                                                   \
+    const double fm[4] = {-fa0[set].x, -fa0[set].y, -fa1[set].x, -fa1[set].y};        \
+    const double fn[4] = {fb0[set].x, fb0[set].y, fb1[set].x, fb1[set].y};            \
+    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                   \
+      _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                 \
+        acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fn[ni], fm[mi], acc[ni][mi], 0, 0, 0); \
+  }
+#pragma unroll
+  for (int s = 0; s < PF; ++s) GPG_DX_LOAD(s)
+  for (int s0 = 0; s0 < nstep; s0 += PF + 1) {
+#pragma unroll
+    for (int u = 0; u <= PF; ++u) {
+      if (s0 + u + PF < nstep) GPG_DX_LOAD((u + PF) % (PF + 1))
+      __builtin_amdgcn_sched_barrier(0);
+      GPG_DX_MFMA(u)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#undef GPG_DX_LOAD
+#undef GPG_DX_MFMA
+}
+
+
+}  // namespace

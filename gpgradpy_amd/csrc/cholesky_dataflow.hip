@@ -1,0 +1,494 @@
+// Dataflow (left-looking, tile task graph) Cholesky for gfx950: the whole factorisation as ONE launch.
+// Replaces scipy.linalg.cho_factor(Kcov_precon, lower=True) (reference Kernel.py:251; LAPACK dpotrf).
+// tile_chol_kernel: 64 x 64 tiles (small matrices), tile128_chol_kernel: 128 x 128 tiles.
+#include "chol_device.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// tile_chol_kernel: dataflow (left-looking) Cholesky of the trailing block A[c0:, c0:] in 64 x 64 tiles,
+// ONE launch.  Used where the blocked algorithm is latency-bound: the last few thousand columns of a large
+// matrix and small matrices as a whole.  Workgroup b owns tile (i, j) = tasks[b] (column-major task order,
+// rows i >= j; the right-hand-side rows below the matrix are ordinary tile rows):
+//     acc  = A_ij - sum_{k<j} L_ik L_jk^T      MFMA, k-blocks consumed as soon as their flags are up
+//     i==j : L_jj = chol(acc) by wave 0 (potrf64_wave), reciprocal pivots to dinv
+//     i> j : L_ij = acc L_jj^-T by the quad-row substitution, once flag(j, j) is up
+//     publish: __threadfence, then flag(i, j) = 1 (agent-scope release)
+// A task only ever waits for tasks with a smaller index, and workgroups are dispatched in index order, so
+// the oldest unfinished workgroup can always run to completion (no deadlock whatever the residency).  As
+// a backstop every wait is bounded in time: on timeout the kernel raises the abort word, all workgroups drain, and
+// the host falls back on the blocked schedule.  (That does happen when two such launches share the GPU, e.g.
+// two processes on one device: each launch's waiting workgroups can hold the slots the other one's oldest
+// pending workgroup needs.)  The serial chain per 64 columns is potrf -> substitution ->
+// one 64-deep MFMA block (~20 us) instead of three dependent launches per step plus B_p and U_p.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2)
+tile_chol_kernel(double* A, int ld, int c0, int Mt, const int* __restrict__ tasks, int* flags, int* pieces, int* abort_word,
+                 double* __restrict__ dinv, int* __restrict__ info, int N) {
+  constexpr int KB = 16, SA = 80, BUF = KB * SA;
+  __shared__ __attribute__((aligned(16))) double U[4 * BUF];      // staging sA[2] | sB[2]; later the tile Ts[64][SA]
+  __shared__ __attribute__((aligned(16))) double Ls[64][4][18];   // L_jj image (i > j) / potrf scratch St[64][64] (i == j)
+  __shared__ double sdinv[64];
+  __shared__ int sh_kr;
+  double* const sA = U;
+  double* const sB = U + 2 * BUF;
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int task = tasks[blockIdx.x];
+  const int ti = task & 0xffff, tj = task >> 16;
+  const size_t r0 = (size_t)c0 + 64 * (size_t)ti;        // first matrix row of the tile
+  const size_t cj = (size_t)c0 + 64 * (size_t)tj;        // first matrix column of the tile
+  const int q = tid & 3;
+  const int sp = tid & 31, sk = tid >> 5;
+  int* const frow_i = flags + (size_t)ti * Mt;           // flags of tile row i
+  int* const frow_j = flags + (size_t)tj * Mt;
+
+  // accumulators start as A_ij
+  d4 acc[4];
+  {
+    const double* Cw = A + r0 + 16 * w + l15 + (cj + l4) * (size_t)ld;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[ni][r] = Cw[(size_t)(ni * 16 + 4 * r) * ld];
+  }
+
+  // ---- (1) left-looking accumulation over the finished tile columns ------------------------------------------
+  int kdone = 0;
+  while (kdone < tj) {
+    if (tid == 0) {
+      int kr = kdone;
+      const unsigned long long t_wait = __builtin_amdgcn_s_memrealtime();
+      for (;;) {
+        while (kr < tj && __hip_atomic_load(frow_i + kr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 &&
+               __hip_atomic_load(frow_j + kr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+          ++kr;
+        if (kr > kdone) break;
+        if (__builtin_amdgcn_s_memrealtime() - t_wait > GPG_TILE_WAIT_TICKS || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+          __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          atomicMax(info, GPG_INFO_INTERNAL);
+          kr = -1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+      }
+      sh_kr = kr;
+    }
+    __syncthreads();
+    const int kr = sh_kr;
+    if (kr < 0) return;                                  // abort: drain
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the producers' tiles are visible from here on
+    const size_t ck = (size_t)c0 + 64 * (size_t)kdone;
+    wave_tile_gemm(acc, A + r0 + 2 * sp + (ck + sk) * (size_t)ld, ld, A + cj + 2 * sp + (ck + sk) * (size_t)ld, ld,
+                   4 * (kr - kdone), sA, sB, w, l15, l4, sp, sk);
+    __syncthreads();                                     // staging buffers free again; sh_kr may be rewritten
+    kdone = kr;
+  }
+
+  // ---- (2) accumulators -> LDS tile Ts[col][row] --------------------------------------------------------------
+  {
+    double* Ts = U;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Ts[(ni * 16 + 4 * r + l4) * SA + 16 * w + l15] = acc[ni][r];
+  }
+  if (ti == tj) {
+    __syncthreads();
+    if (w == 0) {   // diagonal tile: factor it (one wave; entries above the diagonal are garbage nobody reads)
+      double* blk = A + r0 + cj * (size_t)ld;
+      const int bad = potrf64_wave(U, SA, reinterpret_cast<double(*)[64]>(&Ls[0][0][0]), blk, ld, dinv + cj, pieces + 4 * tj);
+      if (bad && lane == 0 && (int)cj + bad - 1 < N) atomicCAS(info, 0, (int)cj + bad);
+    }
+  } else {
+    // substitute against the diagonal tile of this column piece by piece, as its 16-column pieces are published
+    __syncthreads();
+    double x[16];
+    {
+      const double* Tr = U + q * SA + (tid >> 2);
+#pragma unroll
+      for (int m = 0; m < 16; ++m) x[m] = Tr[(4 * m) * SA];
+    }
+    const double* Ljj = A + cj + cj * (size_t)ld;
+#define GPG_TC_PIECE(S)                                                                      \
+    {                                                                                       \
+      if (!wg_wait_flag(pieces + 4 * tj + (S), abort_word, info, &sh_kr)) return;            \
+      _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                        \
+        const int t = tid + 256 * u, jj = 16 * (S) + (t >> 6), k = t & 63;                   \
+        Ls[jj][k & 3][k >> 2] = Ljj[k + (size_t)jj * ld];                                    \
+      }                                                                                     \
+      if (tid < 16) sdinv[16 * (S) + tid] = dinv[cj + 16 * (S) + tid];                       \
+      __syncthreads();                                                                      \
+      GPG_QUAD_SUBST_PIECE(x, Ls, sdinv, q, S)                                               \
+      /* pin x: otherwise the FMAs of a piece are deferred into the next ones and everything spills */ \
+      _Pragma("unroll") for (int m = 0; m < 16; ++m) asm volatile("" : "+v"(x[m]));              \
+    }
+    GPG_TC_PIECE(0)
+    GPG_TC_PIECE(1)
+    GPG_TC_PIECE(2)
+    GPG_TC_PIECE(3)
+#undef GPG_TC_PIECE
+    double* Xr = A + r0 + (tid >> 2) + (cj + q) * (size_t)ld;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) Xr[(size_t)(4 * m) * ld] = x[m];
+  }
+  // ---- (3) publish ----------------------------------------------------------------------------------------------
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(frow_i + tj, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// tile128_chol_kernel: the whole factorisation as ONE dataflow launch over 128 x 128 tiles (left-looking).
+// Workgroup b owns tile (i, j) = tasks[b], column-major task order, rows i >= j (the right-hand-side rows
+// below the matrix are one more tile row):
+//     acc  = A_ij - sum_{k<j} L_ik L_jk^T   the direct-fragment MFMA loop of gemm_direct_kernel over every finished tile
+//                                          column, consumed in runs as the flags come up.  The C tile is read
+//                                          once and written once per factorisation (the right-looking update
+//                                          streams it once per panel) and there is no launch chain at all.
+//     i==j : potrf of the 128 x 128 tile inside the workgroup (potrf64, 64-row substitution, 64 x 64 MFMA
+//            update, potrf64)
+//     i> j : L_ij = acc L_jj^-T, two 64-row passes of panel_solve_rows64 against the 128-wide diagonal tile
+//     publish: __threadfence, flag(i, j) = 1 (agent-scope release)
+// Progress argument and bounded waits as in tile_chol_kernel.
+// ------------------------------------------------------------------------------------------------
+// The diagonal tile publishes its pieces as they are final -- L11 (flag_a, after the first potrf64), L21 (flag_c,
+// after its 64-row solve), L22 (flag_b = the tile's completion flag): column block 0 of this tile is solved and the
+// MFMA update of block 1 runs while the diagonal tile is still in its second potrf64.
+__device__ __forceinline__ int tile_solve_rows128(const double* L, int ldl, const double* dinv, double* X, int ldx, double* U,
+                                                  double (*Ls)[4][18], double* sdinv, int* flag_a, int* flag_c, int* flag_b,
+                                                  int* abort_word, int* info, int* sh) {
+  constexpr int SA = 80, BUF = 16 * SA;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int q = tid & 3, rr = tid >> 2;
+  const int sp = tid & 31, sk = tid >> 5;
+  double x0[16], x1[16], li[16];
+  // ---- column block 0 ----------------------------------------------------------------------------------------
+  {
+    const double* Xr = X + rr + (size_t)q * ldx;     // own rows: in flight while the flag is polled
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      x0[m] = Xr[(size_t)(4 * m) * ldx];
+      x1[m] = Xr[64 + (size_t)(4 * m) * ldx];
+    }
+    if (!wg_wait_flag(flag_a, abort_word, info, sh)) return 0;
+    for (int t = tid; t < 64 * 64; t += 256) {
+      const int jj = t >> 6, k = t & 63;
+      Ls[jj][k & 3][k >> 2] = L[k + (size_t)jj * ldl];
+    }
+    if (tid < 64) sdinv[tid] = dinv[tid];
+  }
+  __syncthreads();
+  GPG_QUAD_SUBST2(x0, x1, Ls, sdinv, q)
+  {
+    double* Xr = X + rr + (size_t)q * ldx;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      Xr[(size_t)(4 * m) * ldx] = x0[m];
+      Xr[64 + (size_t)(4 * m) * ldx] = x1[m];
+    }
+  }
+  if (!wg_wait_flag(flag_c, abort_word, info, sh)) return 0;   // barrier inside: X1 visible to the workgroup, Ls free
+  // ---- column block 1: T2 -= X1 L21^T for the two row halves, each transposed through the LDS tile ---------------
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    d4 acc[4];
+    const double* Cw = X + 64 * h + 16 * w + l15 + (size_t)(64 + l4) * ldx;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[ni][r] = Cw[(size_t)(ni * 16 + 4 * r) * ldx];
+    wave_tile_gemm(acc, X + 64 * h + 2 * sp + (size_t)sk * ldx, ldx, L + 64 + 2 * sp + (size_t)sk * ldl, ldl, 4, U, U + 2 * BUF,
+                   w, l15, l4, sp, sk);
+    __syncthreads();
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) U[(ni * 16 + 4 * r + l4) * SA + 16 * w + l15] = acc[ni][r];
+    __syncthreads();
+    const double* Tr = U + q * SA + rr;
+    if (h == 0) {
+#pragma unroll
+      for (int m = 0; m < 16; ++m) x0[m] = Tr[(4 * m) * SA];
+    } else {
+#pragma unroll
+      for (int m = 0; m < 16; ++m) x1[m] = Tr[(4 * m) * SA];
+    }
+    __syncthreads();   // tile consumed before the next pass stages into U again
+  }
+  if (!wg_wait_flag(flag_b, abort_word, info, sh)) return 0;
+  {   // image of L22
+    const double* L22 = L + 64 + (size_t)64 * ldl;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int t = tid + 256 * i;
+      li[i] = L22[(t & 63) + (size_t)(t >> 6) * ldl];
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int t = tid + 256 * i, jj = t >> 6, k = t & 63;
+      Ls[jj][k & 3][k >> 2] = li[i];
+    }
+    if (tid < 64) sdinv[tid] = dinv[64 + tid];
+  }
+  __syncthreads();
+  GPG_QUAD_SUBST2(x0, x1, Ls, sdinv, q)
+  {
+    double* Xr = X + rr + (size_t)(64 + q) * ldx;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      Xr[(size_t)(4 * m) * ldx] = x0[m];
+      Xr[64 + (size_t)(4 * m) * ldx] = x1[m];
+    }
+  }
+  __syncthreads();
+  return 1;
+}
+
+// Finalisation of a 128 x 128 tile that already sits updated in memory (kept out of line so that its register
+// needs do not leak into the MFMA loop of the kernel).  Returns 0 if the wait for the diagonal tile timed out.
+__shared__ __attribute__((aligned(16))) double t128_U[4 * 16 * 80];   // staging / transposition tile of the finalisation
+__shared__ __attribute__((aligned(16))) double t128_Ls[64][4][18];    // diagonal-block image / potrf scratch
+__shared__ double t128_sdinv[64];
+
+__device__ __noinline__ int tile128_finalize(double* A, int ld, size_t r0, size_t cj, int is_diag, int* flag_jj, int* flag_a,
+                                             int* flag_c, int* abort_word, double* dinv, int* info, int N) {
+  constexpr int SA = 80;
+  double* const U = t128_U;
+  double (*const Ls)[4][18] = t128_Ls;
+  double* const sdinv = t128_sdinv;
+  __shared__ int sh_ok;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+#ifdef GPG_STAMP
+  unsigned long long* fo = (g_stamp_buf != nullptr && blockIdx.x < 16384) ? g_stamp_buf + 16384 * 8 + (size_t)blockIdx.x * 8 : nullptr;
+#define GPG_FS(k) if (tid == 0 && fo) fo[k] = __builtin_amdgcn_s_memrealtime();
+#else
+#define GPG_FS(k)
+#endif
+  GPG_FS(0)
+  if (is_diag) {
+    double* blk = A + cj + cj * (size_t)ld;
+    double (*St)[64] = reinterpret_cast<double(*)[64]>(&Ls[0][0][0]);   // potrf scratch over the Ls region
+    if (w == 0) {   // A11 was left in the LDS tile by this same wave (no barrier, no trip through memory)
+      const int bad = potrf64_wave(U, SA, St, blk, ld, dinv + cj);
+      if (bad && lane == 0 && (int)cj + bad - 1 < N) atomicCAS(info, 0, (int)cj + bad);
+      __threadfence();   // L11 and its reciprocal pivots (all written by this wave) are published early
+      if (lane == 0) __hip_atomic_store(flag_a, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();   // also drains the other waves' stores of A21 / A22
+    GPG_FS(1)
+    // L21 = A21 L11^-T
+    panel_solve_rows64(blk, ld, dinv + cj, blk + 64, ld, 64, 64, U, Ls, sdinv);
+    __threadfence();   // L21 is final (every thread stored part of it; the solve ended with a barrier)
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(flag_c, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    GPG_FS(2)
+    // A22 -= L21 L21^T on MFMA, then factor it from the LDS tile
+    const int sp = tid & 31, sk = tid >> 5;
+    d4 a2[4];
+    const double* C2 = blk + 64 + 16 * w + l15 + (size_t)(64 + l4) * ld;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a2[ni][r] = C2[(size_t)(ni * 16 + 4 * r) * ld];
+    const double* g21 = blk + 64 + 2 * sp + (size_t)sk * ld;
+    wave_tile_gemm(a2, g21, ld, g21, ld, 4, U, U + 2 * 16 * SA, w, l15, l4, sp, sk);
+    __syncthreads();
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) U[(ni * 16 + 4 * r + l4) * SA + 16 * w + l15] = a2[ni][r];
+    __syncthreads();
+    GPG_FS(3)
+    if (w == 0) {
+      const int bad = potrf64_wave(U, SA, St, blk + 64 + (size_t)64 * ld, ld, dinv + cj + 64);
+      if (bad && lane == 0 && (int)cj + 64 + bad - 1 < N) atomicCAS(info, 0, (int)cj + 64 + bad);
+    }
+    GPG_FS(4)
+    return 1;
+  }
+  GPG_FS(1)
+  const double* Ljj = A + cj + cj * (size_t)ld;
+  double* X = A + r0 + cj * (size_t)ld;
+  if (!tile_solve_rows128(Ljj, ld, dinv + cj, X, ld, U, Ls, sdinv, flag_a, flag_c, flag_jj, abort_word, info, &sh_ok)) return 0;
+  GPG_FS(2)
+  GPG_FS(3)
+  return 1;
+}
+
+__global__ void __launch_bounds__(256, 2)
+tile128_chol_kernel(double* A, int ld, int Mt, const int* __restrict__ tasks, int* flags, int* flag_a, int* abort_word,
+                    double* __restrict__ dinv, int* __restrict__ info, int N) {
+  __shared__ int sh_kr;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w & 1, wn = w >> 1;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int task = tasks[blockIdx.x];
+  const int ti = task & 0xffff, tj = task >> 16;
+  const size_t r0 = 128 * (size_t)ti, cj = 128 * (size_t)tj;
+  int* const frow_i = flags + (size_t)ti * Mt;
+  int* const frow_j = flags + (size_t)tj * Mt;
+
+#ifdef GPG_STAMP
+  const unsigned long long tk_start = __builtin_amdgcn_s_memrealtime();
+  unsigned long long tk_spin = 0, tk_gemm = 0, tk_runs = 0;
+#endif
+  // accumulator layout of direct_tile_gemm_x2: acc[2p + e][2g + m][r] <-> row 32 g + 2 l15 + m, column 32 p + 2 (4 r + l4) + e
+  d4 acc[4][4];
+  double* Cw = A + r0 + wm * 64 + 2 * l15 + (cj + wn * 64 + 2 * l4) * (size_t)ld;
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double2 v = *reinterpret_cast<const double2*>(Cw + 32 * g + (size_t)(32 * (ni >> 1) + 8 * r + (ni & 1)) * ld);
+        acc[ni][2 * g][r] = v.x;
+        acc[ni][2 * g + 1][r] = v.y;
+      }
+
+  // ---- (1) left-looking accumulation ----------------------------------------------------------------------------
+  int kdone = 0;
+  while (kdone < tj) {
+    GPG_T(q0)
+    if (tid == 0) {
+      int kr = kdone;
+      const unsigned long long t_wait = __builtin_amdgcn_s_memrealtime();
+      for (;;) {
+        while (kr < tj && __hip_atomic_load(frow_i + kr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 &&
+               __hip_atomic_load(frow_j + kr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+          ++kr;
+        if (kr > kdone) break;
+        if (__builtin_amdgcn_s_memrealtime() - t_wait > GPG_TILE_WAIT_TICKS || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+          __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          atomicMax(info, GPG_INFO_INTERNAL);
+          kr = -1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+      sh_kr = kr;
+    }
+    __syncthreads();
+    const int kr = sh_kr;
+    if (kr < 0) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    GPG_T(q1)
+    const size_t ck = 128 * (size_t)kdone;
+    direct_tile_gemm_x2<3>(acc, A + r0 + wm * 64 + 2 * l15 + (ck + l4) * (size_t)ld, ld,
+                           A + cj + wn * 64 + 2 * l15 + (ck + l4) * (size_t)ld, ld, 32 * (kr - kdone));
+    __syncthreads();   // sh_kr may be rewritten
+    GPG_T(q2)
+#ifdef GPG_STAMP
+    tk_spin += q1 - q0; tk_gemm += q2 - q1; ++tk_runs;
+#endif
+    kdone = kr;
+  }
+
+#ifdef GPG_STAMP
+  const unsigned long long tk_fin0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  // ---- (2) the updated tile goes back to memory; the finalisation works on it in place.  Diagonal tile: the
+  //      top-left 64 x 64 block goes straight into the LDS tile its own wave factors next, the strictly upper
+  //      block is dropped. ---------------------------------------------------------------------------------------
+  if (ti == tj && w == 0) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          t128_U[(32 * (ni >> 1) + 8 * r + 2 * l4 + (ni & 1)) * 80 + 32 * (mi >> 1) + 2 * l15 + (mi & 1)] = acc[ni][mi][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  } else if (!(ti == tj && wm == 0)) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          double2 v;
+          v.x = acc[ni][2 * g][r];
+          v.y = acc[ni][2 * g + 1][r];
+          *reinterpret_cast<double2*>(Cw + 32 * g + (size_t)(32 * (ni >> 1) + 8 * r + (ni & 1)) * ld) = v;
+        }
+  }
+  if (ti != tj) __syncthreads();
+  if (tile128_finalize(A, ld, r0, cj, ti == tj, frow_j + tj, flag_a + tj, flag_a + Mt + tj, abort_word, dinv, info, N) == 0) return;
+  // ---- (3) publish ----------------------------------------------------------------------------------------------
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(frow_i + tj, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef GPG_STAMP
+  if (tid == 0 && g_stamp_buf != nullptr && blockIdx.x < 16384) {
+    unsigned long long* o = g_stamp_buf + (size_t)blockIdx.x * 8;
+    o[0] = tk_start; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = tk_spin; o[3] = tk_gemm; o[4] = tk_runs;
+    o[5] = tk_fin0; o[6] = (unsigned long long)task;
+  }
+#endif
+}
+
+
+// Column-major task list of the dataflow factorisation (Mt tile columns, Rt >= Mt tile rows), cached per shape.
+const TileMap& get_tile_tasks(gpg_ctx* c, int Mt, int Rt) {
+  const unsigned long long key = (1ull << 63) | ((unsigned long long)Mt << 20) | (unsigned)Rt;
+  auto it = c->tilemaps.find(key);
+  if (it != c->tilemaps.end()) return it->second;
+  std::vector<int> list;
+  for (int j = 0; j < Mt; ++j)
+    for (int i = j; i < Rt; ++i) list.push_back(i | (j << 16));
+  TileMap tm;
+  tm.n = (int)list.size();
+  tm.dev = nullptr;
+  (void)hipMalloc(&tm.dev, sizeof(int) * list.size());
+  (void)hipMemcpy(tm.dev, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice);
+  return c->tilemaps.emplace(key, tm).first->second;
+}
+
+// Factor A[c0:, c0:] (and carry the rows below the matrix) with the dataflow kernel, on c->stream.
+static void launch_tile_chol(gpg_ctx* c, int c0) {
+  const int Mt = (c->Npad - c0) / 64, Rt = (c->ld - c0) / 64;
+  if (Mt <= 0) return;
+  const TileMap& tm = get_tile_tasks(c, Mt, Rt);
+  const size_t nflag = (size_t)Mt * Rt + 1 + 4 * (size_t)Mt;   // tile flags, abort word, four piece flags per diagonal tile
+  if (c->tile_flags_cap < nflag) {
+    if (c->tile_flags) (void)hipFree(c->tile_flags);
+    (void)hipMalloc(&c->tile_flags, sizeof(int) * nflag);
+    c->tile_flags_cap = nflag;
+  }
+  (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
+  const double m = (double)(c->Npad - c0);
+  gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, m * m * m / 3.0);
+  int* abort_word = c->tile_flags + (size_t)Mt * Rt;
+  hipLaunchKernelGGL(tile_chol_kernel, dim3(tm.n), dim3(256), 0, c->stream, c->A, c->ld, c0, Mt, (const int*)tm.dev,
+                     c->tile_flags, abort_word + 1, abort_word, c->dinv, c->info, c->N);
+  gpg_prof_end(c);
+}
+
+// The whole matrix with the 128-tile dataflow kernel, on c->stream.
+static void launch_tile128_chol(gpg_ctx* c) {
+  const int Mt = c->Npad / 128, Rt = c->ld / 128;
+  const TileMap& tm = get_tile_tasks(c, Mt, Rt);
+  const size_t nflag = (size_t)Mt * Rt + 1 + 2 * Mt;   // tile flags, abort word, two early flags per diagonal tile
+  if (c->tile_flags_cap < nflag) {
+    if (c->tile_flags) (void)hipFree(c->tile_flags);
+    (void)hipMalloc(&c->tile_flags, sizeof(int) * nflag);
+    c->tile_flags_cap = nflag;
+  }
+  (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
+  const double m = (double)c->Npad;
+  gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, m * m * m / 3.0);
+  int* abort_word = c->tile_flags + (size_t)Mt * Rt;
+  hipLaunchKernelGGL(tile128_chol_kernel, dim3(tm.n), dim3(256), 0, c->stream, c->A, c->ld, Mt, (const int*)tm.dev,
+                     c->tile_flags, abort_word + 1, abort_word, c->dinv, c->info, c->N);
+  gpg_prof_end(c);
+}
+
+}  // namespace
+
+void gpg_launch_tile_chol(gpg_ctx* c, int c0) { launch_tile_chol(c, c0); }
+void gpg_launch_tile128_chol(gpg_ctx* c) { launch_tile128_chol(c); }

@@ -99,6 +99,8 @@ void gpg_launch_prep(gpg_ctx* c, const AsmParams& p, double var_fval, double var
                      double s0, double t0, double s1, double t1);
 void gpg_launch_assembly(gpg_ctx* c, const AsmParams& p);
 void gpg_launch_cross(gpg_ctx* c, const AsmParams& p, int nx, int nxp);   // Wt <- P^-1 Kyx (transposed)
+void gpg_launch_tile_chol(gpg_ctx* c, int c0);                          // dataflow factorisation of A[c0:, c0:], 64-tiles
+void gpg_launch_tile128_chol(gpg_ctx* c);                              // dataflow factorisation, 128-tiles (whole matrix)
 void gpg_cholesky(gpg_ctx* c);                                           // blocked right-looking, in place
 void gpg_forward_rows(gpg_ctx* c, double* W, int ldw, int rows);         // W <- W L^-T (rows = RHS rows)
 void gpg_launch_lkd_reduce(gpg_ctx* c, int slot);                        // writes scal[slot*8 ..]

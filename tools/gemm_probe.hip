@@ -1,6 +1,7 @@
 // Diagnostic (not product code): times the trailing-update kernel alone on a square lower update and
 // ablates its phases (build with -DGPG_ABLATE_CLOAD / -DGPG_ABLATE_DMA).
 #include "../gpgradpy_amd/csrc/cholesky.hip"
+#include "../gpgradpy_amd/csrc/cholesky_dataflow.hip"
 #include <cstdio>
 #include <cstdlib>
 void gpg_prof_begin(gpg_ctx*, int, double) {}

@@ -1,6 +1,7 @@
 // Diagnostic (not product code): times the fused B_p kernel (panel_solve_kernel) alone and, built with
 // -DGPG_STAMP, prints the cycle shares of its phases.
 #include "../gpgradpy_amd/csrc/cholesky.hip"
+#include "../gpgradpy_amd/csrc/cholesky_dataflow.hip"
 #include <cstdio>
 #include <cstdlib>
 void gpg_prof_begin(gpg_ctx*, int, double) {}

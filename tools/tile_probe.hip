@@ -1,6 +1,7 @@
 // Diagnostic (not product code): runs the dataflow Cholesky kernels alone on a synthetic SPD matrix; with
 // -DGPG_STAMP writes a per-task timeline (start, end, spin / MFMA cycles, runs) to gpurun_out/tile_timeline.csv.
 #include "../gpgradpy_amd/csrc/cholesky.hip"
+#include "../gpgradpy_amd/csrc/cholesky_dataflow.hip"
 #include <cstdio>
 #include <cstdlib>
 void gpg_prof_begin(gpg_ctx*, int, double) {}
