@@ -115,6 +115,7 @@ def main():
     ap.add_argument("--lookahead", type=int, default=-1, help="1/0 force the two-stream look-ahead on/off (blocked schedule)")
     ap.add_argument("--factor-mode", default="auto", choices=["auto", "blocked", "tile64", "tile128"],
                     help="Cholesky schedule (include/gpgrad.h gpg_factor_mode); default: one dataflow launch")
+    ap.add_argument("--batch", type=int, default=-1, help="restart rows per batched launch on small matrices (gpg_set_batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-all", action="store_true", help="time every kernel category (adds event overhead)")
     args = ap.parse_args()
@@ -161,6 +162,8 @@ def main():
     if args.lookahead >= 0:
         GP.set_lookahead(args.lookahead)
     GP.set_factor_mode(args.factor_mode)
+    if args.batch >= 0:
+        GP.set_batch(args.batch)
     Npad = -(-N // 128) * 128
     if args.factor_mode == "blocked":
         dom_kernel = "gemm_dma_kernel<4> (trailing update C -= A_p A_p^T of the blocked schedule, 128x128 tiles)"

@@ -181,7 +181,7 @@ void gpg_destroy(gpg_ctx* c) {
   for (auto& pe : c->prof_pending) { (void)hipEventDestroy(pe.e0); (void)hipEventDestroy(pe.e1); }
   for (auto& ev : c->prof_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   double* bufs[] = {c->A, c->Xt, c->y, c->noise, c->dvec, c->invp, c->zvec, c->tmpv, c->dinv, c->scal, c->Wt, c->xq_dev,
-                    c->musig, c->gradbuf, c->dense_tmp, c->Wfull, c->Minv, c->gpartial};
+                    c->musig, c->gradbuf, c->dense_tmp, c->Wfull, c->Minv, c->gpartial, c->batchA, c->batchV};
   for (double* b : bufs) if (b) (void)hipFree(b);
   if (c->info) (void)hipFree(c->info);
   if (c->gpos) (void)hipFree(c->gpos);
@@ -213,6 +213,7 @@ int gpg_set_grad_mask(gpg_ctx* c, const unsigned char* use_grad_pt) {
   c->have_data = false;
   c->factor_valid = c->eval_ready = false;
   if (c->dense_tmp) { (void)hipFree(c->dense_tmp); c->dense_tmp = nullptr; }
+  if (c->batchA) { (void)hipFree(c->batchA); (void)hipFree(c->batchV); c->batchA = c->batchV = nullptr; c->batch_cap = 0; }
   if (c->Wfull) { (void)hipFree(c->Wfull); (void)hipFree(c->Minv); c->Wfull = c->Minv = nullptr; }
   if (c->Wt) { (void)hipFree(c->Wt); (void)hipFree(c->xq_dev); (void)hipFree(c->musig); (void)hipFree(c->gradbuf); c->Wt = c->xq_dev = c->musig = c->gradbuf = nullptr; c->xq_cap = 0; }
   return 0;
@@ -325,7 +326,64 @@ static int gpg_lkd_batch_once(gpg_ctx* c, int m, const double* hp_rows, int row_
     if (rc) return rc;
   }
   GPG_HIP_OK(c, hipMemsetAsync(c->info, 0, sizeof(int) * m, c->stream));
-  for (int i = 0; i < m; ++i) enqueue_lkd(c, &hps[i], i);
+  // Small matrices (the 64-tile dataflow regime): one factorisation is latency-bound and leaves most of the chip
+  // idle, so up to batch_max restart rows are assembled into separate workspaces and factorised by ONE launch.
+  const bool small = c->tail_cols > 0 && c->Npad <= c->tail_cols;
+  int bmax = c->batch_max;
+  if (bmax < 0) {   // auto: enough matrices to put ~8k tiles in flight (8 at cfg2's 40 tile columns, 64 for tiny matrices)
+    const long mt = c->Npad / 64, ntask = mt * (mt + 5) / 2;
+    bmax = (int)(8192 / (ntask > 0 ? ntask : 1));
+    bmax = bmax < 8 ? 8 : (bmax > 64 ? 64 : bmax);
+  }
+  int B = (small && bmax > 1 && m > 1) ? (m < bmax ? m : bmax) : 1;
+  if (B > 1) {
+    const size_t bytesA = sizeof(double) * c->A_elems;
+    while (B > 1 && bytesA * B > ((size_t)16 << 30)) --B;          // at most 16 GB of extra workspaces
+    if (B > c->batch_cap) {
+      if (c->batchA) (void)hipFree(c->batchA);
+      if (c->batchV) (void)hipFree(c->batchV);
+      c->batchA = c->batchV = nullptr; c->batch_cap = 0;
+      if (hipMalloc(&c->batchA, bytesA * B) != hipSuccess || hipMalloc(&c->batchV, sizeof(double) * 3 * c->Npad * B) != hipSuccess) {
+        if (c->batchA) (void)hipFree(c->batchA);
+        c->batchA = c->batchV = nullptr;
+        (void)hipGetLastError();
+        B = 1;                                                       // no room: one matrix at a time
+      } else {
+        c->batch_cap = B;
+      }
+    }
+  }
+  if (B > 1) {
+    double *A0 = c->A, *dvec0 = c->dvec, *invp0 = c->invp, *dinv0 = c->dinv;
+    int* info0 = c->info;
+    for (int r0 = 0; r0 < m; r0 += B) {
+      const int Bg = (m - r0) < B ? (m - r0) : B;
+      for (int b = 0; b < Bg; ++b) {
+        c->A = c->batchA + (size_t)b * c->A_elems;
+        c->dvec = c->batchV + (size_t)(3 * b) * c->Npad;
+        c->invp = c->dvec + c->Npad;
+        c->dinv = c->invp + c->Npad;
+        AsmParams p = make_params(c, &hps[r0 + b], 0);
+        c->last_precon = p.precon;
+        gpg_launch_prep(c, p, hps[r0 + b].var_fval, hps[r0 + b].var_fgrad, 1.0, 0.0, 0.0, 1.0);
+        gpg_launch_assembly(c, p);
+      }
+      if (Bg > 1) {
+        gpg_launch_tile_chol_batch(c, Bg, c->batchA, c->A_elems, c->batchV + 2 * (size_t)c->Npad, 3 * c->Npad, info0 + r0);
+      } else {
+        c->info = info0 + r0;
+        gpg_cholesky(c);
+      }
+      for (int b = 0; b < Bg; ++b) {
+        c->A = c->batchA + (size_t)b * c->A_elems;
+        c->dvec = c->batchV + (size_t)(3 * b) * c->Npad;
+        gpg_launch_lkd_reduce(c, r0 + b);
+      }
+    }
+    c->A = A0; c->dvec = dvec0; c->invp = invp0; c->dinv = dinv0; c->info = info0;
+  } else {
+    for (int i = 0; i < m; ++i) enqueue_lkd(c, &hps[i], i);
+  }
   GPG_HIP_OK(c, hipMemcpyAsync(c->h_scal, c->scal, sizeof(double) * 8 * m, hipMemcpyDeviceToHost, c->stream));
   GPG_HIP_OK(c, hipMemcpyAsync(c->h_info, c->info, sizeof(int) * m, hipMemcpyDeviceToHost, c->stream));
   GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
@@ -561,6 +619,13 @@ int gpg_set_factor_mode(gpg_ctx* c, int mode) {
     case GPG_FACTOR_TILE128: c->chol_impl = 1; c->tail_cols = 0; break;
     default: c->err = "unknown factor mode"; return -1;
   }
+  return 0;
+}
+
+int gpg_set_batch(gpg_ctx* c, int max_matrices) {
+  if (!c) return -1;
+  if (max_matrices < -1 || max_matrices > 64) { c->err = "batch size must be in [-1, 64]"; return -1; }
+  c->batch_max = max_matrices;
   return 0;
 }
 

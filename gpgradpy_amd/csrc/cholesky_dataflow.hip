@@ -24,7 +24,8 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256, 2)
 tile_chol_kernel(double* A, int ld, int c0, int Mt, const int* __restrict__ tasks, int* flags, int* pieces, int* abort_word,
-                 double* __restrict__ dinv, int* __restrict__ info, int N) {
+                 double* __restrict__ dinv, int* __restrict__ info, int N, const int* __restrict__ batch_of, size_t a_stride,
+                 int d_stride, int f_stride) {
   constexpr int KB = 16, SA = 80, BUF = KB * SA;
   __shared__ __attribute__((aligned(16))) double U[4 * BUF];      // staging sA[2] | sB[2]; later the tile Ts[64][SA]
   __shared__ __attribute__((aligned(16))) double Ls[64][4][18];   // L_jj image (i > j) / potrf scratch St[64][64] (i == j)
@@ -37,6 +38,14 @@ tile_chol_kernel(double* A, int ld, int c0, int Mt, const int* __restrict__ task
   const int l15 = lane & 15, l4 = lane >> 4;
   const int task = tasks[blockIdx.x];
   const int ti = task & 0xffff, tj = task >> 16;
+  if (batch_of) {   // batched launch: several independent matrices (restart rows) share the grid
+    const int b = batch_of[blockIdx.x];
+    A += (size_t)b * a_stride;
+    dinv += (size_t)b * d_stride;
+    info += b;
+    flags += (size_t)b * f_stride;
+    pieces += (size_t)b * f_stride;
+  }
   const size_t r0 = (size_t)c0 + 64 * (size_t)ti;        // first matrix row of the tile
   const size_t cj = (size_t)c0 + 64 * (size_t)tj;        // first matrix column of the tile
   const int q = tid & 3;
@@ -465,7 +474,45 @@ static void launch_tile_chol(gpg_ctx* c, int c0) {
   gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, m * m * m / 3.0);
   int* abort_word = c->tile_flags + (size_t)Mt * Rt;
   hipLaunchKernelGGL(tile_chol_kernel, dim3(tm.n), dim3(256), 0, c->stream, c->A, c->ld, c0, Mt, (const int*)tm.dev,
-                     c->tile_flags, abort_word + 1, abort_word, c->dinv, c->info, c->N);
+                     c->tile_flags, abort_word + 1, abort_word, c->dinv, c->info, c->N, (const int*)nullptr, (size_t)0, 0, 0);
+  gpg_prof_end(c);
+}
+
+// B independent matrices of the context's shape (workspaces Abase + b a_stride, reciprocal pivots dinv_base +
+// b d_stride, info[b]) factorised by ONE launch: the task lists of the matrices are interleaved tile column by tile
+// column, so every matrix's dependency chain advances at the same time and the chip is filled by small problems
+// whose single factorisation is latency-bound.  Task order per matrix is unchanged (progress argument holds).
+static void launch_tile_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a_stride, double* dinv_base, int d_stride,
+                                   int* info_base) {
+  const int Mt = c->Npad / 64, Rt = c->ld / 64;
+  const unsigned long long key = (2ull << 62) | ((unsigned long long)B << 40) | ((unsigned long long)Mt << 20) | (unsigned)Rt;
+  auto it = c->tilemaps.find(key);
+  if (it == c->tilemaps.end()) {
+    std::vector<int> list, bof;
+    for (int j = 0; j < Mt; ++j)
+      for (int b = 0; b < B; ++b)
+        for (int i = j; i < Rt; ++i) { list.push_back(i | (j << 16)); bof.push_back(b); }
+    TileMap tm;
+    tm.n = (int)list.size();
+    (void)hipMalloc(&tm.dev, sizeof(int) * 2 * list.size());
+    (void)hipMemcpy(tm.dev, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice);
+    (void)hipMemcpy(tm.dev + list.size(), bof.data(), sizeof(int) * bof.size(), hipMemcpyHostToDevice);
+    it = c->tilemaps.emplace(key, tm).first;
+  }
+  const TileMap& tm = it->second;
+  const size_t per = (size_t)Mt * Rt + 1 + 4 * (size_t)Mt, nflag = per * B;
+  if (c->tile_flags_cap < nflag) {
+    if (c->tile_flags) (void)hipFree(c->tile_flags);
+    (void)hipMalloc(&c->tile_flags, sizeof(int) * nflag);
+    c->tile_flags_cap = nflag;
+  }
+  (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
+  const double m = (double)c->Npad;
+  gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, B * m * m * m / 3.0);
+  int* abort_word = c->tile_flags + (size_t)Mt * Rt;      // the abort word of matrix 0 serves the whole launch
+  hipLaunchKernelGGL(tile_chol_kernel, dim3(tm.n), dim3(256), 0, c->stream, Abase, c->ld, 0, Mt, (const int*)tm.dev,
+                     c->tile_flags, abort_word + 1, abort_word, dinv_base, info_base, c->N, (const int*)(tm.dev + tm.n), a_stride,
+                     d_stride, (int)per);
   gpg_prof_end(c);
 }
 
@@ -492,3 +539,7 @@ static void launch_tile128_chol(gpg_ctx* c) {
 
 void gpg_launch_tile_chol(gpg_ctx* c, int c0) { launch_tile_chol(c, c0); }
 void gpg_launch_tile128_chol(gpg_ctx* c) { launch_tile128_chol(c); }
+void gpg_launch_tile_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a_stride, double* dinv_base, int d_stride,
+                                int* info_base) {
+  launch_tile_chol_batch(c, B, Abase, a_stride, dinv_base, d_stride, info_base);
+}

@@ -68,6 +68,10 @@ struct gpg_ctx {
   double* musig = nullptr;   // [2 x nxp]
   double* gradbuf = nullptr; // [2 x nxp x d] posterior-gradient reductions + [nxp x 64] backward-solve scratch
   int xq_cap = 0;
+  double* batchA = nullptr;     // [batch_cap x A_elems] workspaces of the batched small-matrix factorisation (on first use)
+  double* batchV = nullptr;     // [batch_cap x 3 x Npad] dvec / invp / dinv of each batched matrix
+  int batch_cap = 0;
+  int batch_max = -1;           // matrices per batched launch (-1: auto, 0 / 1: off)
   double* dense_tmp = nullptr;  // [N x N] materialisation buffer (on request)
   double* Wfull = nullptr;      // [Npad x Npad] L^-T (likelihood gradient, on first use)
   double* Minv = nullptr;       // [Npad x Npad] -(L L^T)^-1, lower triangle
@@ -100,7 +104,9 @@ void gpg_launch_prep(gpg_ctx* c, const AsmParams& p, double var_fval, double var
 void gpg_launch_assembly(gpg_ctx* c, const AsmParams& p);
 void gpg_launch_cross(gpg_ctx* c, const AsmParams& p, int nx, int nxp);   // Wt <- P^-1 Kyx (transposed)
 void gpg_launch_tile_chol(gpg_ctx* c, int c0);                          // dataflow factorisation of A[c0:, c0:], 64-tiles
-void gpg_launch_tile128_chol(gpg_ctx* c);                              // dataflow factorisation, 128-tiles (whole matrix)
+void gpg_launch_tile128_chol(gpg_ctx* c);
+void gpg_launch_tile_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a_stride, double* dinv_base, int d_stride,
+                                int* info_base);                              // dataflow factorisation, 128-tiles (whole matrix)
 void gpg_cholesky(gpg_ctx* c);                                           // blocked right-looking, in place
 void gpg_forward_rows(gpg_ctx* c, double* W, int ldw, int rows);         // W <- W L^-T (rows = RHS rows)
 void gpg_launch_lkd_reduce(gpg_ctx* c, int slot);                        // writes scal[slot*8 ..]

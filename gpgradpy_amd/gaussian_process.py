@@ -672,6 +672,12 @@ class GaussianProcess(HparaOptz):
         if rc != 0:
             raise _lib.GpgError(f'gpg_set_factor_mode failed ({rc}): {self._err()}')
 
+    def set_batch(self, max_matrices):
+        """Restart rows factorised per launch by calc_lkd_batch on small matrices (include/gpgrad.h: gpg_set_batch)."""
+        rc = self._lib.gpg_set_batch(self._ctx, int(max_matrices))
+        if rc != 0:
+            raise _lib.GpgError(f'gpg_set_batch failed ({rc}): {self._err()}')
+
     def factor_fallbacks(self):
         """How often a dataflow factorisation timed out (device shared with another such launch) and the call was
         repeated with the blocked schedule; the context stays on 'blocked' until set_factor_mode is called."""

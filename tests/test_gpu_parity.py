@@ -262,6 +262,35 @@ def test_factor_modes_agree_and_fail_alike():
         assert np.isclose(v[2], ref[2], rtol=1e-8) and np.isclose(v[3], ref[3], rtol=1e-8)
 
 
+def test_batched_small_matrices_bitwise():
+    """calc_lkd_batch on a small matrix factorises up to 8 restart rows per launch (gpg_set_batch); every row must be
+    bit-identical to the one-matrix-per-launch path, including rows whose factorisation fails."""
+    import gpgradpy_amd
+    from oracle import gp_oracle as orc
+    n, d = 70, 5
+    X, f, g = orc.synthetic_design(n, d, seed=21)
+    hp_x0 = np.random.default_rng(7).uniform(-2.5, -0.5, (19, d))          # 19 rows: groups of 8, 8, 3
+    out = {}
+    for bmax in (0, 8, 5):
+        GP = gpgradpy_amd.GaussianProcess(d, True, 'Ma5f2', 'precon')
+        GP.set_data(X, f, np.zeros(n), g, np.zeros((n, d)))
+        GP.set_batch(bmax)
+        out[bmax] = GP.calc_lkd_batch(hp_x0)
+        one = GP.calc_lkd_all(GP.hp_vec2dataclass(GP.hp_info_optz_lkd, hp_x0[11]))[0].ln_lkd
+        assert one == out[bmax][11]
+    assert np.all(np.isfinite(out[0]))
+    np.testing.assert_array_equal(out[8], out[0])
+    np.testing.assert_array_equal(out[5], out[0])
+    # a non-positive-definite row inside a batch only fails that row
+    GP = gpgradpy_amd.GaussianProcess(d, True, 'SqExp', 'base')
+    GP.set_data(X, f, np.zeros(n), g, np.zeros((n, d)))
+    GP._etaK = GP._eta_Kgrad = 0.0
+    rows = np.random.default_rng(8).uniform(-1.0, 0.0, (6, d))
+    rows[2] = -9.0                                                          # theta = 1e-9: numerically singular without nugget
+    ln = GP.calc_lkd_batch(rows)
+    assert np.isnan(ln[2]) and np.all(np.isfinite(np.delete(ln, 2)))
+
+
 def test_gradient_free_base():
     """BASELINE cfg1 shape (gradient-free SqExp, n=200, d=2): wellcond coerced to 'base'."""
     import gpgradpy_amd
