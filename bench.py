@@ -211,6 +211,8 @@ def main():
     if rank == 0:
         tr = prof["gemm_trail"]
         achieved = tr["work"] / (tr["ms"] * 1e-3) * 1e-12 if tr["ms"] > 0 else 0.0
+        # restart rows are batched into one factorisation launch (gpg_set_batch): flops per launch = B x Npad^3 / 3
+        mats_per_launch = int(round(tr["work"] / max(1, tr["count"]) / (Npad ** 3 / 3.0))) if tr["count"] else 1
         asm = prof["assembly"]
         result = {
             "metric": "marginal-likelihood evals/sec (grad-enh, n=2000 d=8)" if (n, d, args.config) == (2000, 8, "cfg3")
@@ -227,8 +229,11 @@ def main():
             "roofline": {"bound": "mfma", "kernel": dom_kernel,
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
-                         "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH_CFG3 if (n, d, args.config, args.factor_mode) == (2000, 8, "cfg3", "auto") else None,
-                         "traffic_unit": "bytes/launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_c_pmc_summary.txt)",
+                         "matrices_per_launch": mats_per_launch,
+                         "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH_CFG3 * mats_per_launch
+                                    if (n, d, args.config, args.factor_mode) == (2000, 8, "cfg3", "auto") else None,
+                         "traffic_unit": "bytes/launch = matrices per launch x the single-matrix PMC figure (FETCH_SIZE x2 + "
+                                         "WRITE_SIZE, profiles/r01_c_pmc_summary.txt)",
                          "launches": tr["count"], "avg_launch_ms": tr["ms"] / max(1, tr["count"]),
                          "algorithmic_flops": tr["work"],
                          "share_of_step_time": tr["ms"] * 1e-3 / elapsed if elapsed > 0 else None},

@@ -335,23 +335,32 @@ static int gpg_lkd_batch_once(gpg_ctx* c, int m, const double* hp_rows, int row_
     bmax = (int)(8192 / (ntask > 0 ? ntask : 1));
     bmax = bmax < 8 ? 8 : (bmax > 64 ? 64 : bmax);
   }
-  int B = (small && bmax > 1 && m > 1) ? (m < bmax ? m : bmax) : 1;
-  if (B > 1) {
+  const bool large_df = !small && c->chol_impl == 1;   // 128-tile dataflow regime: a few matrices fill each other's chain-bound ends
+  if (large_df && bmax != 0 && bmax != 1) bmax = c->batch_max < 0 ? (c->Npad <= 32768 ? 4 : 1) : bmax;   // measured: +6 % at N = 18k, none at 68k
+  int B = 1;
+  if ((small || large_df) && bmax > 1 && m > 1) {
+    // workspaces are sized once for the largest batch this shape will use (not for this call's m): a later, larger
+    // call must not pay a multi-GB reallocation
     const size_t bytesA = sizeof(double) * c->A_elems;
-    while (B > 1 && bytesA * B > ((size_t)16 << 30)) --B;          // at most 16 GB of extra workspaces
-    if (B > c->batch_cap) {
+    int Bcap = bmax;
+    while (Bcap > 1 && bytesA * Bcap > ((size_t)96 << 30)) --Bcap;   // at most 96 GB of extra workspaces (288 GB per GPU)
+    if (Bcap > c->batch_cap) {
       if (c->batchA) (void)hipFree(c->batchA);
       if (c->batchV) (void)hipFree(c->batchV);
       c->batchA = c->batchV = nullptr; c->batch_cap = 0;
-      if (hipMalloc(&c->batchA, bytesA * B) != hipSuccess || hipMalloc(&c->batchV, sizeof(double) * 3 * c->Npad * B) != hipSuccess) {
+      while (Bcap > 1) {
+        if (hipMalloc(&c->batchA, bytesA * Bcap) == hipSuccess && hipMalloc(&c->batchV, sizeof(double) * 3 * c->Npad * Bcap) == hipSuccess) {
+          c->batch_cap = Bcap;
+          break;
+        }
         if (c->batchA) (void)hipFree(c->batchA);
         c->batchA = c->batchV = nullptr;
         (void)hipGetLastError();
-        B = 1;                                                       // no room: one matrix at a time
-      } else {
-        c->batch_cap = B;
+        Bcap /= 2;                                                   // no room: try half, then one matrix at a time
       }
     }
+    B = m < c->batch_cap ? m : c->batch_cap;
+    if (B < 1) B = 1;
   }
   if (B > 1) {
     double *A0 = c->A, *dvec0 = c->dvec, *invp0 = c->invp, *dinv0 = c->dinv;

@@ -331,13 +331,22 @@ __device__ __noinline__ int tile128_finalize(double* A, int ld, size_t r0, size_
 
 __global__ void __launch_bounds__(256, 2)
 tile128_chol_kernel(double* A, int ld, int Mt, const int* __restrict__ tasks, int* flags, int* flag_a, int* abort_word,
-                    double* __restrict__ dinv, int* __restrict__ info, int N) {
+                    double* __restrict__ dinv, int* __restrict__ info, int N, const int* __restrict__ batch_of, size_t a_stride,
+                    int d_stride, int f_stride) {
   __shared__ int sh_kr;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w & 1, wn = w >> 1;
   const int l15 = lane & 15, l4 = lane >> 4;
   const int task = tasks[blockIdx.x];
   const int ti = task & 0xffff, tj = task >> 16;
+  if (batch_of) {   // batched launch: several independent matrices (restart rows) share the grid
+    const int b = batch_of[blockIdx.x];
+    A += (size_t)b * a_stride;
+    dinv += (size_t)b * d_stride;
+    info += b;
+    flags += (size_t)b * f_stride;
+    flag_a += (size_t)b * f_stride;
+  }
   const size_t r0 = 128 * (size_t)ti, cj = 128 * (size_t)tj;
   int* const frow_i = flags + (size_t)ti * Mt;
   int* const frow_j = flags + (size_t)tj * Mt;
@@ -531,7 +540,43 @@ static void launch_tile128_chol(gpg_ctx* c) {
   gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, m * m * m / 3.0);
   int* abort_word = c->tile_flags + (size_t)Mt * Rt;
   hipLaunchKernelGGL(tile128_chol_kernel, dim3(tm.n), dim3(256), 0, c->stream, c->A, c->ld, Mt, (const int*)tm.dev,
-                     c->tile_flags, abort_word + 1, abort_word, c->dinv, c->info, c->N);
+                     c->tile_flags, abort_word + 1, abort_word, c->dinv, c->info, c->N, (const int*)nullptr, (size_t)0, 0, 0);
+  gpg_prof_end(c);
+}
+
+// The same for B matrices at once (see launch_tile_chol_batch): at the two ends of a factorisation the dependency
+// chain leaves most of the chip idle, and a second matrix fills it.
+static void launch_tile128_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a_stride, double* dinv_base, int d_stride,
+                                      int* info_base) {
+  const int Mt = c->Npad / 128, Rt = c->ld / 128;
+  const unsigned long long key = (2ull << 62) | (1ull << 61) | ((unsigned long long)B << 40) | ((unsigned long long)Mt << 20) | (unsigned)Rt;
+  auto it = c->tilemaps.find(key);
+  if (it == c->tilemaps.end()) {
+    std::vector<int> list, bof;
+    for (int j = 0; j < Mt; ++j)
+      for (int b = 0; b < B; ++b)
+        for (int i = j; i < Rt; ++i) { list.push_back(i | (j << 16)); bof.push_back(b); }
+    TileMap tm;
+    tm.n = (int)list.size();
+    (void)hipMalloc(&tm.dev, sizeof(int) * 2 * list.size());
+    (void)hipMemcpy(tm.dev, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice);
+    (void)hipMemcpy(tm.dev + list.size(), bof.data(), sizeof(int) * bof.size(), hipMemcpyHostToDevice);
+    it = c->tilemaps.emplace(key, tm).first;
+  }
+  const TileMap& tm = it->second;
+  const size_t per = (size_t)Mt * Rt + 1 + 2 * (size_t)Mt, nflag = per * B;
+  if (c->tile_flags_cap < nflag) {
+    if (c->tile_flags) (void)hipFree(c->tile_flags);
+    (void)hipMalloc(&c->tile_flags, sizeof(int) * nflag);
+    c->tile_flags_cap = nflag;
+  }
+  (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
+  const double m = (double)c->Npad;
+  gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, B * m * m * m / 3.0);
+  int* abort_word = c->tile_flags + (size_t)Mt * Rt;
+  hipLaunchKernelGGL(tile128_chol_kernel, dim3(tm.n), dim3(256), 0, c->stream, Abase, c->ld, Mt, (const int*)tm.dev,
+                     c->tile_flags, abort_word + 1, abort_word, dinv_base, info_base, c->N, (const int*)(tm.dev + tm.n), a_stride,
+                     d_stride, (int)per);
   gpg_prof_end(c);
 }
 
@@ -541,5 +586,6 @@ void gpg_launch_tile_chol(gpg_ctx* c, int c0) { launch_tile_chol(c, c0); }
 void gpg_launch_tile128_chol(gpg_ctx* c) { launch_tile128_chol(c); }
 void gpg_launch_tile_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a_stride, double* dinv_base, int d_stride,
                                 int* info_base) {
-  launch_tile_chol_batch(c, B, Abase, a_stride, dinv_base, d_stride, info_base);
+  if (c->tail_cols > 0 && c->Npad <= c->tail_cols) launch_tile_chol_batch(c, B, Abase, a_stride, dinv_base, d_stride, info_base);
+  else launch_tile128_chol_batch(c, B, Abase, a_stride, dinv_base, d_stride, info_base);
 }

@@ -180,10 +180,11 @@ int gpg_set_factor_mode(gpg_ctx* ctx, int mode);
  * happened (results are unaffected; rc -4 is only returned if the blocked repeat fails too). */
 int gpg_factor_fallbacks(gpg_ctx* ctx);
 
-/* gpg_lkd_batch on small matrices (the 64-tile dataflow regime, <= 9216 padded columns): up to max_matrices restart
- * rows are assembled into separate workspaces and factorised by ONE launch -- a single small factorisation is
- * latency-bound and leaves most of the chip idle.  Results are bit-identical to the one-at-a-time path.
- * -1 (default): automatic (8 rows at 40 tile columns, up to 64 for tiny matrices); 0 / 1: off. */
+/* gpg_lkd_batch: up to max_matrices restart rows are assembled into separate workspaces and factorised by ONE
+ * dataflow launch (task lists interleaved tile column by tile column).  A single small factorisation is
+ * latency-bound and leaves most of the chip idle; a large one does so at its two ends.  Results are bit-identical to
+ * the one-at-a-time path.  -1 (default): automatic (8 .. 64 rows up to 9216 padded columns, 4 rows up to 32768
+ * columns, 1 above); 0 / 1: off. */
 int gpg_set_batch(gpg_ctx* ctx, int max_matrices);
 
 /* Library / device facts for logs: writes "gfx950 MI355X ..." style text. */

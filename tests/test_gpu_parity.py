@@ -281,6 +281,17 @@ def test_batched_small_matrices_bitwise():
     assert np.all(np.isfinite(out[0]))
     np.testing.assert_array_equal(out[8], out[0])
     np.testing.assert_array_equal(out[5], out[0])
+    # the 128-tile regime batches as well (4 matrices per launch): same bitwise guarantee
+    n2, d2 = 1100, 8
+    X2, f2, g2 = orc.synthetic_design(n2, d2, seed=5)
+    rows2 = np.random.default_rng(9).uniform(-2.0, -0.7, (5, d2))
+    res = {}
+    for bmax in (0, -1):
+        GP = gpgradpy_amd.GaussianProcess(d2, True, 'SqExp', 'precon')
+        GP.set_data(X2, f2, np.zeros(n2), g2, np.zeros((n2, d2)))
+        GP.set_batch(bmax)
+        res[bmax] = GP.calc_lkd_batch(rows2)
+    np.testing.assert_array_equal(res[-1], res[0])
     # a non-positive-definite row inside a batch only fails that row
     GP = gpgradpy_amd.GaussianProcess(d, True, 'SqExp', 'base')
     GP.set_data(X, f, np.zeros(n), g, np.zeros((n, d)))
