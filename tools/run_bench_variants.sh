@@ -1,8 +1,6 @@
-# A/B of the Cholesky options on the headline workload (one process per variant)
-for cfg in "1 256" "0 256" "3 256" "1 512"; do
-set -- $cfg; la=$1; pn=$2
-timeout -k 10 200 python bench.py --prof-all --no-cpu-baseline --lookahead $la --panel $pn > gpurun_out/b_la${la}_p${pn}_prof.json && python -c "
-import json; r=json.load(open('gpurun_out/b_la${la}_p${pn}_prof.json')); print('opts=$la panel=$pn prof', round(r['value'],2), round(r['ms_per_step'],2), round(r['roofline']['achieved'],1), {k: round(v,2) for k,v in r['kernel_ms_per_eval'].items()})"
-timeout -k 10 200 python bench.py --no-cpu-baseline --lookahead $la --panel $pn > gpurun_out/b_la${la}_p${pn}.json && python -c "
-import json; r=json.load(open('gpurun_out/b_la${la}_p${pn}.json')); print('opts=$la panel=$pn', round(r['value'],2), round(r['ms_per_step'],2), round(r['roofline']['achieved'],1))"
+# A/B of the factorisation schedules and the batch size on the headline workload (one process per variant)
+for v in "auto -1" "auto 0" "auto 2" "auto 8" "tile128 0" "tile64 0" "blocked 0"; do
+set -- $v; mode=$1; batch=$2
+timeout -k 10 300 python bench.py --no-cpu-baseline --factor-mode $mode --batch $batch > gpurun_out/b_${mode}_b${batch}.json && python -c "
+import json; r=json.load(open('gpurun_out/b_${mode}_b${batch}.json')); print('mode=$mode batch=$batch', round(r['value'],2), 'evals/s', round(r['ms_per_step'],2), 'ms', round(r['roofline']['achieved'],1), 'TF')"
 done
