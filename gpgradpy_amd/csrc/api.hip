@@ -336,7 +336,7 @@ static int gpg_lkd_batch_once(gpg_ctx* c, int m, const double* hp_rows, int row_
     bmax = bmax < 8 ? 8 : (bmax > 64 ? 64 : bmax);
   }
   const bool large_df = !small && c->chol_impl == 1;   // 128-tile dataflow regime: a few matrices fill each other's chain-bound ends
-  if (large_df && bmax != 0 && bmax != 1) bmax = c->batch_max < 0 ? (c->Npad <= 32768 ? 4 : 1) : bmax;   // measured: +6 % at N = 18k, none at 68k
+  if (large_df && bmax != 0 && bmax != 1) bmax = c->batch_max < 0 ? (c->Npad <= 32768 ? 8 : 1) : bmax;   // measured: +9 % at N = 18k, none at 68k
   int B = 1;
   if ((small || large_df) && bmax > 1 && m > 1) {
     // workspaces are sized once for the largest batch this shape will use (not for this call's m): a later, larger

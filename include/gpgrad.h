@@ -183,7 +183,7 @@ int gpg_factor_fallbacks(gpg_ctx* ctx);
 /* gpg_lkd_batch: up to max_matrices restart rows are assembled into separate workspaces and factorised by ONE
  * dataflow launch (task lists interleaved tile column by tile column).  A single small factorisation is
  * latency-bound and leaves most of the chip idle; a large one does so at its two ends.  Results are bit-identical to
- * the one-at-a-time path.  -1 (default): automatic (8 .. 64 rows up to 9216 padded columns, 4 rows up to 32768
+ * the one-at-a-time path.  -1 (default): automatic (8 .. 64 rows up to 9216 padded columns, 8 rows up to 32768
  * columns, 1 above); 0 / 1: off. */
 int gpg_set_batch(gpg_ctx* ctx, int max_matrices);
 
