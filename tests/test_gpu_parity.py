@@ -302,6 +302,40 @@ def test_batched_small_matrices_bitwise():
     assert np.isnan(ln[2]) and np.all(np.isfinite(np.delete(ln, 2)))
 
 
+def test_random_small_shapes_against_oracle():
+    """Seeded sweep over odd shapes (n = 1 .. 60, d = 1 .. 16, both kernels, three noise models, both schedules of the
+    small-matrix regime): N not a multiple of any tile, one to ten tile columns, single-point data sets."""
+    import gpgradpy_amd
+    from oracle import gp_oracle as orc
+    rng = np.random.default_rng(2024)
+    for case in range(30):
+        d = int(rng.integers(1, 17))
+        n = int(rng.integers(1, max(2, min(60, 640 // (d + 1)))))
+        kernel = 'SqExp' if case % 2 == 0 else 'Ma5f2'
+        noise = ('none', 'known', 'unknown')[case % 3]
+        X, f, g = orc.synthetic_design(n, d, seed=100 + case)
+        std_f = std_g = None
+        vf = vg = varK = None
+        if noise == 'none':
+            std_f, std_g = np.zeros(n), np.zeros((n, d))
+        elif noise == 'known':
+            std_f, std_g = np.full(n, 1e-2), np.full((n, d), 1e-1)
+            varK = 1.7
+        else:
+            vf, vg, varK = 1e-4, 1e-2, 0.6
+        theta = 10.0 ** rng.uniform(-2.0, -0.3, d)
+        GP = gpgradpy_amd.GaussianProcess(d, True, kernel, 'precon')
+        GP.set_data(X, f, std_f, g, std_g)
+        GP.set_factor_mode('blocked' if case % 5 == 4 else 'auto')
+        info, ok = GP.calc_lkd_all(GP.make_hp_class(theta=theta, varK=varK, var_fval=vf, var_fgrad=vg))
+        y = orc.make_data_vec(f, g)
+        nv = orc.calc_noise_vec(n, d, True, std_f, std_g, vf, vg)
+        r = orc.calc_lkd(X, y, theta, kernel, True, "precon", GP._etaK, nv, noise != 'none', varK=varK)
+        assert ok and r.ok, (case, n, d, kernel, noise)
+        ref = dict(hp_beta=r.hp_beta, hp_varK=r.hp_varK, ln_det_Kmat=r.ln_det_Kmat, ln_lkd=r.ln_lkd)
+        tol.check_scalars(info.hp_beta[0], info.hp_varK, info.ln_det_Kmat, info.ln_lkd, ref, y.size, noise != 'none')
+
+
 def test_gradient_free_base():
     """BASELINE cfg1 shape (gradient-free SqExp, n=200, d=2): wellcond coerced to 'base'."""
     import gpgradpy_amd
