@@ -183,6 +183,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    GP.reserve_batch(args.steps)                                  # setup (like set_data): workspaces of the batched launches
     if args.warmup > 0:
         GP.calc_lkd_batch(rows_for(args.warmup))
     cats = list(gpgradpy_amd._lib.PROF_CATS) if args.prof_all else ["gemm_trail", "assembly"]

@@ -305,6 +305,46 @@ static int gpg_lkd_grad_once(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out, dou
   return 0;
 }
 
+// How many restart rows of the context's shape one dataflow launch factorises (gpg_set_batch), and the workspaces
+// for them.  Small matrices (64-tile regime): one factorisation is latency-bound and leaves most of the chip idle;
+// large ones (128-tile regime) do so at their two ends.  Workspaces are sized once for the largest batch the shape
+// will use, not for this call's m: a later, larger call must not pay a multi-GB reallocation.
+static int batch_plan(gpg_ctx* c, int m) {
+  const bool small = c->tail_cols > 0 && c->Npad <= c->tail_cols;
+  const bool large_df = !small && c->chol_impl == 1;
+  int bmax = c->batch_max;
+  if (bmax < 0) {
+    if (small) {   // enough matrices to put ~8k tiles in flight (8 at cfg2's 40 tile columns, 64 for tiny matrices)
+      const long mt = c->Npad / 64, ntask = mt * (mt + 5) / 2;
+      bmax = (int)(8192 / (ntask > 0 ? ntask : 1));
+      bmax = bmax < 8 ? 8 : (bmax > 64 ? 64 : bmax);
+    } else {
+      bmax = c->Npad <= 32768 ? 8 : 1;   // measured: +9 % at N = 18k, none at 68k
+    }
+  }
+  if (!(small || large_df) || bmax <= 1 || m <= 1) return 1;
+  const size_t bytesA = sizeof(double) * c->A_elems;
+  int Bcap = bmax;
+  while (Bcap > 1 && bytesA * Bcap > ((size_t)96 << 30)) --Bcap;   // at most 96 GB of extra workspaces (288 GB per GPU)
+  if (Bcap > c->batch_cap) {
+    if (c->batchA) (void)hipFree(c->batchA);
+    if (c->batchV) (void)hipFree(c->batchV);
+    c->batchA = c->batchV = nullptr; c->batch_cap = 0;
+    while (Bcap > 1) {
+      if (hipMalloc(&c->batchA, bytesA * Bcap) == hipSuccess && hipMalloc(&c->batchV, sizeof(double) * 3 * c->Npad * Bcap) == hipSuccess) {
+        c->batch_cap = Bcap;
+        break;
+      }
+      if (c->batchA) (void)hipFree(c->batchA);
+      c->batchA = c->batchV = nullptr;
+      (void)hipGetLastError();
+      Bcap /= 2;                                                   // no room: try half, then one matrix at a time
+    }
+  }
+  const int B = m < c->batch_cap ? m : c->batch_cap;
+  return B < 1 ? 1 : B;
+}
+
 static int gpg_lkd_batch_once(gpg_ctx* c, int m, const double* hp_rows, int row_len, double eta, int wellcond,
                               int closed_form_varK, gpg_lkd_out* out) {
   if (!c) return -1;
@@ -326,42 +366,7 @@ static int gpg_lkd_batch_once(gpg_ctx* c, int m, const double* hp_rows, int row_
     if (rc) return rc;
   }
   GPG_HIP_OK(c, hipMemsetAsync(c->info, 0, sizeof(int) * m, c->stream));
-  // Small matrices (the 64-tile dataflow regime): one factorisation is latency-bound and leaves most of the chip
-  // idle, so up to batch_max restart rows are assembled into separate workspaces and factorised by ONE launch.
-  const bool small = c->tail_cols > 0 && c->Npad <= c->tail_cols;
-  int bmax = c->batch_max;
-  if (bmax < 0) {   // auto: enough matrices to put ~8k tiles in flight (8 at cfg2's 40 tile columns, 64 for tiny matrices)
-    const long mt = c->Npad / 64, ntask = mt * (mt + 5) / 2;
-    bmax = (int)(8192 / (ntask > 0 ? ntask : 1));
-    bmax = bmax < 8 ? 8 : (bmax > 64 ? 64 : bmax);
-  }
-  const bool large_df = !small && c->chol_impl == 1;   // 128-tile dataflow regime: a few matrices fill each other's chain-bound ends
-  if (large_df && bmax != 0 && bmax != 1) bmax = c->batch_max < 0 ? (c->Npad <= 32768 ? 8 : 1) : bmax;   // measured: +9 % at N = 18k, none at 68k
-  int B = 1;
-  if ((small || large_df) && bmax > 1 && m > 1) {
-    // workspaces are sized once for the largest batch this shape will use (not for this call's m): a later, larger
-    // call must not pay a multi-GB reallocation
-    const size_t bytesA = sizeof(double) * c->A_elems;
-    int Bcap = bmax;
-    while (Bcap > 1 && bytesA * Bcap > ((size_t)96 << 30)) --Bcap;   // at most 96 GB of extra workspaces (288 GB per GPU)
-    if (Bcap > c->batch_cap) {
-      if (c->batchA) (void)hipFree(c->batchA);
-      if (c->batchV) (void)hipFree(c->batchV);
-      c->batchA = c->batchV = nullptr; c->batch_cap = 0;
-      while (Bcap > 1) {
-        if (hipMalloc(&c->batchA, bytesA * Bcap) == hipSuccess && hipMalloc(&c->batchV, sizeof(double) * 3 * c->Npad * Bcap) == hipSuccess) {
-          c->batch_cap = Bcap;
-          break;
-        }
-        if (c->batchA) (void)hipFree(c->batchA);
-        c->batchA = c->batchV = nullptr;
-        (void)hipGetLastError();
-        Bcap /= 2;                                                   // no room: try half, then one matrix at a time
-      }
-    }
-    B = m < c->batch_cap ? m : c->batch_cap;
-    if (B < 1) B = 1;
-  }
+  const int B = batch_plan(c, m);
   if (B > 1) {
     double *A0 = c->A, *dvec0 = c->dvec, *invp0 = c->invp, *dinv0 = c->dinv;
     int* info0 = c->info;
@@ -629,6 +634,13 @@ int gpg_set_factor_mode(gpg_ctx* c, int mode) {
     default: c->err = "unknown factor mode"; return -1;
   }
   return 0;
+}
+
+int gpg_reserve_batch(gpg_ctx* c, int rows) {
+  if (!c) return -1;
+  if (!c->have_data) { c->err = "gpg_set_data must be called first"; return -1; }
+  GPG_HIP_OK(c, hipSetDevice(c->device));
+  return batch_plan(c, rows) >= 1 ? 0 : -2;
 }
 
 int gpg_set_batch(gpg_ctx* c, int max_matrices) {

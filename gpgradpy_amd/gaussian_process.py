@@ -678,6 +678,12 @@ class GaussianProcess(HparaOptz):
         if rc != 0:
             raise _lib.GpgError(f'gpg_set_batch failed ({rc}): {self._err()}')
 
+    def reserve_batch(self, rows):
+        """Allocate the workspaces calc_lkd_batch(rows) will use (setup, like set_data)."""
+        rc = self._lib.gpg_reserve_batch(self._ctx, int(rows))
+        if rc != 0:
+            raise _lib.GpgError(f'gpg_reserve_batch failed ({rc}): {self._err()}')
+
     def factor_fallbacks(self):
         """How often a dataflow factorisation timed out (device shared with another such launch) and the call was
         repeated with the blocked schedule; the context stays on 'blocked' until set_factor_mode is called."""

@@ -186,6 +186,9 @@ int gpg_factor_fallbacks(gpg_ctx* ctx);
  * the one-at-a-time path.  -1 (default): automatic (8 .. 64 rows up to 9216 padded columns, 8 rows up to 32768
  * columns, 1 above); 0 / 1: off. */
 int gpg_set_batch(gpg_ctx* ctx, int max_matrices);
+/* Allocates the batch workspaces a gpg_lkd_batch call with `rows` rows will use (otherwise done by the first such
+ * call): setup, like gpg_set_data, for callers that time gpg_lkd_batch. */
+int gpg_reserve_batch(gpg_ctx* ctx, int rows);
 
 /* Library / device facts for logs: writes "gfx950 MI355X ..." style text. */
 int gpg_device_info(int device, char* buf, int buflen);
