@@ -229,7 +229,17 @@ class HparaOptz:
         all_total_fun_iter = np.full(n_optz, np.nan)
         optz_obj_all = np.full(n_optz, np.nan)
         optz_sol_all = np.full((n_optz, self.hp_info_optz_lkd.n_hp), np.nan)
-        for i in range(n_optz):
+        # the starts are independent: with torch.distributed up, rank r runs its contiguous block of them on its own
+        # GPU and one all_gather shares (objective, success, iterations, solution) -- SURVEY.md 8e applied to the
+        # optimiser's multi-start (the reference runs them one after the other, OptzLkd.py:252-290)
+        from .multistart import gather_rows, shard_rows
+        try:
+            import torch.distributed as dist
+            world, rank = (dist.get_world_size(), dist.get_rank()) if dist.is_available() and dist.is_initialized() else (1, 0)
+        except ImportError:                                   # pragma: no cover
+            world, rank = 1, 0
+        lo, hi = shard_rows(n_optz, world, rank)
+        for i in range(lo, hi):
             x0_i = hp_x0_all[i, :]
             self._last_hp_vec = np.full((1, x0_i.size), np.nan)
             res = minimize(self.return_optz_val, x0_i, method=self.optz_mtd, jac=self.return_optz_grad,
@@ -240,6 +250,10 @@ class HparaOptz:
             all_total_fun_iter[i] = res.nit
             if not res.success:
                 print(f'Surr hpara optz: Con GOOD, Optimizer: {res.message}')
+        if world > 1:
+            table = gather_rows(np.column_stack((optz_obj_all, all_optz_success, all_total_fun_iter, optz_sol_all))[lo:hi], n_optz)
+            optz_obj_all, all_optz_success, all_total_fun_iter = table[:, 0], table[:, 1] > 0.5, table[:, 2]
+            optz_sol_all = table[:, 3:]
         idx_min = np.nanargmin(optz_obj_all)
         best_hp = optz_sol_all[idx_min, :]
         surr_optz_info = {'hp_optz_success': np.mean(all_optz_success), 'hp_optz_iter_mean': np.mean(all_total_fun_iter),

@@ -48,3 +48,29 @@ def select_best_restart(hp_x0, eval_fn, group=None, device=None):
             ln_all[rlo:rhi] = gathered[r][:rhi - rlo].cpu().numpy()
     idx = int(np.nanargmax(ln_all))
     return hp_x0[idx][None, :], ln_all, idx
+
+
+def gather_rows(local_rows, m, group=None, device=None):
+    """All ranks contribute their contiguous block of an [m, w] table (shard_rows partition); every rank gets the full
+    table.  One all_gather of equal-size padded blocks (latency-bound: a few hundred bytes per rank)."""
+    import torch
+    import torch.distributed as dist
+    local_rows = np.atleast_2d(np.asarray(local_rows, dtype=np.float64))
+    if not (dist.is_available() and dist.is_initialized()):
+        return local_rows
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    w = local_rows.shape[1]
+    width = -(-m // world)
+    if device is None:
+        device = torch.device('cuda', torch.cuda.current_device()) if dist.get_backend(group) == 'nccl' \
+            else torch.device('cpu')
+    buf = torch.full((width, w), float('nan'), dtype=torch.float64, device=device)
+    if local_rows.shape[0] > 0:
+        buf[:local_rows.shape[0]] = torch.from_numpy(local_rows).to(device)
+    gathered = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(gathered, buf, group=group)
+    out = np.full((m, w), np.nan)
+    for r in range(world):
+        lo, hi = shard_rows(m, world, r)
+        out[lo:hi] = gathered[r][:hi - lo].cpu().numpy()
+    return out

@@ -62,3 +62,54 @@ def test_multistart_two_ranks_gloo(tmp_path):
     assert np.isnan(ln0[0])
     np.testing.assert_allclose(ln0[1:], z["ln_lkd_all"][1:], rtol=1e-8)
     assert int(np.load(tmp_path / "idx_0.npy")[0]) == int(z["idx_max"]) == int(np.load(tmp_path / "idx_1.npy")[0])
+
+
+def _optz_worker(rank, world, port, out_dir):
+    """The optimiser's multi-start (gpgradpy_amd/hpara_optz.py::optz_hp_max_lkd) sharded over two ranks.  The objective
+    is an analytic stand-in for the device likelihood (this tests the sharding + gather, not the kernels)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from scipy.optimize import Bounds
+    from gpgradpy_amd.hpara import HparaOptzInfo
+    from gpgradpy_amd.hpara_optz import HparaOptz
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    class Fake(HparaOptz):
+        started = []
+
+        def __init__(self):
+            self.hp_info_optz_lkd = HparaOptzInfo(n_hp=2, has_theta=True, idx_theta=np.array([0, 1]), has_kernel=False, idx_kernel=None,
+                                                  has_varK=False, idx_varK=None, has_var_fval=False, idx_var_fval=None,
+                                                  has_var_fgrad=False, idx_var_fgrad=None, bvec_log_optz=np.array([True, True]))
+
+        # two basins: the deeper one at (1, -1)
+        def return_optz_val(self, x):
+            x = np.atleast_1d(x)
+            return float(min((x[0] + 2) ** 2 + (x[1] - 1) ** 2 + 1.0, 2 * (x[0] - 1) ** 2 + (x[1] + 1) ** 2))
+
+        def return_optz_grad(self, x):
+            x = np.atleast_1d(x)
+            a = (x[0] + 2) ** 2 + (x[1] - 1) ** 2 + 1.0
+            b = 2 * (x[0] - 1) ** 2 + (x[1] + 1) ** 2
+            return np.array([2 * (x[0] + 2), 2 * (x[1] - 1)]) if a < b else np.array([4 * (x[0] - 1), 2 * (x[1] + 1)])
+
+    gp = Fake()
+    x0 = np.array([[-2.5, 1.5], [-1.5, 0.5], [0.5, -0.5], [2.0, -2.0], [0.9, -1.2]])
+    best, cond, info = gp.optz_hp_max_lkd(x0, Bounds([-5, -5], [5, 5], keep_feasible=True))
+    np.save(os.path.join(out_dir, f"best_{rank}.npy"), best)
+    np.save(os.path.join(out_dir, f"obj_{rank}.npy"), gp.optz_obj_all_last)
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_optimiser_multistart_sharded_two_ranks_gloo(tmp_path):
+    world = 2
+    mp.spawn(_optz_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    b0, b1 = np.load(tmp_path / "best_0.npy"), np.load(tmp_path / "best_1.npy")
+    o0, o1 = np.load(tmp_path / "obj_0.npy"), np.load(tmp_path / "obj_1.npy")
+    np.testing.assert_array_equal(b0, b1)                      # every rank ends with the same optimum ...
+    np.testing.assert_array_equal(o0, o1)                      # ... and the full table of the five runs
+    np.testing.assert_allclose(b0, [1.0, -1.0], atol=1e-5)     # the deeper basin, found by a start of rank 1's block
+    assert np.all(np.isfinite(o0)) and o0.shape == (5,)
+    assert np.isclose(o0[:2], 1.0, atol=1e-8).all() and np.isclose(o0[2:], 0.0, atol=1e-8).all()
