@@ -258,6 +258,7 @@ __device__ __forceinline__ void wave_tile_gemm(d4 (&acc)[4], const double* ga, i
 
 #ifdef GPG_STAMP   // diagnostic build of tools/gemm_probe.hip only: per-wave cycle shares of the loop phases
 __device__ unsigned long long* g_stamp_buf;
+#define GPG_STAMP_MAX 131072   // workgroups with a timeline record
 #define GPG_T(var) unsigned long long var; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0);
 #else
 #define GPG_T(var)

@@ -273,7 +273,7 @@ __device__ __noinline__ int tile128_finalize(double* A, int ld, size_t r0, size_
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
 #ifdef GPG_STAMP
-  unsigned long long* fo = (g_stamp_buf != nullptr && blockIdx.x < 16384) ? g_stamp_buf + 16384 * 8 + (size_t)blockIdx.x * 8 : nullptr;
+  unsigned long long* fo = (g_stamp_buf != nullptr && blockIdx.x < GPG_STAMP_MAX) ? g_stamp_buf + (size_t)GPG_STAMP_MAX * 8 + (size_t)blockIdx.x * 8 : nullptr;
 #define GPG_FS(k) if (tid == 0 && fo) fo[k] = __builtin_amdgcn_s_memrealtime();
 #else
 #define GPG_FS(k)
@@ -442,7 +442,7 @@ tile128_chol_kernel(double* A, int ld, int Mt, const int* __restrict__ tasks, in
   __syncthreads();
   if (tid == 0) __hip_atomic_store(frow_i + tj, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 #ifdef GPG_STAMP
-  if (tid == 0 && g_stamp_buf != nullptr && blockIdx.x < 16384) {
+  if (tid == 0 && g_stamp_buf != nullptr && blockIdx.x < GPG_STAMP_MAX) {
     unsigned long long* o = g_stamp_buf + (size_t)blockIdx.x * 8;
     o[0] = tk_start; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = tk_spin; o[3] = tk_gemm; o[4] = tk_runs;
     o[5] = tk_fin0; o[6] = (unsigned long long)task;

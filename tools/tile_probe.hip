@@ -35,18 +35,23 @@ int main(int argc, char** argv) {
   hipMemset(c.info, 0, sizeof(int));
 #ifdef GPG_STAMP
   unsigned long long* dbuf = nullptr;
-  if (hipMalloc(&dbuf, 16384 * 16 * 8) != hipSuccess || dbuf == nullptr) { printf("stamp buffer alloc failed\n"); return 1; }
-  hipMemset(dbuf, 0, 16384 * 16 * 8);
+  if (hipMalloc(&dbuf, GPG_STAMP_MAX * 16 * 8) != hipSuccess || dbuf == nullptr) { printf("stamp buffer alloc failed\n"); return 1; }
+  hipMemset(dbuf, 0, GPG_STAMP_MAX * 16 * 8);
   if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &dbuf, sizeof(dbuf)) != hipSuccess) { printf("symbol copy failed\n"); return 1; }
   hipDeviceSynchronize();
 #endif
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const size_t total = (size_t)c.ld * n;
+  const int B = impl == 5 ? 8 : 1;
+  double* bA = nullptr; double* bD = nullptr; int* binfo = nullptr;
+  if (B > 1) { hipMalloc(&bA, sizeof(double) * (size_t)c.ld * n * B); hipMalloc(&bD, sizeof(double) * (size_t)n * B); hipMalloc(&binfo, sizeof(int) * B); hipMemset(binfo, 0, sizeof(int) * B); c.chol_impl = 1; }
   float best = 1e30f;
   for (int rep = 0; rep < 3; ++rep) {
-    hipLaunchKernelGGL(fill_spd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.stream, c.A, c.ld, n);
+    if (B > 1) for (int b = 0; b < B; ++b) hipLaunchKernelGGL(fill_spd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.stream, bA + (size_t)b * total, c.ld, n);
+    else hipLaunchKernelGGL(fill_spd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.stream, c.A, c.ld, n);
     hipEventRecord(e0, c.stream);
-    gpg_cholesky(&c);
+    if (B > 1) gpg_launch_tile_chol_batch(&c, B, bA, total, bD, n, binfo);
+    else gpg_cholesky(&c);
     hipEventRecord(e1, c.stream);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -58,20 +63,20 @@ int main(int argc, char** argv) {
     const int T = impl == 1 ? 128 : 64;
     hipMemcpy(&ab, c.tile_flags + (size_t)(c.Npad / T) * (c.ld / T), sizeof(int), hipMemcpyDeviceToHost);
   }
-  printf("n=%d impl=%d: %.3f ms, %.2f TFLOP/s (n^3/3), info=%d abort=%d\n", n, impl, best, (double)n * n * n / 3.0 / best * 1e-9, info, ab);
+  printf("n=%d impl=%d: %.3f ms, %.2f TFLOP/s (n^3/3), info=%d abort=%d\n", n, impl, best, (double)B * n * n * n / 3.0 / best * 1e-9, info, ab);
 #ifdef GPG_STAMP
   {
-    std::vector<unsigned long long> hb(16384 * 16);
+    std::vector<unsigned long long> hb(GPG_STAMP_MAX * 16);
     hipMemcpy(hb.data(), dbuf, hb.size() * 8, hipMemcpyDeviceToHost);
     FILE* f = fopen("../gpurun_out/tile_timeline.csv", "w");
     if (f) {
       fprintf(f, "block,ti,tj,start,end,spin_cyc,gemm_cyc,runs,fin0,f0,f1,f2,f3,f4\n");
       unsigned long long t0 = ~0ull;
-      for (int b = 0; b < 16384; ++b) if (hb[b * 8 + 1] && hb[b * 8] < t0) t0 = hb[b * 8];
-      for (int b = 0; b < 16384; ++b) {
+      for (int b = 0; b < GPG_STAMP_MAX; ++b) if (hb[b * 8 + 1] && hb[b * 8] < t0) t0 = hb[b * 8];
+      for (int b = 0; b < GPG_STAMP_MAX; ++b) {
         const unsigned long long* o = &hb[(size_t)b * 8];
         if (o[1] == 0) continue;
-        const unsigned long long* g = &hb[(size_t)16384 * 8 + (size_t)b * 8];
+        const unsigned long long* g = &hb[(size_t)GPG_STAMP_MAX * 8 + (size_t)b * 8];
         fprintf(f, "%d,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu\n", b, o[6] & 0xffff, o[6] >> 16, o[0] - t0, o[1] - t0, o[2], o[3], o[4], o[5] - t0, g[0] - t0, g[1] - t0, g[2] - t0, g[3] - t0, g[4] ? g[4] - t0 : 0ull);
       }
       fclose(f);
