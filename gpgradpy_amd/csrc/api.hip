@@ -151,6 +151,7 @@ int gpg_create(gpg_ctx** out, int device, int n_eval, int dim, int use_grad, int
   }
   c->ng = c->use_grad ? n_eval : 0;
   c->A_elems = (size_t)c->ld * c->Npad;
+  c->vec_rows_cols = c->Npad;
   CREATE_OK(hipMalloc(&c->A, sizeof(double) * c->A_elems));
   CREATE_OK(hipMalloc(&c->gpos, sizeof(int) * c->n));
   {
@@ -181,7 +182,7 @@ void gpg_destroy(gpg_ctx* c) {
   for (auto& pe : c->prof_pending) { (void)hipEventDestroy(pe.e0); (void)hipEventDestroy(pe.e1); }
   for (auto& ev : c->prof_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   double* bufs[] = {c->A, c->Xt, c->y, c->noise, c->dvec, c->invp, c->zvec, c->tmpv, c->dinv, c->scal, c->Wt, c->xq_dev,
-                    c->musig, c->gradbuf, c->dense_tmp, c->Wfull, c->Minv, c->gpartial, c->batchA, c->batchV};
+                    c->musig, c->gradbuf, c->dense_tmp, c->Wfull, c->Minv, c->gpartial, c->batchA, c->batchV, c->vec_rows};
   for (double* b : bufs) if (b) (void)hipFree(b);
   if (c->info) (void)hipFree(c->info);
   if (c->gpos) (void)hipFree(c->gpos);

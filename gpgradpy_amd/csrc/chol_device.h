@@ -256,6 +256,95 @@ __device__ __forceinline__ void wave_tile_gemm(d4 (&acc)[4], const double* ga, i
     __builtin_amdgcn_sched_barrier(0);                                                      \
   }
 
+// Reverse quad-row substitution x <- x L^-1 (backward solve against L^T): columns are eliminated from 63 down to 0.
+// LsT is the TRANSPOSED image LsT[j][q][m] = L[j][4m + q] (row j of the block), sdinv the reciprocal pivots.
+#define GPG_QUAD_SUBST_REV(x, LsT, sdinv, q)                                                 \
+  {                                                                                         \
+    double lv[2][16];                                                                       \
+    _Pragma("unroll") for (int m = 0; m < 16; ++m) lv[1][m] = LsT[63][q][m];                 \
+    _Pragma("unroll") for (int mj = 15; mj >= 0; --mj) {                                     \
+      GPG_QS_STEP_REV(x, LsT, sdinv, q, 3)                                                   \
+      GPG_QS_STEP_REV(x, LsT, sdinv, q, 2)                                                   \
+      GPG_QS_STEP_REV(x, LsT, sdinv, q, 1)                                                   \
+      GPG_QS_STEP_REV(x, LsT, sdinv, q, 0)                                                   \
+    }                                                                                       \
+  }
+#define GPG_QS_STEP_REV(x, LsT, sdinv, q, QJ)                                                \
+  {                                                                                         \
+    constexpr int cur = QJ & 1, nxt = cur ^ 1;                                               \
+    const int jc = 4 * mj + QJ;                                                             \
+    const int jn = jc - 1 >= 0 ? jc - 1 : 0;                                                \
+    const int m1n = jn >> 2;                                                                \
+    _Pragma("unroll") for (int m = 0; m < 16; ++m) if (m <= m1n) lv[nxt][m] = LsT[jn][q][m]; \
+    const double xs = x[mj] * sdinv[jc];                                                    \
+    x[mj] = (q == QJ) ? xs : x[mj];                                                         \
+    const double xj = quad_bcast<QJ>(x[mj]);                                                \
+    if (QJ > 0) {                                                                           \
+      const double t = x[mj] - xj * lv[cur][mj];                                            \
+      x[mj] = (q < QJ) ? t : x[mj];                                                         \
+    }                                                                                       \
+    _Pragma("unroll") for (int m = 0; m < mj; ++m) x[m] -= xj * lv[cur][m];                  \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+  }
+
+// wave_tile_gemm_nn: acc (wave tile 16 x 64) -= A[64 x K] B[K x 64] with B given "k-major": gb points at
+// B[k = 0][n = 0], k runs along contiguous memory, n strides by ldb (a block of L used untransposed by the backward
+// solve).  Same staging buffers / pipeline as wave_tile_gemm; only the B staging differs: 8 consecutive threads fetch
+// the 16 k of one n (128 contiguous bytes) and scatter them into the k-major LDS rows.
+__device__ __forceinline__ void wave_tile_gemm_nn(d4 (&acc)[4], const double* ga, int lda, const double* gb, int ldb, int nchunk,
+                                                  double* sA, double* sB, int w, int l15, int l4, int sp, int sk) {
+  constexpr int KB = 16, SA = 80, BUF = KB * SA;
+  const size_t a8 = (size_t)8 * lda;
+  const int tid = threadIdx.x;
+  const int bk = 2 * (tid & 7), bn = tid >> 3;               // B staging: k pair, n (and n + 32)
+  const double* gbt = gb + bk + (size_t)bn * ldb;
+  const size_t bn32 = (size_t)32 * ldb;
+  double2 ra0_a, ra0_b, rb0_a, rb0_b, ra1_a, ra1_b, rb1_a, rb1_b;
+#define GPG_NN_GLOAD(set)                                        \
+  ra##set##_a = *reinterpret_cast<const double2*>(ga);           \
+  ra##set##_b = *reinterpret_cast<const double2*>(ga + a8);      \
+  rb##set##_a = *reinterpret_cast<const double2*>(gbt);          \
+  rb##set##_b = *reinterpret_cast<const double2*>(gbt + bn32);   \
+  ga += 2 * a8;                                                  \
+  gbt += KB;
+#define GPG_NN_SSTORE(buf, set)                                                              \
+  {                                                                                          \
+    double2 v0, v1;                                                                          \
+    v0.x = -ra##set##_a.x; v0.y = -ra##set##_a.y; v1.x = -ra##set##_b.x; v1.y = -ra##set##_b.y;  \
+    *reinterpret_cast<double2*>(sA + (buf) * BUF + sk * SA + 2 * sp) = v0;                    \
+    *reinterpret_cast<double2*>(sA + (buf) * BUF + (sk + 8) * SA + 2 * sp) = v1;              \
+    sB[(buf) * BUF + bk * SA + bn] = rb##set##_a.x;                                           \
+    sB[(buf) * BUF + (bk + 1) * SA + bn] = rb##set##_a.y;                                     \
+    sB[(buf) * BUF + bk * SA + bn + 32] = rb##set##_b.x;                                      \
+    sB[(buf) * BUF + (bk + 1) * SA + bn + 32] = rb##set##_b.y;                                \
+  }
+#define GPG_NN_COMPUTE(buf)                                                                  \
+  _Pragma("unroll") for (int kk = 0; kk < KB; kk += 4) {                                      \
+    const double fm = sA[(buf) * BUF + (kk + l4) * SA + 16 * w + l15];                        \
+    double fn[4];                                                                            \
+    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni) fn[ni] = sB[(buf) * BUF + (kk + l4) * SA + ni * 16 + l15]; \
+    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                          \
+      acc[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(fn[ni], fm, acc[ni], 0, 0, 0);           \
+  }
+  GPG_NN_GLOAD(0);
+  GPG_NN_GLOAD(1);
+  GPG_NN_SSTORE(0, 0);
+  __syncthreads();
+  for (int ch = 0; ch < nchunk; ch += 2) {
+    if (ch + 2 < nchunk) { GPG_NN_GLOAD(0); }
+    GPG_NN_COMPUTE(0);
+    GPG_NN_SSTORE(1, 1);
+    __syncthreads();
+    if (ch + 3 < nchunk) { GPG_NN_GLOAD(1); }
+    GPG_NN_COMPUTE(1);
+    if (ch + 2 < nchunk) { GPG_NN_SSTORE(0, 0); }
+    __syncthreads();
+  }
+#undef GPG_NN_GLOAD
+#undef GPG_NN_SSTORE
+#undef GPG_NN_COMPUTE
+}
+
 #ifdef GPG_STAMP   // diagnostic build of tools/gemm_probe.hip only: per-wave cycle shares of the loop phases
 __device__ unsigned long long* g_stamp_buf;
 #define GPG_STAMP_MAX 131072   // workgroups with a timeline record

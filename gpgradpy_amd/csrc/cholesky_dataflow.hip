@@ -451,6 +451,194 @@ tile128_chol_kernel(double* A, int ld, int Mt, const int* __restrict__ tasks, in
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// rows_fwd_kernel: W <- W L^-T for right-hand-side rows held OUTSIDE the matrix (rows layout, leading dimension ldw,
+// 64-row tiles) against the finished factor in A, as ONE dataflow launch: workgroup (rt, j) owns the 64 x 64 block of
+// row tile rt and column block j, accumulates  W_j - sum_{k<j} X_k L_jk^T  on MFMA as the X_k of its own row tile are
+// published (the L tiles are final), substitutes against L_jj and raises flag(rt, j).  The blocked version
+// (gpg_forward_rows: panel solve + GEMM launch per 512 columns) is bound by ~70 dependent launches of 100+ us each;
+// here the chain per 64 columns is one 64-deep MFMA block, one substitution and one flag hop.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2)
+rows_fwd_kernel(const double* __restrict__ A, int ld, const double* __restrict__ dinv, double* W, int ldw, int Mt, int nrt,
+                int* flags, int* abort_word, int* info) {
+  constexpr int KB = 16, SA = 80, BUF = KB * SA;
+  __shared__ __attribute__((aligned(16))) double U[4 * BUF];
+  __shared__ __attribute__((aligned(16))) double Ls[64][4][18];
+  __shared__ double sdinv[64];
+  __shared__ int sh_kr;
+  double* const sA = U;
+  double* const sB = U + 2 * BUF;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int tj = blockIdx.x / nrt, rt = blockIdx.x - tj * nrt;      // column-block-major task order
+  const size_t r0 = 64 * (size_t)rt, cj = 64 * (size_t)tj;
+  const int q = tid & 3;
+  const int sp = tid & 31, sk = tid >> 5;
+  int* const frow = flags + (size_t)rt * Mt;
+
+  d4 acc[4];
+  {
+    const double* Cw = W + r0 + 16 * w + l15 + (cj + l4) * (size_t)ldw;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[ni][r] = Cw[(size_t)(ni * 16 + 4 * r) * ldw];
+  }
+  {   // L_jj is final: its image is fetched before the first wait
+    const double* Ljj = A + cj + cj * (size_t)ld;
+    for (int t = tid; t < 64 * 64; t += 256) {
+      const int jj = t >> 6, k = t & 63;
+      Ls[jj][k & 3][k >> 2] = Ljj[k + (size_t)jj * ld];
+    }
+    if (tid < 64) sdinv[tid] = dinv[cj + tid];
+  }
+  int kdone = 0;
+  while (kdone < tj) {
+    if (tid == 0) {
+      int kr = kdone;
+      const unsigned long long t_wait = __builtin_amdgcn_s_memrealtime();
+      for (;;) {
+        while (kr < tj && __hip_atomic_load(frow + kr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ++kr;
+        if (kr > kdone) break;
+        if (__builtin_amdgcn_s_memrealtime() - t_wait > GPG_TILE_WAIT_TICKS ||
+            __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+          __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          atomicMax(info, GPG_INFO_INTERNAL);
+          kr = -1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      sh_kr = kr;
+    }
+    __syncthreads();
+    const int kr = sh_kr;
+    if (kr < 0) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const size_t ck = 64 * (size_t)kdone;
+    wave_tile_gemm(acc, W + r0 + 2 * sp + (ck + sk) * (size_t)ldw, ldw, A + cj + 2 * sp + (ck + sk) * (size_t)ld, ld,
+                   4 * (kr - kdone), sA, sB, w, l15, l4, sp, sk);
+    __syncthreads();
+    kdone = kr;
+  }
+  {
+    double* Ts = U;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Ts[(ni * 16 + 4 * r + l4) * SA + 16 * w + l15] = acc[ni][r];
+  }
+  __syncthreads();
+  double x[16];
+  {
+    const double* Tr = U + q * SA + (tid >> 2);
+#pragma unroll
+    for (int m = 0; m < 16; ++m) x[m] = Tr[(4 * m) * SA];
+  }
+  GPG_QUAD_SUBST(x, Ls, sdinv, q)
+  double* Xr = W + r0 + (tid >> 2) + (cj + q) * (size_t)ldw;
+#pragma unroll
+  for (int m = 0; m < 16; ++m) Xr[(size_t)(4 * m) * ldw] = x[m];
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(frow + tj, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ------------------------------------------------------------------------------------------------
+// rows_bwd_kernel: Z <- Z L^-1 (every row solved against L^T) for right-hand-side rows in the rows layout, ONE
+// dataflow launch, column blocks from the last to the first: workgroup (rt, j) accumulates
+// Z_j - sum_{k>j} Z_k L_kj on MFMA (L_kj used untransposed: k-major staging) as the Z_k of its row tile are
+// published, then runs the reverse substitution against L_jj.  Replaces 2 x Npad/64 dependent launches
+// (gpg_backward_rows).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2)
+rows_bwd_kernel(const double* __restrict__ A, int ld, const double* __restrict__ dinv, double* Z, int ldz, int Mt, int nrt,
+                int* flags, int* abort_word, int* info) {
+  constexpr int KB = 16, SA = 80, BUF = KB * SA;
+  __shared__ __attribute__((aligned(16))) double U[4 * BUF];
+  __shared__ __attribute__((aligned(16))) double Ls[64][4][18];   // transposed image: Ls[j][q][m] = L_jj[j][4m + q]
+  __shared__ double sdinv[64];
+  __shared__ int sh_kr;
+  double* const sA = U;
+  double* const sB = U + 2 * BUF;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int jr = blockIdx.x / nrt, rt = blockIdx.x - jr * nrt;
+  const int tj = Mt - 1 - jr;                                      // last column block first
+  const size_t r0 = 64 * (size_t)rt, cj = 64 * (size_t)tj;
+  const int q = tid & 3;
+  const int sp = tid & 31, sk = tid >> 5;
+  int* const frow = flags + (size_t)rt * Mt;
+
+  d4 acc[4];
+  {
+    const double* Cw = Z + r0 + 16 * w + l15 + (cj + l4) * (size_t)ldz;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[ni][r] = Cw[(size_t)(ni * 16 + 4 * r) * ldz];
+  }
+  {
+    const double* Ljj = A + cj + cj * (size_t)ld;
+    for (int t = tid; t < 64 * 64; t += 256) {
+      const int cc = t >> 6, rr = t & 63;                          // element L_jj[rr][cc], read down the column
+      Ls[rr][cc & 3][cc >> 2] = Ljj[rr + (size_t)cc * ld];
+    }
+    if (tid < 64) sdinv[tid] = dinv[cj + tid];
+  }
+  int khi = Mt;                                                    // blocks [khi, Mt) are applied
+  while (khi > tj + 1) {
+    if (tid == 0) {
+      int kr = khi;
+      const unsigned long long t_wait = __builtin_amdgcn_s_memrealtime();
+      for (;;) {
+        while (kr > tj + 1 && __hip_atomic_load(frow + kr - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) --kr;
+        if (kr < khi) break;
+        if (__builtin_amdgcn_s_memrealtime() - t_wait > GPG_TILE_WAIT_TICKS ||
+            __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+          __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          atomicMax(info, GPG_INFO_INTERNAL);
+          kr = -1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      sh_kr = kr;
+    }
+    __syncthreads();
+    const int kr = sh_kr;
+    if (kr < 0) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const size_t ck = 64 * (size_t)kr;                             // contraction rows [64 kr, 64 khi)
+    wave_tile_gemm_nn(acc, Z + r0 + 2 * sp + (ck + sk) * (size_t)ldz, ldz, A + ck + cj * (size_t)ld, ld, 4 * (khi - kr), sA, sB, w,
+                      l15, l4, sp, sk);
+    __syncthreads();
+    khi = kr;
+  }
+  {
+    double* Ts = U;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Ts[(ni * 16 + 4 * r + l4) * SA + 16 * w + l15] = acc[ni][r];
+  }
+  __syncthreads();
+  double x[16];
+  {
+    const double* Tr = U + q * SA + (tid >> 2);
+#pragma unroll
+    for (int m = 0; m < 16; ++m) x[m] = Tr[(4 * m) * SA];
+  }
+  GPG_QUAD_SUBST_REV(x, Ls, sdinv, q)
+  double* Xr = Z + r0 + (tid >> 2) + (cj + q) * (size_t)ldz;
+#pragma unroll
+  for (int m = 0; m < 16; ++m) Xr[(size_t)(4 * m) * ldz] = x[m];
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(frow + tj, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Column-major task list of the dataflow factorisation (Mt tile columns, Rt >= Mt tile rows), cached per shape.
 const TileMap& get_tile_tasks(gpg_ctx* c, int Mt, int Rt) {
   const unsigned long long key = (1ull << 63) | ((unsigned long long)Mt << 20) | (unsigned)Rt;
@@ -580,10 +768,45 @@ static void launch_tile128_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a
   gpg_prof_end(c);
 }
 
+// W (rows x Npad, rows a multiple of 64) <- W L^-T with the dataflow kernel; returns false if it does not apply.
+static bool launch_rows_bwd(gpg_ctx* c, double* Z, int ldz, int rows) {
+  if (rows <= 0 || rows % 64 != 0) return false;
+  const int Mt = c->Npad / 64, nrt = rows / 64;
+  if ((long)Mt * nrt > 4096) return false;
+  const size_t nflag = (size_t)Mt * nrt + 1;
+  if (c->tile_flags_cap < nflag) {
+    if (c->tile_flags) (void)hipFree(c->tile_flags);
+    (void)hipMalloc(&c->tile_flags, sizeof(int) * nflag);
+    c->tile_flags_cap = nflag;
+  }
+  (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
+  hipLaunchKernelGGL(rows_bwd_kernel, dim3(Mt * nrt), dim3(256), 0, c->stream, (const double*)c->A, c->ld, (const double*)c->dinv, Z,
+                     ldz, Mt, nrt, c->tile_flags, c->tile_flags + (nflag - 1), c->info);
+  return true;
+}
+
+static bool launch_rows_fwd(gpg_ctx* c, double* W, int ldw, int rows) {
+  if (rows <= 0 || rows % 64 != 0) return false;
+  const int Mt = c->Npad / 64, nrt = rows / 64;
+  if ((long)Mt * nrt > 4096) return false;             // many rows: the blocked sweep is throughput-bound, not latency-bound
+  const size_t nflag = (size_t)Mt * nrt + 1;
+  if (c->tile_flags_cap < nflag) {
+    if (c->tile_flags) (void)hipFree(c->tile_flags);
+    (void)hipMalloc(&c->tile_flags, sizeof(int) * nflag);
+    c->tile_flags_cap = nflag;
+  }
+  (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
+  hipLaunchKernelGGL(rows_fwd_kernel, dim3(Mt * nrt), dim3(256), 0, c->stream, (const double*)c->A, c->ld, (const double*)c->dinv, W,
+                     ldw, Mt, nrt, c->tile_flags, c->tile_flags + (nflag - 1), c->info);
+  return true;
+}
+
 }  // namespace
 
 void gpg_launch_tile_chol(gpg_ctx* c, int c0) { launch_tile_chol(c, c0); }
 void gpg_launch_tile128_chol(gpg_ctx* c) { launch_tile128_chol(c); }
+bool gpg_launch_rows_fwd(gpg_ctx* c, double* W, int ldw, int rows) { return launch_rows_fwd(c, W, ldw, rows); }
+bool gpg_launch_rows_bwd(gpg_ctx* c, double* Z, int ldz, int rows) { return launch_rows_bwd(c, Z, ldz, rows); }
 void gpg_launch_tile_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a_stride, double* dinv_base, int d_stride,
                                 int* info_base) {
   if (c->tail_cols > 0 && c->Npad <= c->tail_cols) launch_tile_chol_batch(c, B, Abase, a_stride, dinv_base, d_stride, info_base);

@@ -62,6 +62,8 @@ struct gpg_ctx {
   double* dinv = nullptr;    // [Npad] reciprocal pivots 1 / L_jj of the factor in A
   double* scal = nullptr;    // device scalars of the reductions
   int* info = nullptr;       // device: first failing pivot (0 = none)
+  double* vec_rows = nullptr;   // [64 x vec_rows_cols] carrier tile of the single-vector backward solve (on first use)
+  int vec_rows_cols = 0;        // = Npad of the full-gradient shape (allocation size)
   double* Wt = nullptr;      // prediction RHS rows [wt_rows x Npad]
   int wt_rows = 0;
   double* xq_dev = nullptr;  // [d x nxp]
@@ -105,6 +107,8 @@ void gpg_launch_assembly(gpg_ctx* c, const AsmParams& p);
 void gpg_launch_cross(gpg_ctx* c, const AsmParams& p, int nx, int nxp);   // Wt <- P^-1 Kyx (transposed)
 void gpg_launch_tile_chol(gpg_ctx* c, int c0);                          // dataflow factorisation of A[c0:, c0:], 64-tiles
 void gpg_launch_tile128_chol(gpg_ctx* c);
+bool gpg_launch_rows_fwd(gpg_ctx* c, double* W, int ldw, int rows);
+bool gpg_launch_rows_bwd(gpg_ctx* c, double* Z, int ldz, int rows);      // dataflow Z <- Z L^-1 (all rows of the 64-row tiles)      // dataflow W <- W L^-T (few row tiles); false: not applicable
 void gpg_launch_tile_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a_stride, double* dinv_base, int d_stride,
                                 int* info_base);                              // dataflow factorisation, 128-tiles (whole matrix)
 void gpg_cholesky(gpg_ctx* c);                                           // blocked right-looking, in place

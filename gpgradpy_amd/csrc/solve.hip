@@ -452,6 +452,22 @@ void gpg_launch_lkd_reduce(gpg_ctx* c, int slot) {
 
 void gpg_backward_solve(gpg_ctx* c) {
   const int Npad = c->Npad;
+  if (c->chol_impl != 0 || c->tail_cols != 0) {
+    // the vector rides as row 0 of a zeroed 64-row tile through the dataflow backward solve (one launch instead of
+    // 2 Npad / 64 dependent ones)
+    if (!c->vec_rows) (void)hipMalloc(&c->vec_rows, sizeof(double) * 64 * (size_t)c->vec_rows_cols);
+    if (c->vec_rows) {
+      (void)hipMemsetAsync(c->vec_rows, 0, sizeof(double) * 64 * (size_t)Npad, c->stream);
+      // right-hand side: the forward-solved RHS row 0 of the factorisation workspace (row Npad of A)
+      (void)hipMemcpy2DAsync(c->vec_rows, 64 * sizeof(double), c->A + Npad, (size_t)c->ld * sizeof(double), sizeof(double), Npad,
+                             hipMemcpyDeviceToDevice, c->stream);
+      if (gpg_launch_rows_bwd(c, c->vec_rows, 64, 64)) {
+        (void)hipMemcpy2DAsync(c->zvec, sizeof(double), c->vec_rows, 64 * sizeof(double), sizeof(double), Npad,
+                               hipMemcpyDeviceToDevice, c->stream);
+        return;
+      }
+    }
+  }
   for (int k0 = Npad - 64; k0 >= 0; k0 -= 64) {
     const int has_t = (k0 + 64 < Npad);
     if (has_t)
@@ -462,6 +478,8 @@ void gpg_backward_solve(gpg_ctx* c) {
 
 // Z (nrhs x Npad, RHS-rows layout, leading dimension ldz) <- Z L^-1, i.e. every row solved against L^T
 void gpg_backward_rows(gpg_ctx* c, double* Z, int ldz, int nrhs, double* tbuf) {
+  // one dataflow launch over the 64-row tiles that hold the nrhs rows (the other rows of a tile ride along)
+  if ((c->chol_impl != 0 || c->tail_cols != 0) && gpg_launch_rows_bwd(c, Z, ldz, ((nrhs + 63) / 64) * 64)) return;
   const int Npad = c->Npad;
   for (int k0 = Npad - 64; k0 >= 0; k0 -= 64) {
     const int has_t = (k0 + 64 < Npad);
