@@ -511,7 +511,7 @@ static int predict_impl(gpg_ctx* c, int nx, const double* xq, double varK, doubl
   AsmParams p = c->eval_params;
   gpg_launch_cross(c, p, nx, nxp);
   gpg_launch_predict_reduce(c, nx, nxp, c->eval_beta, varK, 0);
-  gpg_forward_rows(c, c->Wt, nxp, nxp);
+  gpg_forward_rows(c, c->Wt, nxp, nxp, nx);
   gpg_launch_predict_reduce(c, nx, nxp, c->eval_beta, varK, 1);
   std::vector<double> hgrad;
   if (dmudx) {
@@ -560,7 +560,7 @@ int gpg_predict_hess(gpg_ctx* c, const double* xq, double varK, double* mu, doub
   gpg_launch_hess_stage(c, p, nxp, h1, h2, T, 0);
   GPG_HIP_OK(c, hipMemsetAsync(c->Wt, 0, sizeof(double) * (size_t)nxp * c->Npad, c->stream));
   gpg_launch_hess_stage(c, p, nxp, h1, h2, T, 1);
-  gpg_forward_rows(c, c->Wt, nxp, nxp);
+  gpg_forward_rows(c, c->Wt, nxp, nxp, d + 1);
   gpg_launch_hess_stage(c, p, nxp, h1, h2, T, 2);
   std::vector<double> h(3 * GPG_MAX_DIM * GPG_MAX_DIM);
   GPG_HIP_OK(c, hipMemcpyAsync(h.data(), h1, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream));

@@ -461,7 +461,7 @@ tile128_chol_kernel(double* A, int ld, int Mt, const int* __restrict__ tasks, in
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256, 2)
 rows_fwd_kernel(const double* __restrict__ A, int ld, const double* __restrict__ dinv, double* W, int ldw, int Mt, int nrt,
-                int* flags, int* abort_word, int* info) {
+                int valid, int* flags, int* abort_word, int* info) {
   constexpr int KB = 16, SA = 80, BUF = KB * SA;
   __shared__ __attribute__((aligned(16))) double U[4 * BUF];
   __shared__ __attribute__((aligned(16))) double Ls[64][4][18];
@@ -536,7 +536,9 @@ rows_fwd_kernel(const double* __restrict__ A, int ld, const double* __restrict__
 #pragma unroll
     for (int m = 0; m < 16; ++m) x[m] = Tr[(4 * m) * SA];
   }
-  GPG_QUAD_SUBST(x, Ls, sdinv, q)
+  if (64 * rt + 16 * w < valid) {   // rows >= valid are zero (and stay zero): their waves skip the substitution
+    GPG_QUAD_SUBST(x, Ls, sdinv, q)
+  }
   double* Xr = W + r0 + (tid >> 2) + (cj + q) * (size_t)ldw;
 #pragma unroll
   for (int m = 0; m < 16; ++m) Xr[(size_t)(4 * m) * ldw] = x[m];
@@ -554,7 +556,7 @@ rows_fwd_kernel(const double* __restrict__ A, int ld, const double* __restrict__
 // ------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256, 2)
 rows_bwd_kernel(const double* __restrict__ A, int ld, const double* __restrict__ dinv, double* Z, int ldz, int Mt, int nrt,
-                int* flags, int* abort_word, int* info) {
+                int valid, int* flags, int* abort_word, int* info) {
   constexpr int KB = 16, SA = 80, BUF = KB * SA;
   __shared__ __attribute__((aligned(16))) double U[4 * BUF];
   __shared__ __attribute__((aligned(16))) double Ls[64][4][18];   // transposed image: Ls[j][q][m] = L_jj[j][4m + q]
@@ -630,7 +632,9 @@ rows_bwd_kernel(const double* __restrict__ A, int ld, const double* __restrict__
 #pragma unroll
     for (int m = 0; m < 16; ++m) x[m] = Tr[(4 * m) * SA];
   }
-  GPG_QUAD_SUBST_REV(x, Ls, sdinv, q)
+  if (64 * rt + 16 * w < valid) {
+    GPG_QUAD_SUBST_REV(x, Ls, sdinv, q)
+  }
   double* Xr = Z + r0 + (tid >> 2) + (cj + q) * (size_t)ldz;
 #pragma unroll
   for (int m = 0; m < 16; ++m) Xr[(size_t)(4 * m) * ldz] = x[m];
@@ -769,7 +773,7 @@ static void launch_tile128_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a
 }
 
 // W (rows x Npad, rows a multiple of 64) <- W L^-T with the dataflow kernel; returns false if it does not apply.
-static bool launch_rows_bwd(gpg_ctx* c, double* Z, int ldz, int rows) {
+static bool launch_rows_bwd(gpg_ctx* c, double* Z, int ldz, int rows, int valid) {
   if (rows <= 0 || rows % 64 != 0) return false;
   const int Mt = c->Npad / 64, nrt = rows / 64;
   if ((long)Mt * nrt > 4096) return false;
@@ -781,11 +785,11 @@ static bool launch_rows_bwd(gpg_ctx* c, double* Z, int ldz, int rows) {
   }
   (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
   hipLaunchKernelGGL(rows_bwd_kernel, dim3(Mt * nrt), dim3(256), 0, c->stream, (const double*)c->A, c->ld, (const double*)c->dinv, Z,
-                     ldz, Mt, nrt, c->tile_flags, c->tile_flags + (nflag - 1), c->info);
+                     ldz, Mt, nrt, valid < 0 ? rows : valid, c->tile_flags, c->tile_flags + (nflag - 1), c->info);
   return true;
 }
 
-static bool launch_rows_fwd(gpg_ctx* c, double* W, int ldw, int rows) {
+static bool launch_rows_fwd(gpg_ctx* c, double* W, int ldw, int rows, int valid) {
   if (rows <= 0 || rows % 64 != 0) return false;
   const int Mt = c->Npad / 64, nrt = rows / 64;
   if ((long)Mt * nrt > 4096) return false;             // many rows: the blocked sweep is throughput-bound, not latency-bound
@@ -797,7 +801,7 @@ static bool launch_rows_fwd(gpg_ctx* c, double* W, int ldw, int rows) {
   }
   (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
   hipLaunchKernelGGL(rows_fwd_kernel, dim3(Mt * nrt), dim3(256), 0, c->stream, (const double*)c->A, c->ld, (const double*)c->dinv, W,
-                     ldw, Mt, nrt, c->tile_flags, c->tile_flags + (nflag - 1), c->info);
+                     ldw, Mt, nrt, valid < 0 ? rows : valid, c->tile_flags, c->tile_flags + (nflag - 1), c->info);
   return true;
 }
 
@@ -805,8 +809,8 @@ static bool launch_rows_fwd(gpg_ctx* c, double* W, int ldw, int rows) {
 
 void gpg_launch_tile_chol(gpg_ctx* c, int c0) { launch_tile_chol(c, c0); }
 void gpg_launch_tile128_chol(gpg_ctx* c) { launch_tile128_chol(c); }
-bool gpg_launch_rows_fwd(gpg_ctx* c, double* W, int ldw, int rows) { return launch_rows_fwd(c, W, ldw, rows); }
-bool gpg_launch_rows_bwd(gpg_ctx* c, double* Z, int ldz, int rows) { return launch_rows_bwd(c, Z, ldz, rows); }
+bool gpg_launch_rows_fwd(gpg_ctx* c, double* W, int ldw, int rows, int valid) { return launch_rows_fwd(c, W, ldw, rows, valid); }
+bool gpg_launch_rows_bwd(gpg_ctx* c, double* Z, int ldz, int rows, int valid) { return launch_rows_bwd(c, Z, ldz, rows, valid); }
 void gpg_launch_tile_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a_stride, double* dinv_base, int d_stride,
                                 int* info_base) {
   if (c->tail_cols > 0 && c->Npad <= c->tail_cols) launch_tile_chol_batch(c, B, Abase, a_stride, dinv_base, d_stride, info_base);

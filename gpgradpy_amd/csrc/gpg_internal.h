@@ -107,12 +107,14 @@ void gpg_launch_assembly(gpg_ctx* c, const AsmParams& p);
 void gpg_launch_cross(gpg_ctx* c, const AsmParams& p, int nx, int nxp);   // Wt <- P^-1 Kyx (transposed)
 void gpg_launch_tile_chol(gpg_ctx* c, int c0);                          // dataflow factorisation of A[c0:, c0:], 64-tiles
 void gpg_launch_tile128_chol(gpg_ctx* c);
-bool gpg_launch_rows_fwd(gpg_ctx* c, double* W, int ldw, int rows);
-bool gpg_launch_rows_bwd(gpg_ctx* c, double* Z, int ldz, int rows);      // dataflow Z <- Z L^-1 (all rows of the 64-row tiles)      // dataflow W <- W L^-T (few row tiles); false: not applicable
+// dataflow W <- W L^-T / Z <- Z L^-1 for a few 64-row tiles; rows >= valid must be zero (their substitution is skipped);
+// false: not applicable (caller falls back on the blocked sweep)
+bool gpg_launch_rows_fwd(gpg_ctx* c, double* W, int ldw, int rows, int valid);
+bool gpg_launch_rows_bwd(gpg_ctx* c, double* Z, int ldz, int rows, int valid);
 void gpg_launch_tile_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a_stride, double* dinv_base, int d_stride,
                                 int* info_base);                              // dataflow factorisation, 128-tiles (whole matrix)
 void gpg_cholesky(gpg_ctx* c);                                           // blocked right-looking, in place
-void gpg_forward_rows(gpg_ctx* c, double* W, int ldw, int rows);         // W <- W L^-T (rows = RHS rows)
+void gpg_forward_rows(gpg_ctx* c, double* W, int ldw, int rows, int valid = -1);   // W <- W L^-T (rows >= valid are zero)
 void gpg_launch_lkd_reduce(gpg_ctx* c, int slot);                        // writes scal[slot*8 ..]
 void gpg_backward_solve(gpg_ctx* c);                                     // zvec <- L^-T (RHS row 0)
 void gpg_launch_alpha(gpg_ctx* c, double* alpha_dev);                    // alpha = zvec * invp

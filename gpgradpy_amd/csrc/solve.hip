@@ -461,7 +461,7 @@ void gpg_backward_solve(gpg_ctx* c) {
       // right-hand side: the forward-solved RHS row 0 of the factorisation workspace (row Npad of A)
       (void)hipMemcpy2DAsync(c->vec_rows, 64 * sizeof(double), c->A + Npad, (size_t)c->ld * sizeof(double), sizeof(double), Npad,
                              hipMemcpyDeviceToDevice, c->stream);
-      if (gpg_launch_rows_bwd(c, c->vec_rows, 64, 64)) {
+      if (gpg_launch_rows_bwd(c, c->vec_rows, 64, 64, 1)) {
         (void)hipMemcpy2DAsync(c->zvec, sizeof(double), c->vec_rows, 64 * sizeof(double), sizeof(double), Npad,
                                hipMemcpyDeviceToDevice, c->stream);
         return;
@@ -479,7 +479,7 @@ void gpg_backward_solve(gpg_ctx* c) {
 // Z (nrhs x Npad, RHS-rows layout, leading dimension ldz) <- Z L^-1, i.e. every row solved against L^T
 void gpg_backward_rows(gpg_ctx* c, double* Z, int ldz, int nrhs, double* tbuf) {
   // one dataflow launch over the 64-row tiles that hold the nrhs rows (the other rows of a tile ride along)
-  if ((c->chol_impl != 0 || c->tail_cols != 0) && gpg_launch_rows_bwd(c, Z, ldz, ((nrhs + 63) / 64) * 64)) return;
+  if ((c->chol_impl != 0 || c->tail_cols != 0) && gpg_launch_rows_bwd(c, Z, ldz, ((nrhs + 63) / 64) * 64, nrhs)) return;
   const int Npad = c->Npad;
   for (int k0 = Npad - 64; k0 >= 0; k0 -= 64) {
     const int has_t = (k0 + 64 < Npad);
