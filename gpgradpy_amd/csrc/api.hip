@@ -367,7 +367,11 @@ static int gpg_lkd_batch_once(gpg_ctx* c, int m, const double* hp_rows, int row_
     if (rc) return rc;
   }
   GPG_HIP_OK(c, hipMemsetAsync(c->info, 0, sizeof(int) * m, c->stream));
-  const int B = batch_plan(c, m);
+  int B = batch_plan(c, m);
+  if (B > 1) {   // equal groups (10 rows with room for 8 -> 5 + 5, not 8 + 2)
+    const int ngroups = (m + B - 1) / B;
+    B = (m + ngroups - 1) / ngroups;
+  }
   if (B > 1) {
     double *A0 = c->A, *dvec0 = c->dvec, *invp0 = c->invp, *dinv0 = c->dinv;
     int* info0 = c->info;
