@@ -34,6 +34,14 @@ def lhs_sample(xlimits, n, seed=1):
     return xlimits[:, 0] + u * (xlimits[:, 1] - xlimits[:, 0])
 
 
+def _nanmedian(a, width=None):
+    """np.median of a history slice; an empty slice gives NaN (per column) without NumPy's warnings."""
+    a = np.asarray(a, dtype=float)
+    if a.shape[0] == 0:
+        return np.full(width, np.nan) if width is not None else np.nan
+    return np.median(a, axis=0)
+
+
 class HparaOptz:
     """Mixin for `gpgradpy_amd.GaussianProcess`."""
 
@@ -133,7 +141,11 @@ class HparaOptz:
         lhs_lb, lhs_ub = np.full(n_hp, np.nan), np.full(n_hp, np.nan)
         box_lb, box_ub = np.full(n_hp, np.nan), np.full(n_hp, np.nan)
 
-        def fill(idx, med, rng):
+        def fill(idx, med, rng, init=None):
+            # no stored history yet (i_optz = 0, or rows never filled): the reference would take the median of an empty
+            # slice (NaN) and stop with 'Invalid bounds'; start from the initial hyperparameter instead
+            if init is not None:
+                med = np.where(np.isnan(med), init, med)
             med = np.minimum(np.maximum(med, rng[0]), rng[1])
             lhs_lb[idx] = np.maximum(med / lhs_factor, rng[0])
             lhs_ub[idx] = np.minimum(med * lhs_factor, rng[1])
@@ -141,16 +153,16 @@ class HparaOptz:
             box_ub[idx] = np.minimum(med * box_factor, rng[1])
 
         if hp_optz_info.has_theta:
-            fill(hp_optz_info.idx_theta, np.median(self.hp_theta_all[idx_min:idx_max, :], axis=0), self.hp_theta_range)
+            fill(hp_optz_info.idx_theta, _nanmedian(self.hp_theta_all[idx_min:idx_max, :], self.dim), self.hp_theta_range, self.hp_theta_init)
         if hp_optz_info.has_kernel:
             raise NotImplementedError('kernels with their own hyperparameter are outside the accelerated path')
         if hp_optz_info.has_varK:
-            fill(hp_optz_info.idx_varK, np.median(self.hp_varK_all[idx_min:idx_max]), self.hp_varK_range)
+            fill(hp_optz_info.idx_varK, _nanmedian(self.hp_varK_all[idx_min:idx_max]), self.hp_varK_range, self.hp_varK_init)
         if hp_optz_info.has_var_fval:
-            med = np.max((self.hp_var_fval_range[0], np.median(self.hp_var_fval_all[idx_min:idx_max])))
+            med = np.fmax(self.hp_var_fval_range[0], _nanmedian(self.hp_var_fval_all[idx_min:idx_max]))
             fill(hp_optz_info.idx_var_fval, med, self.hp_var_fval_range)
         if hp_optz_info.has_var_fgrad:
-            med = np.max((self.hp_var_fgrad_range[0], np.median(self.hp_var_fgrad_all[idx_min:idx_max])))
+            med = np.fmax(self.hp_var_fgrad_range[0], _nanmedian(self.hp_var_fgrad_all[idx_min:idx_max]))
             fill(hp_optz_info.idx_var_fgrad, med, self.hp_var_fgrad_range)
 
         bvec = hp_optz_info.bvec_log_optz

@@ -113,3 +113,23 @@ def test_optz_hp_flow_matches_reference(path):
         assert GP.hp_optz_success[it] == c[f"it{it}_success"]
     GP.set_hpara('stored', 1)
     np.testing.assert_allclose(GP.hp_vals.theta, GP.hp_theta_all[1])
+
+
+@pytest.mark.gpu
+def test_first_optimisation_without_history():
+    """i_optz = 0 with more than hp_const_n_eval points: no stored hyperparameters to take a median of (the reference
+    stops with 'Invalid bounds' there); the start rows are then centred on the initial hyperparameters."""
+    import gpgradpy_amd
+    from oracle import gp_oracle as orc
+    n, d = 20, 3
+    X, f, g = orc.synthetic_design(n, d, seed=4)
+    GP = gpgradpy_amd.GaussianProcess(d, True, 'SqExp', 'precon')
+    GP.lkd_hp_best_n_eval = 10
+    GP.init_optz_surr(3)
+    GP.set_data(X, f, np.zeros(n), g, np.zeros((n, d)))
+    hp_x0, bounds = GP.get_hp_x0_lhs_median(0, GP.hp_info_optz_lkd, 10)
+    np.testing.assert_allclose(bounds.lb, np.log10(GP.hp_theta_init / GP.hp_box_bound_factor) * np.ones(d))
+    GP.set_hpara('optz', 0)
+    assert np.all(np.isfinite(GP.hp_theta_all[0])) and GP.hp_optz_success[0] == 1.0
+    start = GP.make_hp_class(theta=GP.hp_theta_init * np.ones(d))
+    assert GP.calc_lkd_all(GP.make_hp_class(theta=GP.hp_vals.theta))[0].ln_lkd >= GP.calc_lkd_all(start)[0].ln_lkd
