@@ -182,7 +182,7 @@ void gpg_destroy(gpg_ctx* c) {
   for (auto& pe : c->prof_pending) { (void)hipEventDestroy(pe.e0); (void)hipEventDestroy(pe.e1); }
   for (auto& ev : c->prof_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   double* bufs[] = {c->A, c->Xt, c->y, c->noise, c->dvec, c->invp, c->zvec, c->tmpv, c->dinv, c->scal, c->Wt, c->xq_dev,
-                    c->musig, c->gradbuf, c->dense_tmp, c->Wfull, c->Minv, c->gpartial, c->batchA, c->batchV, c->vec_rows};
+                    c->musig, c->gradbuf, c->dense_tmp, c->Wfull, c->Minv, c->gpartial, c->batchA, c->batchV, c->vec_rows, c->vec_x};
   for (double* b : bufs) if (b) (void)hipFree(b);
   if (c->info) (void)hipFree(c->info);
   if (c->gpos) (void)hipFree(c->gpos);
@@ -477,14 +477,22 @@ int gpg_factor_fallbacks(gpg_ctx* c) { return c ? c->factor_fallbacks : -1; }
 static int predict_impl(gpg_ctx* c, int nx, const double* xq, double varK, double* mu, double* sig, double* sig2_raw,
                         double* dmudx, double* dsigdx);
 
+// The dataflow triangular solves of the posterior have the same bounded waits as the factorisation; the factor in A
+// is untouched by them, so the evaluation is simply repeated with the blocked sweeps.
+static int solve_failure(gpg_ctx* c) {
+  if (*c->h_info != GPG_INFO_INTERNAL) return 0;
+  c->err = "dataflow triangular solve: a dependency wait timed out (another dataflow launch on this device?)";
+  return -4;
+}
+
 int gpg_predict(gpg_ctx* c, int nx, const double* xq, double varK, double* mu, double* sig, double* sig2_raw) {
-  return predict_impl(c, nx, xq, varK, mu, sig, sig2_raw, nullptr, nullptr);
+  return with_fallback(c, [&] { return predict_impl(c, nx, xq, varK, mu, sig, sig2_raw, nullptr, nullptr); });
 }
 
 int gpg_predict_grad(gpg_ctx* c, int nx, const double* xq, double varK, double* mu, double* sig, double* sig2_raw,
                      double* dmudx, double* dsigdx) {
   if (c && (!dmudx || !dsigdx)) { c->err = "dmudx / dsigdx is NULL"; return -1; }
-  return predict_impl(c, nx, xq, varK, mu, sig, sig2_raw, dmudx, dsigdx);
+  return with_fallback(c, [&] { return predict_impl(c, nx, xq, varK, mu, sig, sig2_raw, dmudx, dsigdx); });
 }
 
 static int predict_impl(gpg_ctx* c, int nx, const double* xq, double varK, double* mu, double* sig, double* sig2_raw,
@@ -512,6 +520,7 @@ static int predict_impl(gpg_ctx* c, int nx, const double* xq, double varK, doubl
     for (int k = 0; k < c->d; ++k) xt[(size_t)k * nxp + j] = xq[(size_t)j * c->d + k];
   GPG_HIP_OK(c, hipMemcpyAsync(c->xq_dev, xt.data(), sizeof(double) * xt.size(), hipMemcpyHostToDevice, c->stream));
   GPG_HIP_OK(c, hipMemsetAsync(c->Wt, 0, sizeof(double) * (size_t)nxp * c->Npad, c->stream));
+  GPG_HIP_OK(c, hipMemsetAsync(c->info, 0, sizeof(int), c->stream));
   AsmParams p = c->eval_params;
   gpg_launch_cross(c, p, nx, nxp);
   gpg_launch_predict_reduce(c, nx, nxp, c->eval_beta, varK, 0);
@@ -530,8 +539,10 @@ static int predict_impl(gpg_ctx* c, int nx, const double* xq, double varK, doubl
   }
   std::vector<double> host(2 * (size_t)nxp);
   GPG_HIP_OK(c, hipMemcpyAsync(host.data(), c->musig, sizeof(double) * 2 * nxp, hipMemcpyDeviceToHost, c->stream));
+  GPG_HIP_OK(c, hipMemcpyAsync(c->h_info, c->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
   GPG_HIP_OK(c, hipGetLastError());
+  if (solve_failure(c)) return -4;
   const double sigK = sqrt(varK);
   for (int j = 0; j < nx; ++j) {
     mu[j] = host[j];
@@ -549,9 +560,17 @@ static int predict_impl(gpg_ctx* c, int nx, const double* xq, double varK, doubl
   return 0;
 }
 
+static int predict_hess_once(gpg_ctx* c, const double* xq, double varK, double* mu, double* sig, double* dmudx,
+                             double* dsigdx, double* d2mudx2, double* d2sigdx2);
+
 int gpg_predict_hess(gpg_ctx* c, const double* xq, double varK, double* mu, double* sig, double* dmudx, double* dsigdx,
                      double* d2mudx2, double* d2sigdx2) {
   if (c && (!d2mudx2 || !d2sigdx2 || !dmudx || !dsigdx)) { c->err = "Hessian / gradient output is NULL"; return -1; }
+  return with_fallback(c, [&] { return predict_hess_once(c, xq, varK, mu, sig, dmudx, dsigdx, d2mudx2, d2sigdx2); });
+}
+
+static int predict_hess_once(gpg_ctx* c, const double* xq, double varK, double* mu, double* sig, double* dmudx,
+                             double* dsigdx, double* d2mudx2, double* d2sigdx2) {
   double s2 = 0.0;
   int rc = predict_impl(c, 1, xq, varK, mu, sig, &s2, dmudx, dsigdx);   // leaves K^-1 Kyx in row 0 of Wt
   if (rc) return rc;
@@ -568,8 +587,10 @@ int gpg_predict_hess(gpg_ctx* c, const double* xq, double varK, double* mu, doub
   gpg_launch_hess_stage(c, p, nxp, h1, h2, T, 2);
   std::vector<double> h(3 * GPG_MAX_DIM * GPG_MAX_DIM);
   GPG_HIP_OK(c, hipMemcpyAsync(h.data(), h1, sizeof(double) * h.size(), hipMemcpyDeviceToHost, c->stream));
+  GPG_HIP_OK(c, hipMemcpyAsync(c->h_info, c->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
   GPG_HIP_OK(c, hipGetLastError());
+  if (solve_failure(c)) return -4;
   const double* H1 = h.data();
   const double* H2 = H1 + GPG_MAX_DIM * GPG_MAX_DIM;
   const double* TT = H2 + GPG_MAX_DIM * GPG_MAX_DIM;

@@ -643,6 +643,105 @@ rows_bwd_kernel(const double* __restrict__ A, int ld, const double* __restrict__
   if (tid == 0) __hip_atomic_store(frow + tj, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ------------------------------------------------------------------------------------------------
+// vec_solve_kernel<BWD, RR>: the same dataflow solves for at most RR (1 or 4) right-hand-side rows (posterior
+// evaluation at one point, the alpha vector): no MFMA tile, no 64-row substitution.  Workgroup j owns column block
+// j; lane <-> column c of the block, wave w accumulates the quarter m in [16w, 16w+16) of every finished block k
+//     FWD: t[r][c] -= x_k[r][m] L[64j + c][64k + m]   (k < j)        BWD: t[r][c] -= z_k[r][m] L[64k + m][64j + c]  (k > j)
+// with L read straight from memory (the block applied next is prefetched while the wave polls).  The solution is
+// exchanged through a compact copy xc[r][Npad] that the host fills with a NaN sentinel: THE DATA IS THE FLAG -- a
+// producer publishes x_k with agent-scope atomic stores, a consumer wave re-reads the 16 values it needs (one line)
+// until none is the sentinel; no separate flag, no release/acquire fence on the chain.  The values are broadcast by
+// v_readlane.  No barrier until the four partial sums meet in LDS; wave r (< R) then runs the 64-step substitution
+// of row r in the scaled variable u = v / L_cc (two dependent instructions per step: v_readlane, v_fma) with the
+// diagonal block held in registers.
+// ------------------------------------------------------------------------------------------------
+#define GPG_VEC_SENTINEL 0x7ff8dead7ff8deadull     // quiet NaN that no arithmetic produces; both halves equal (memsetD32)
+template <int BWD, int RR>
+__global__ void __launch_bounds__(256)
+vec_solve_kernel(const double* __restrict__ A, int ld, const double* __restrict__ dinv, double* W, int ldw, int Mt, int R,
+                 unsigned long long* xc, int Npad, int* abort_word, int* info) {
+  __shared__ double part[4][RR][64];     // [wave][row][column] partial sums
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tj = BWD ? Mt - 1 - (int)blockIdx.x : (int)blockIdx.x;
+  const size_t cj = 64 * (size_t)tj;
+  const int ktot = BWD ? Mt - 1 - tj : tj;
+  const double dv = dinv[cj + lane];
+  // diagonal block, scaled by the lane's own reciprocal pivot: FWD lane c keeps row c of L_jj, BWD column c
+  double Ls[64];
+  double v0 = 0.0;
+  if (w < R) {
+#pragma unroll
+    for (int m = 0; m < 64; ++m)
+      Ls[m] = (BWD ? A[cj + m + (cj + lane) * (size_t)ld] : A[cj + lane + (cj + m) * (size_t)ld]) * dv;
+    v0 = W[w + (cj + lane) * (size_t)ldw];
+  }
+  double t[RR];
+#pragma unroll
+  for (int r = 0; r < RR; ++r) t[r] = 0.0;
+  double lcur[16];
+  const bool carrier = lane < 16 * RR && (lane >> 4) < R;     // lane 16 r + mm carries x_k[r][16 w + mm]
+  bool dead = false;
+  for (int kk = 0; kk < ktot; ++kk) {      // FWD: k = kk, BWD: k = Mt-1-kk
+    const size_t ck = 64 * (size_t)(BWD ? Mt - 1 - kk : kk);
+#pragma unroll
+    for (int mm = 0; mm < 16; ++mm) {
+      const int m = 16 * w + mm;
+      lcur[mm] = BWD ? A[ck + m + (cj + lane) * (size_t)ld] : A[cj + lane + (ck + m) * (size_t)ld];
+    }
+    const unsigned long long* src = xc + (size_t)(carrier ? lane >> 4 : 0) * Npad + ck + 16 * w + (lane & 15);
+    unsigned long long bits = 0;
+    unsigned long long t_wait = 0;
+    for (;;) {
+      bits = carrier ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+      if (!__any(bits == GPG_VEC_SENTINEL)) break;
+      const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+      if (t_wait == 0) t_wait = now;
+      if (now - t_wait > GPG_TILE_WAIT_TICKS || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        if (lane == 0) {
+          __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          atomicMax(info, GPG_INFO_INTERNAL);
+        }
+        dead = true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (dead) break;
+    const double xv = __longlong_as_double((long long)bits);
+#pragma unroll
+    for (int r = 0; r < RR; ++r)
+#pragma unroll
+      for (int mm = 0; mm < 16; ++mm) t[r] -= readlane_d(xv, 16 * r + mm) * lcur[mm];
+  }
+#pragma unroll
+  for (int r = 0; r < RR; ++r) part[w][r][lane] = t[r];
+  __syncthreads();
+  if (w < R && !dead) {
+    const int r = w < RR ? w : 0;
+    double u = (v0 + part[0][r][lane] + part[1][r][lane] + part[2][r][lane] + part[3][r][lane]) * dv;
+    double x = 0.0;
+    if (!BWD) {
+#pragma unroll
+      for (int m = 0; m < 64; ++m) {
+        const double xm = readlane_d(u, m);
+        u -= xm * Ls[m];                 // meaningful in lanes c > m; finished lanes are never read again
+        x = (lane == m) ? xm : x;
+      }
+    } else {
+#pragma unroll
+      for (int m = 63; m >= 0; --m) {
+        const double xm = readlane_d(u, m);
+        u -= xm * Ls[m];
+        x = (lane == m) ? xm : x;
+      }
+    }
+    __hip_atomic_store(xc + (size_t)w * Npad + cj + lane, (unsigned long long)__double_as_longlong(x), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    W[w + (cj + lane) * (size_t)ldw] = x;
+  }
+}
+
 // Column-major task list of the dataflow factorisation (Mt tile columns, Rt >= Mt tile rows), cached per shape.
 const TileMap& get_tile_tasks(gpg_ctx* c, int Mt, int Rt) {
   const unsigned long long key = (1ull << 63) | ((unsigned long long)Mt << 20) | (unsigned)Rt;
@@ -773,8 +872,31 @@ static void launch_tile128_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a
 }
 
 // W (rows x Npad, rows a multiple of 64) <- W L^-T with the dataflow kernel; returns false if it does not apply.
+static bool launch_vec_solve(gpg_ctx* c, double* W, int ldw, int R, bool bwd) {
+  const int Mt = c->Npad / 64;
+  if (c->tile_flags_cap < 1) {
+    (void)hipMalloc(&c->tile_flags, sizeof(int) * 64);
+    c->tile_flags_cap = 64;
+  }
+  if (c->vec_x_cols < c->Npad) {
+    if (c->vec_x) (void)hipFree(c->vec_x);
+    (void)hipMalloc(&c->vec_x, sizeof(double) * 4 * (size_t)c->Npad);
+    c->vec_x_cols = c->Npad;
+  }
+  (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int), c->stream);                              // abort word
+  (void)hipMemsetD32Async((hipDeviceptr_t)c->vec_x, (int)(GPG_VEC_SENTINEL & 0xffffffffull), (size_t)2 * R * c->Npad, c->stream);
+#define GPG_VEC_LAUNCH(BWD, RR)                                                                                          \
+  hipLaunchKernelGGL((vec_solve_kernel<BWD, RR>), dim3(Mt), dim3(256), 0, c->stream, (const double*)c->A, c->ld,          \
+                     (const double*)c->dinv, W, ldw, Mt, R, (unsigned long long*)c->vec_x, c->Npad, c->tile_flags, c->info)
+  if (bwd) { if (R == 1) GPG_VEC_LAUNCH(1, 1); else GPG_VEC_LAUNCH(1, 4); }
+  else     { if (R == 1) GPG_VEC_LAUNCH(0, 1); else GPG_VEC_LAUNCH(0, 4); }
+#undef GPG_VEC_LAUNCH
+  return true;
+}
+
 static bool launch_rows_bwd(gpg_ctx* c, double* Z, int ldz, int rows, int valid) {
   if (rows <= 0 || rows % 64 != 0) return false;
+  if (valid >= 1 && valid <= 4 && c->Npad / 64 <= 512) return launch_vec_solve(c, Z, ldz, valid, true);
   const int Mt = c->Npad / 64, nrt = rows / 64;
   if ((long)Mt * nrt > 4096) return false;
   const size_t nflag = (size_t)Mt * nrt + 1;
@@ -791,6 +913,7 @@ static bool launch_rows_bwd(gpg_ctx* c, double* Z, int ldz, int rows, int valid)
 
 static bool launch_rows_fwd(gpg_ctx* c, double* W, int ldw, int rows, int valid) {
   if (rows <= 0 || rows % 64 != 0) return false;
+  if (valid >= 1 && valid <= 4 && c->Npad / 64 <= 512) return launch_vec_solve(c, W, ldw, valid, false);
   const int Mt = c->Npad / 64, nrt = rows / 64;
   if ((long)Mt * nrt > 4096) return false;             // many rows: the blocked sweep is throughput-bound, not latency-bound
   const size_t nflag = (size_t)Mt * nrt + 1;

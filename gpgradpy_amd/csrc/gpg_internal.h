@@ -64,6 +64,8 @@ struct gpg_ctx {
   int* info = nullptr;       // device: first failing pivot (0 = none)
   double* vec_rows = nullptr;   // [64 x vec_rows_cols] carrier tile of the single-vector backward solve (on first use)
   int vec_rows_cols = 0;        // = Npad of the full-gradient shape (allocation size)
+  double* vec_x = nullptr;      // [4 x vec_x_cols] compact solution rows of the vector solves (on first use)
+  int vec_x_cols = 0;
   double* Wt = nullptr;      // prediction RHS rows [wt_rows x Npad]
   int wt_rows = 0;
   double* xq_dev = nullptr;  // [d x nxp]

@@ -4,6 +4,7 @@
 //   backward solve  : z = L^-T w for the single vector needed by alpha (GpEvalModel.py:57)
 //   predict_reduce  : mu = beta + Kyx' alpha, sig2 = 1 - diag(Kxy K^-1 Kyx) (GpEvalModel.py:162-168)
 //   extract         : dense N x N copies on request (tests / drop-in 7-tuple)
+#include <algorithm>
 #include "gpg_internal.h"
 
 namespace {
@@ -114,6 +115,47 @@ __global__ void __launch_bounds__(1024) predict_reduce_kernel(const double* __re
   } else {
     for (int c = cg; c < N; c += 16) { double w = Wt[(size_t)c * nxp + j]; acc += w * w; }
   }
+  sh[cg][jl] = acc;
+  __syncthreads();
+  if (cg == 0) {
+    double s = 0.0;
+    for (int q = 0; q < 16; ++q) s += sh[q][jl];
+    out[j] = phase == 0 ? beta + s : 1.0 - s;
+  }
+}
+
+// The same reductions for a few query rows, spread over S slices of the columns (grid = (nxp / 64, S)) so that a
+// single-point evaluation is not one workgroup streaming the whole row set; the partial sums are added in slice order
+// by predict_final_kernel (deterministic).
+__global__ void __launch_bounds__(1024) predict_partial_kernel(const double* __restrict__ Wt, int nxp, int N, int chunk,
+                                                               const double* __restrict__ z, int phase,
+                                                               double* __restrict__ partial) {
+  __shared__ double sh[16][64];
+  const int jl = threadIdx.x & 63, cg = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + jl;
+  const int c0 = blockIdx.y * chunk, c1 = min(N, c0 + chunk);
+  double acc = 0.0;
+  if (phase == 0) {
+    for (int c = c0 + cg; c < c1; c += 16) acc += Wt[(size_t)c * nxp + j] * z[c];
+  } else {
+    for (int c = c0 + cg; c < c1; c += 16) { double w = Wt[(size_t)c * nxp + j]; acc += w * w; }
+  }
+  sh[cg][jl] = acc;
+  __syncthreads();
+  if (cg == 0) {
+    double s = 0.0;
+    for (int q = 0; q < 16; ++q) s += sh[q][jl];
+    partial[(size_t)blockIdx.y * nxp + j] = s;
+  }
+}
+
+__global__ void __launch_bounds__(1024) predict_final_kernel(const double* __restrict__ partial, int nxp, int S, double beta,
+                                                             int phase, double* __restrict__ out) {
+  __shared__ double sh[16][64];
+  const int jl = threadIdx.x & 63, cg = threadIdx.x >> 6;
+  const int j = blockIdx.x * 64 + jl;
+  double acc = 0.0;
+  for (int q = cg; q < S; q += 16) acc += partial[(size_t)q * nxp + j];
   sh[cg][jl] = acc;
   __syncthreads();
   if (cg == 0) {
@@ -508,6 +550,15 @@ void gpg_launch_alpha(gpg_ctx* c, double* alpha_dev) {
 
 void gpg_launch_predict_reduce(gpg_ctx* c, int nx, int nxp, double beta, double varK, int phase) {
   (void)nx; (void)varK;
+  const int S = std::min(128, c->Npad / nxp);      // slices; the partial sums live in tmpv [Npad]
+  if (S >= 2) {
+    const int chunk = (c->N + S - 1) / S;
+    hipLaunchKernelGGL(predict_partial_kernel, dim3(nxp / 64, S), dim3(1024), 0, c->stream, c->Wt, nxp, c->N, chunk, c->zvec,
+                       phase, c->tmpv);
+    hipLaunchKernelGGL(predict_final_kernel, dim3(nxp / 64), dim3(1024), 0, c->stream, c->tmpv, nxp, S, beta, phase,
+                       c->musig + (size_t)phase * nxp);
+    return;
+  }
   hipLaunchKernelGGL(predict_reduce_kernel, dim3(nxp / 64), dim3(1024), 0, c->stream, c->Wt, nxp, c->N, c->zvec, beta,
                      phase, c->musig + (size_t)phase * nxp);
 }

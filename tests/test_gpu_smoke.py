@@ -17,7 +17,12 @@ def _shared_gpu_worker(rank, q):
     GP.set_data(X, f, np.zeros(n), g, np.zeros((n, d)))
     hp_x0 = np.random.default_rng(3).uniform(-2.0, -0.7, (6, d))
     ln = GP.calc_lkd_batch(hp_x0)
-    q.put((rank, ln, GP.factor_fallbacks()))
+    # posterior solves are dataflow launches too: a burst of single-point evaluations next to the other process
+    hp = GP.optz_closed_form_hp(GP.hp_vec2dataclass(GP.hp_info_optz_lkd, hp_x0[0]))
+    GP.set_hpara('set', 0, hp_vals=hp)
+    xq = np.random.default_rng(5).uniform(-1.0, 1.0, (40, d))
+    post = np.array([GP.eval_model(xq[i:i + 1])[:2] for i in range(40)]).reshape(40, 2)
+    q.put((rank, np.concatenate([ln, post.ravel()]), GP.factor_fallbacks()))
 
 
 @pytest.mark.gpu
@@ -44,4 +49,4 @@ def test_two_processes_share_one_gpu():
     assert fb == 0                                     # alone on the device: no fallback
     for _, ln, _ in res:
         assert np.all(np.isfinite(ln))
-        np.testing.assert_allclose(ln, ref, rtol=1e-9)
+        np.testing.assert_allclose(ln, ref, rtol=1e-8, atol=1e-10)
