@@ -3,6 +3,42 @@
 #pragma once
 #include "gpg_internal.h"
 
+// Consumer side of a flag: what a workgroup reads after seeing a flag (a finished tile, its reciprocal pivots) is
+// memory that neither its CU nor its XCD has read before in this launch -- nobody reads a tile before its flag, and
+// tiles / pivot groups do not share cache lines -- so no stale copy can sit in the L1 / L2 it reads through and the
+// agent-scope acquire's `buffer_inv sc1` (invalidate the XCD's whole L2, on every wait of every workgroup) is not
+// needed: ordering against the polling load is enough.  -DGPG_HEAVY_ACQUIRE restores the full fence for A/B runs.
+#ifdef GPG_HEAVY_ACQUIRE
+#define GPG_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent")
+#else
+#define GPG_ACQUIRE() __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup")
+#endif
+
+// Producer side: write the L2's dirty lines back (`buffer_wbl2 sc1`) before the flag goes up; __threadfence() would add
+// the invalidate of an acquire on top.
+#ifdef GPG_HEAVY_RELEASE
+#define GPG_RELEASE() __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent")
+#define GPG_ST(p, v) (*(p) = (v))
+#else
+// Everything another workgroup reads after a flag (factor tiles, reciprocal pivots, solved rows) is stored with
+// GPG_ST: an agent-scope atomic store, i.e. `global_store_dwordx2 ... sc1`, written through the XCD's L2 to memory.
+// The release is then only the wait for those stores (`s_waitcnt vmcnt(0)`) instead of `buffer_wbl2 sc1`, the
+// write-back of every dirty line of the L2.
+#define GPG_RELEASE() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define GPG_ST(p, v) gpg_store_through((p), (v))
+__device__ __forceinline__ void gpg_store_through(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+#endif
+// Every thread that wrote part of a tile runs GPG_RELEASE() and the workgroup meets at a barrier before one thread
+// raises the flag, so the flag store itself needs no second write-back.
+#ifdef GPG_HEAVY_RELEASE
+#define GPG_FLAG_UP(p) __hip_atomic_store(p, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT)
+#else
+#define GPG_FLAG_UP(p) __hip_atomic_store(p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#endif
+
 typedef double d4 __attribute__((ext_vector_type(4)));
 
 namespace {
@@ -98,13 +134,13 @@ __device__ __forceinline__ int potrf64_wave(const double* src, int sld, double (
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
       St[16 * s + c][i] = a[c];
-      if (i >= 16 * s + c) blk[i + (size_t)(16 * s + c) * ld] = a[c];
+      if (i >= 16 * s + c) GPG_ST(&blk[i + (size_t)(16 * s + c) * ld], a[c]);
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if (i >= 16 * s && i < 16 * s + 16) dinv[i] = myinv;
+    if (i >= 16 * s && i < 16 * s + 16) GPG_ST(&dinv[i], myinv);
     if (piece_flags) {   // dataflow kernels: these 16 columns (and their reciprocal pivots) are final -- publish them
-      __threadfence();
-      if (i == 0) __hip_atomic_store(piece_flags + s, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      GPG_RELEASE();
+      if (i == 0) GPG_FLAG_UP(piece_flags + s);
     }
   }
   return bad;
@@ -451,7 +487,7 @@ __device__ __forceinline__ void panel_solve_rows64(const double* __restrict__ L,
     if (t_ok) {
       double* Xr = X + rowt + (size_t)(64 * j + q) * ldx;
 #pragma unroll
-      for (int m = 0; m < 16; ++m) Xr[(size_t)(4 * m) * ldx] = x[m];
+      for (int m = 0; m < 16; ++m) GPG_ST(&Xr[(size_t)(4 * m) * ldx], x[m]);
     }
     __syncthreads();   // X_j visible to the whole workgroup (vmcnt(0) + barrier), Ts / Ls free again
     GPG_T(p5)
@@ -490,7 +526,7 @@ __device__ __forceinline__ int wg_wait_flag(int* flag, int* abort_word, int* inf
   __syncthreads();
   const int ok = *sh;
   __syncthreads();   // sh may be rewritten by the next wait
-  if (ok) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (ok) GPG_ACQUIRE();
   return ok;
 }
 

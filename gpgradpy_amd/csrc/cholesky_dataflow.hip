@@ -87,7 +87,7 @@ tile_chol_kernel(double* A, int ld, int c0, int Mt, const int* __restrict__ task
     __syncthreads();
     const int kr = sh_kr;
     if (kr < 0) return;                                  // abort: drain
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the producers' tiles are visible from here on
+    GPG_ACQUIRE();   // the producers' tiles are visible from here on
     const size_t ck = (size_t)c0 + 64 * (size_t)kdone;
     wave_tile_gemm(acc, A + r0 + 2 * sp + (ck + sk) * (size_t)ld, ld, A + cj + 2 * sp + (ck + sk) * (size_t)ld, ld,
                    4 * (kr - kdone), sA, sB, w, l15, l4, sp, sk);
@@ -140,12 +140,12 @@ tile_chol_kernel(double* A, int ld, int c0, int Mt, const int* __restrict__ task
 #undef GPG_TC_PIECE
     double* Xr = A + r0 + (tid >> 2) + (cj + q) * (size_t)ld;
 #pragma unroll
-    for (int m = 0; m < 16; ++m) Xr[(size_t)(4 * m) * ld] = x[m];
+    for (int m = 0; m < 16; ++m) GPG_ST(&Xr[(size_t)(4 * m) * ld], x[m]);
   }
   // ---- (3) publish ----------------------------------------------------------------------------------------------
-  __threadfence();
+  GPG_RELEASE();
   __syncthreads();
-  if (tid == 0) __hip_atomic_store(frow_i + tj, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) GPG_FLAG_UP(frow_i + tj);
 }
 
 
@@ -196,8 +196,8 @@ __device__ __forceinline__ int tile_solve_rows128(const double* L, int ldl, cons
     double* Xr = X + rr + (size_t)q * ldx;
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
-      Xr[(size_t)(4 * m) * ldx] = x0[m];
-      Xr[64 + (size_t)(4 * m) * ldx] = x1[m];
+      GPG_ST(&Xr[(size_t)(4 * m) * ldx], x0[m]);
+      GPG_ST(&Xr[64 + (size_t)(4 * m) * ldx], x1[m]);
     }
   }
   if (!wg_wait_flag(flag_c, abort_word, info, sh)) return 0;   // barrier inside: X1 visible to the workgroup, Ls free
@@ -249,8 +249,8 @@ __device__ __forceinline__ int tile_solve_rows128(const double* L, int ldl, cons
     double* Xr = X + rr + (size_t)(64 + q) * ldx;
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
-      Xr[(size_t)(4 * m) * ldx] = x0[m];
-      Xr[64 + (size_t)(4 * m) * ldx] = x1[m];
+      GPG_ST(&Xr[(size_t)(4 * m) * ldx], x0[m]);
+      GPG_ST(&Xr[64 + (size_t)(4 * m) * ldx], x1[m]);
     }
   }
   __syncthreads();
@@ -285,16 +285,16 @@ __device__ __noinline__ int tile128_finalize(double* A, int ld, size_t r0, size_
     if (w == 0) {   // A11 was left in the LDS tile by this same wave (no barrier, no trip through memory)
       const int bad = potrf64_wave(U, SA, St, blk, ld, dinv + cj);
       if (bad && lane == 0 && (int)cj + bad - 1 < N) atomicCAS(info, 0, (int)cj + bad);
-      __threadfence();   // L11 and its reciprocal pivots (all written by this wave) are published early
-      if (lane == 0) __hip_atomic_store(flag_a, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      GPG_RELEASE();   // L11 and its reciprocal pivots (all written by this wave) are published early
+      if (lane == 0) GPG_FLAG_UP(flag_a);
     }
     __syncthreads();   // also drains the other waves' stores of A21 / A22
     GPG_FS(1)
     // L21 = A21 L11^-T
     panel_solve_rows64(blk, ld, dinv + cj, blk + 64, ld, 64, 64, U, Ls, sdinv);
-    __threadfence();   // L21 is final (every thread stored part of it; the solve ended with a barrier)
+    GPG_RELEASE();   // L21 is final (every thread stored part of it; the solve ended with a barrier)
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(flag_c, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) GPG_FLAG_UP(flag_c);
     GPG_FS(2)
     // A22 -= L21 L21^T on MFMA, then factor it from the LDS tile
     const int sp = tid & 31, sk = tid >> 5;
@@ -394,7 +394,7 @@ tile128_chol_kernel(double* A, int ld, int Mt, const int* __restrict__ tasks, in
     __syncthreads();
     const int kr = sh_kr;
     if (kr < 0) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    GPG_ACQUIRE();
     GPG_T(q1)
     const size_t ck = 128 * (size_t)kdone;
     direct_tile_gemm_x2<3>(acc, A + r0 + wm * 64 + 2 * l15 + (ck + l4) * (size_t)ld, ld,
@@ -438,9 +438,9 @@ tile128_chol_kernel(double* A, int ld, int Mt, const int* __restrict__ tasks, in
   if (ti != tj) __syncthreads();
   if (tile128_finalize(A, ld, r0, cj, ti == tj, frow_j + tj, flag_a + tj, flag_a + Mt + tj, abort_word, dinv, info, N) == 0) return;
   // ---- (3) publish ----------------------------------------------------------------------------------------------
-  __threadfence();
+  GPG_RELEASE();
   __syncthreads();
-  if (tid == 0) __hip_atomic_store(frow_i + tj, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) GPG_FLAG_UP(frow_i + tj);
 #ifdef GPG_STAMP
   if (tid == 0 && g_stamp_buf != nullptr && blockIdx.x < GPG_STAMP_MAX) {
     unsigned long long* o = g_stamp_buf + (size_t)blockIdx.x * 8;
@@ -515,7 +515,7 @@ rows_fwd_kernel(const double* __restrict__ A, int ld, const double* __restrict__
     __syncthreads();
     const int kr = sh_kr;
     if (kr < 0) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    GPG_ACQUIRE();
     const size_t ck = 64 * (size_t)kdone;
     wave_tile_gemm(acc, W + r0 + 2 * sp + (ck + sk) * (size_t)ldw, ldw, A + cj + 2 * sp + (ck + sk) * (size_t)ld, ld,
                    4 * (kr - kdone), sA, sB, w, l15, l4, sp, sk);
@@ -541,10 +541,10 @@ rows_fwd_kernel(const double* __restrict__ A, int ld, const double* __restrict__
   }
   double* Xr = W + r0 + (tid >> 2) + (cj + q) * (size_t)ldw;
 #pragma unroll
-  for (int m = 0; m < 16; ++m) Xr[(size_t)(4 * m) * ldw] = x[m];
-  __threadfence();
+  for (int m = 0; m < 16; ++m) GPG_ST(&Xr[(size_t)(4 * m) * ldw], x[m]);
+  GPG_RELEASE();
   __syncthreads();
-  if (tid == 0) __hip_atomic_store(frow + tj, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) GPG_FLAG_UP(frow + tj);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -611,7 +611,7 @@ rows_bwd_kernel(const double* __restrict__ A, int ld, const double* __restrict__
     __syncthreads();
     const int kr = sh_kr;
     if (kr < 0) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    GPG_ACQUIRE();
     const size_t ck = 64 * (size_t)kr;                             // contraction rows [64 kr, 64 khi)
     wave_tile_gemm_nn(acc, Z + r0 + 2 * sp + (ck + sk) * (size_t)ldz, ldz, A + ck + cj * (size_t)ld, ld, 4 * (khi - kr), sA, sB, w,
                       l15, l4, sp, sk);
@@ -637,10 +637,10 @@ rows_bwd_kernel(const double* __restrict__ A, int ld, const double* __restrict__
   }
   double* Xr = Z + r0 + (tid >> 2) + (cj + q) * (size_t)ldz;
 #pragma unroll
-  for (int m = 0; m < 16; ++m) Xr[(size_t)(4 * m) * ldz] = x[m];
-  __threadfence();
+  for (int m = 0; m < 16; ++m) GPG_ST(&Xr[(size_t)(4 * m) * ldz], x[m]);
+  GPG_RELEASE();
   __syncthreads();
-  if (tid == 0) __hip_atomic_store(frow + tj, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) GPG_FLAG_UP(frow + tj);
 }
 
 // ------------------------------------------------------------------------------------------------
