@@ -233,6 +233,12 @@ def test_against_oracle_multi_panel(kernel, noise, n, d, panel, mode):
         xm[k] -= eps
         fd[k] = (GP.eval_model(xp[None, :])[0][0] - GP.eval_model(xm[None, :])[0][0]) / (2 * eps)
     np.testing.assert_allclose(dmudx[0], fd, rtol=1e-4, atol=1e-6 * np.abs(fd).max())
+    # 1 .. 4 query points go through the vector-specialised solve kernels (vec_solve_kernel<., 1> and <., 4>)
+    for nx in (1, 2, 3, 4):
+        mu_k, sig_k, dmu_k, dsig_k = GP.eval_model(xq[:nx], calc_grad=True)[:4]
+        np.testing.assert_allclose(mu_k, mu_o[:nx], rtol=tol.MU_RTOL, atol=tol.MU_ATOL_SCALE * max(1.0, np.abs(mu_o).max()))
+        np.testing.assert_allclose(sig_k, sig_o[:nx], rtol=tol.SIG_RTOL, atol=tol.SIG_ATOL_SCALE * np.sqrt(hp2.varK))
+        tol.check_post_grad(dmu_k, dsig_k, dict(dmudx=dmu_o[:nx], dsigdx=dsig_o[:nx]))
 
 
 def test_factor_modes_agree_and_fail_alike():

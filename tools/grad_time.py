@@ -1,7 +1,8 @@
 """Diagnostic: time of one value + gradient evaluation at the headline size, for a few panel widths of the
 forward sweeps of gpg_inverse_from_factor, plus a finite-difference check of the largest component."""
 import sys, time, numpy as np
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import bench, gpgradpy_amd
 n, d = 2000, 8
 X, f, g, tab = bench.make_workload(n, d)

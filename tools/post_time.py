@@ -1,5 +1,6 @@
 import sys, time, numpy as np
-sys.path.insert(0, '/root/repo')
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import bench, gpgradpy_amd
 n, d = 2000, 8
 X, f, g, tab = bench.make_workload(n, d)
