@@ -385,8 +385,10 @@ __device__ __forceinline__ void wave_tile_gemm_nn(d4 (&acc)[4], const double* ga
 __device__ unsigned long long* g_stamp_buf;
 #define GPG_STAMP_MAX 131072   // workgroups with a timeline record
 #define GPG_T(var) unsigned long long var; __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0);
+#define GPG_TR(var) unsigned long long var; __builtin_amdgcn_sched_barrier(0); var = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0);   // 100 MHz ticks
 #else
 #define GPG_T(var)
+#define GPG_TR(var)
 #endif
 
 // ------------------------------------------------------------------------------------------------

@@ -372,7 +372,7 @@ tile128_chol_kernel(double* A, int ld, int Mt, const int* __restrict__ tasks, in
   // ---- (1) left-looking accumulation ----------------------------------------------------------------------------
   int kdone = 0;
   while (kdone < tj) {
-    GPG_T(q0)
+    GPG_TR(q0)
     if (tid == 0) {
       int kr = kdone;
       const unsigned long long t_wait = __builtin_amdgcn_s_memrealtime();
@@ -395,12 +395,12 @@ tile128_chol_kernel(double* A, int ld, int Mt, const int* __restrict__ tasks, in
     const int kr = sh_kr;
     if (kr < 0) return;
     GPG_ACQUIRE();
-    GPG_T(q1)
+    GPG_TR(q1)
     const size_t ck = 128 * (size_t)kdone;
     direct_tile_gemm_x2<3>(acc, A + r0 + wm * 64 + 2 * l15 + (ck + l4) * (size_t)ld, ld,
                            A + cj + wn * 64 + 2 * l15 + (ck + l4) * (size_t)ld, ld, 32 * (kr - kdone));
     __syncthreads();   // sh_kr may be rewritten
-    GPG_T(q2)
+    GPG_TR(q2)
 #ifdef GPG_STAMP
     tk_spin += q1 - q0; tk_gemm += q2 - q1; ++tk_runs;
 #endif

@@ -12,9 +12,7 @@ for r in rows:
     st, en, fin0 = int(r["start"]), int(r["end"]), int(r["fin0"])
     f0, f1, f2 = int(r["f0"]), int(r["f1"]), int(r["f2"])
     tot += en - st
-    # spin_cyc / gemm_cyc are shader-clock cycles (s_memtime): converted at 2.4 GHz / 100 MHz = 24 per tick, so the
-    # split between "MFMA loop" and "tile load + loop overhead" is approximate (the clock is not pinned)
-    sp, gm = int(r["spin_cyc"]) / 24.0, int(r["gemm_cyc"]) / 24.0
+    sp, gm = int(r["spin_cyc"]), int(r["gemm_cyc"])          # s_memrealtime ticks as well
     spin += sp; gemm += gm
     load += (fin0 - st) - sp - gm
     finwait += f1 - f0 if f1 > f0 else 0
