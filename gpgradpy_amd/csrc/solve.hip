@@ -521,7 +521,20 @@ void gpg_backward_solve(gpg_ctx* c) {
 // Z (nrhs x Npad, RHS-rows layout, leading dimension ldz) <- Z L^-1, i.e. every row solved against L^T
 void gpg_backward_rows(gpg_ctx* c, double* Z, int ldz, int nrhs, double* tbuf) {
   // one dataflow launch over the 64-row tiles that hold the nrhs rows (the other rows of a tile ride along)
-  if ((c->chol_impl != 0 || c->tail_cols != 0) && gpg_launch_rows_bwd(c, Z, ldz, ((nrhs + 63) / 64) * 64, nrhs)) return;
+  const int rows = ((nrhs + 63) / 64) * 64;
+  if (c->chol_impl != 0 || c->tail_cols != 0) {
+    if (gpg_launch_rows_bwd(c, Z, ldz, rows, nrhs)) return;
+    // more row tiles than one dataflow launch takes: one launch per group of row tiles (rows are the fast index of Z)
+    const int chunk = (4096 / (c->Npad / 64)) * 64;
+    if (chunk >= 64) {
+      bool ok = true;
+      for (int r0 = 0; r0 < rows && ok; r0 += chunk) {
+        const int nr = std::min(chunk, rows - r0);
+        ok = gpg_launch_rows_bwd(c, Z + r0, ldz, nr, std::min(nr, nrhs - r0));
+      }
+      if (ok) return;      // (a refusal can only come before the first launch: same shape every time)
+    }
+  }
   const int Npad = c->Npad;
   for (int k0 = Npad - 64; k0 >= 0; k0 -= 64) {
     const int has_t = (k0 + 64 < Npad);

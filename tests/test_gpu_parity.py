@@ -342,6 +342,29 @@ def test_random_small_shapes_against_oracle():
         tol.check_scalars(info.hp_beta[0], info.hp_varK, info.ln_det_Kmat, info.ln_lkd, ref, y.size, noise != 'none')
 
 
+def test_many_query_points_split_over_launches():
+    """More query points than one dataflow solve launch takes (row tiles x column blocks > 4096): the backward sweep of
+    the posterior gradients is split over several launches; the result must equal the same points evaluated in
+    small groups."""
+    import gpgradpy_amd
+    from oracle import gp_oracle as orc
+    n, d = 120, 4                                        # N = 600 -> 10 column blocks -> 409 row tiles per launch
+    X, f, g = orc.synthetic_design(n, d, seed=5)
+    GP = gpgradpy_amd.GaussianProcess(d, True, 'SqExp', 'precon')
+    GP.set_data(X, f, np.zeros(n), g, np.zeros((n, d)))
+    hp = GP.optz_closed_form_hp(GP.make_hp_class(theta=np.full(d, 0.3)))
+    GP.set_hpara('set', 0, hp_vals=hp)
+    nx = 409 * 64 + 700                                  # two launches, the second one ragged
+    xq = np.random.default_rng(1).uniform(-2, 2, (nx, d))
+    mu, sig, dmu, dsig = GP.eval_model(xq, calc_grad=True)[:4]
+    for lo in (0, 409 * 64 - 30, nx - 50):
+        m2, s2, dm2, ds2 = GP.eval_model(xq[lo:lo + 50], calc_grad=True)[:4]
+        np.testing.assert_allclose(mu[lo:lo + 50], m2, rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(sig[lo:lo + 50], s2, rtol=1e-8, atol=1e-12)
+        np.testing.assert_allclose(dmu[lo:lo + 50], dm2, rtol=1e-8, atol=1e-10)
+        np.testing.assert_allclose(dsig[lo:lo + 50], ds2, rtol=1e-6, atol=1e-10)
+
+
 def test_gradient_free_base():
     """BASELINE cfg1 shape (gradient-free SqExp, n=200, d=2): wellcond coerced to 'base'."""
     import gpgradpy_amd
