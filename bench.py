@@ -165,12 +165,10 @@ def main():
     if args.batch >= 0:
         GP.set_batch(args.batch)
     Npad = -(-N // 128) * 128
-    if args.factor_mode == "blocked":
-        dom_kernel = "gemm_dma_kernel<4> (trailing update C -= A_p A_p^T of the blocked schedule, 128x128 tiles)"
-    elif args.factor_mode == "tile64" or (args.factor_mode == "auto" and Npad <= 9216):
-        dom_kernel = "tile_chol_kernel (whole Cholesky as one dataflow launch, 64x64 tiles, left-looking)"
-    else:
-        dom_kernel = "tile128_chol_kernel (whole Cholesky as one dataflow launch, 128x128 tiles, left-looking)"
+    DOM_KERNELS = {
+        "blocked": "gemm_dma_kernel<4> (trailing update C -= A_p A_p^T of the blocked schedule, 128x128 tiles)",
+        "tile64": "tile_chol_kernel (whole Cholesky as one dataflow launch, 64x64 tiles, left-looking)",
+        "tile128": "tile128_chol_kernel (whole Cholesky as one dataflow launch, 128x128 tiles, left-looking)"}
 
     # rank r owns rows [8r, 8r+8) of the 64-row table (BASELINE cfg4), cycled when steps > 8
     def rows_for(k):
@@ -202,6 +200,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     best = int(np.nanargmax(ln_all))
+    dom_kernel = DOM_KERNELS[GP.last_factor()[0]]                # what the library actually launched
     prof = GP.prof_read()
     GP.prof_enable([])
     if world > 1:

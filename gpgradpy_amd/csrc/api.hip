@@ -132,7 +132,7 @@ int gpg_create(gpg_ctx** out, int device, int n_eval, int dim, int use_grad, int
   // factorisation schedule (measured, profiles/r01_tile_probe.log): one dataflow launch, 64-tile kernel for small
   // matrices (shorter dependency chain), 128-tile kernel above; chol_impl 0 = blocked right-looking (A/B runs)
   c->chol_impl = 1;
-  c->tail_cols = 9216;
+  c->tail_cols = 12288;
 #define CREATE_OK(call)                                                              \
   do {                                                                               \
     hipError_t e_ = (call);                                                          \
@@ -315,13 +315,18 @@ static int batch_plan(gpg_ctx* c, int m) {
   const bool large_df = !small && c->chol_impl == 1;
   int bmax = c->batch_max;
   if (bmax < 0) {
-    if (small) {   // enough matrices to put ~8k tiles in flight (8 at cfg2's 40 tile columns, 64 for tiny matrices)
+    if (c->Npad < 2048) {   // 64-tile kernel: enough matrices to put ~8k tiles in flight
       const long mt = c->Npad / 64, ntask = mt * (mt + 5) / 2;
       bmax = (int)(8192 / (ntask > 0 ? ntask : 1));
-      bmax = bmax < 8 ? 8 : (bmax > 64 ? 64 : bmax);
+    } else if (c->Npad <= 32768) {
+      // ~1280 tasks of the 128-tile kernel per tile-column round (measured, tools/tile_probe 5: 2560 columns 32 / 37 /
+      // 41 TF with 16 / 32 / 64 matrices, 4608: 42 / 51 / 52 with 8 / 32 / 64, 9216: 59 / 60 with 8 / 16, 18048: +0.3 %
+      // from 8 to 16); none at 68k columns
+      bmax = (1280 + c->Npad / 128 - 1) / (c->Npad / 128);
     } else {
-      bmax = c->Npad <= 32768 ? 8 : 1;   // measured: +9 % at N = 18k, none at 68k
+      bmax = 1;
     }
+    if (bmax > 1) bmax = bmax < 8 ? 8 : (bmax > 64 ? 64 : bmax);
   }
   if (!(small || large_df) || bmax <= 1 || m <= 1) return 1;
   const size_t bytesA = sizeof(double) * c->A_elems;
@@ -473,6 +478,12 @@ int gpg_setup_eval(gpg_ctx* c, const gpg_hp* hp, double beta, double* alpha_out)
   return with_fallback(c, [&] { return gpg_setup_eval_once(c, hp, beta, alpha_out); });
 }
 int gpg_factor_fallbacks(gpg_ctx* c) { return c ? c->factor_fallbacks : -1; }
+int gpg_last_factor(gpg_ctx* c, int* kernel, int* matrices) {
+  if (!c) return -1;
+  if (kernel) *kernel = c->last_factor_kernel;
+  if (matrices) *matrices = c->last_factor_batch;
+  return 0;
+}
 
 static int predict_impl(gpg_ctx* c, int nx, const double* xq, double varK, double* mu, double* sig, double* sig2_raw,
                         double* dmudx, double* dsigdx);
@@ -653,7 +664,7 @@ int gpg_prof_read(gpg_ctx* c, double ms[GPG_PROF_NCAT], long long count[GPG_PROF
 int gpg_set_factor_mode(gpg_ctx* c, int mode) {
   if (!c) return -1;
   switch (mode) {
-    case GPG_FACTOR_AUTO:    c->chol_impl = 1; c->tail_cols = 9216; break;
+    case GPG_FACTOR_AUTO:    c->chol_impl = 1; c->tail_cols = 12288; break;
     case GPG_FACTOR_BLOCKED: c->chol_impl = 0; c->tail_cols = 0; break;
     case GPG_FACTOR_TILE64:  c->chol_impl = 0; c->tail_cols = 1 << 30; break;
     case GPG_FACTOR_TILE128: c->chol_impl = 1; c->tail_cols = 0; break;

@@ -645,6 +645,7 @@ void gpg_cholesky(gpg_ctx* c) {
     gpg_launch_tile128_chol(c);
     return;
   }
+  c->last_factor_kernel = 0; c->last_factor_batch = 1;
   factor_diag_block(c, 0, kb[1]);
   for (int p = 0; p < npanel; ++p) {
     const int k0 = kb[p], k1 = kb[p + 1];                           // panel p = columns [k0, k1)

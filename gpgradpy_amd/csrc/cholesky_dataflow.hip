@@ -930,12 +930,28 @@ static bool launch_rows_fwd(gpg_ctx* c, double* W, int ldw, int rows, int valid)
 
 }  // namespace
 
-void gpg_launch_tile_chol(gpg_ctx* c, int c0) { launch_tile_chol(c, c0); }
-void gpg_launch_tile128_chol(gpg_ctx* c) { launch_tile128_chol(c); }
+void gpg_launch_tile_chol(gpg_ctx* c, int c0) {
+  launch_tile_chol(c, c0);
+  if (c0 == 0) { c->last_factor_kernel = 1; c->last_factor_batch = 1; }
+}
+void gpg_launch_tile128_chol(gpg_ctx* c) {
+  launch_tile128_chol(c);
+  c->last_factor_kernel = 2; c->last_factor_batch = 1;
+}
 bool gpg_launch_rows_fwd(gpg_ctx* c, double* W, int ldw, int rows, int valid) { return launch_rows_fwd(c, W, ldw, rows, valid); }
 bool gpg_launch_rows_bwd(gpg_ctx* c, double* Z, int ldz, int rows, int valid) { return launch_rows_bwd(c, Z, ldz, rows, valid); }
 void gpg_launch_tile_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a_stride, double* dinv_base, int d_stride,
                                 int* info_base) {
-  if (c->tail_cols > 0 && c->Npad <= c->tail_cols) launch_tile_chol_batch(c, B, Abase, a_stride, dinv_base, d_stride, info_base);
-  else launch_tile128_chol_batch(c, B, Abase, a_stride, dinv_base, d_stride, info_base);
+  // Which tile size: a forced mode decides; otherwise the 128-tile kernel (higher MFMA rate per workgroup, longer
+  // dependency chain per column) as soon as the batch puts enough of its tasks in flight to hide that chain
+  // (measured, tools/tile_probe 5 / 6: 2560 columns x 8 matrices 21 TF against 28 for the 64-tile kernel, x 32
+  // matrices 37 against 33; 4608 x 8: 42 / 39; 9216 x 8: 59 / 47).
+  bool use128;
+  if (c->tail_cols >= (1 << 30)) use128 = false;
+  else if (c->tail_cols == 0) use128 = true;
+  else use128 = c->Npad > c->tail_cols || (c->Npad >= 2048 && (long)B * (c->Npad / 128) >= 320);
+  if (use128) launch_tile128_chol_batch(c, B, Abase, a_stride, dinv_base, d_stride, info_base);
+  else launch_tile_chol_batch(c, B, Abase, a_stride, dinv_base, d_stride, info_base);
+  c->last_factor_kernel = use128 ? 2 : 1;
+  c->last_factor_batch = B;
 }

@@ -44,6 +44,8 @@ struct gpg_ctx {
   int panel_impl = 1;                // 1: fused panel_solve_kernel for B_p, 0: trsm64 + small gemm launches (A/B runs)
   int nb_outer = 256;   // panel width
   int factor_fallbacks = 0;   // times a dataflow launch timed out and the call was repeated with the blocked schedule
+  int last_factor_kernel = 0; // schedule of the most recent factorisation launch: 0 blocked, 1 64-tile, 2 128-tile dataflow
+  int last_factor_batch = 0;  // matrices it factorised
   int chol_impl = 0;    // 1: whole factorisation by the 128-tile dataflow kernel
   int tail_cols = 0;    // trailing block of at most this many columns goes to the dataflow tile kernel (0: off)
   int* tile_flags = nullptr;   // device: completion flags of the dataflow kernel + abort word

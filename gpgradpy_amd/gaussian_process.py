@@ -689,6 +689,13 @@ class GaussianProcess(HparaOptz):
         repeated with the blocked schedule; the context stays on 'blocked' until set_factor_mode is called."""
         return int(self._lib.gpg_factor_fallbacks(self._ctx)) if self._ctx else 0
 
+    def last_factor(self):
+        """(schedule, matrices) of the most recent factorisation launch: 'blocked' | 'tile64' | 'tile128'."""
+        import ctypes as C
+        k, b = C.c_int(0), C.c_int(0)
+        self._lib.gpg_last_factor(self._ctx, C.byref(k), C.byref(b))
+        return ('blocked', 'tile64', 'tile128')[k.value], b.value
+
     def download_chofac(self):
         """(P L, True) of the factor currently on the device (Kernel.py:252) as a SciPy cho_factor pair."""
         fac = np.empty((self.n_data, self.n_data))

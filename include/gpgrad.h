@@ -169,7 +169,8 @@ int gpg_set_panel(gpg_ctx* ctx, int nb_outer);
 int gpg_set_lookahead(gpg_ctx* ctx, int on);
 
 /* Factorisation schedule.  GPG_FACTOR_AUTO (default): one dataflow launch -- the 64 x 64-tile kernel up to
- * 9216 padded columns, the 128 x 128-tile kernel above.  GPG_FACTOR_BLOCKED: right-looking blocked
+ * 12288 padded columns, the 128 x 128-tile kernel above (batched launches of gpg_lkd_batch switch to the 128-tile
+ * kernel much earlier, see gpg_set_batch).  GPG_FACTOR_BLOCKED: right-looking blocked
  * algorithm (panel solve + trailing update per panel, look-ahead on a second stream; A/B measurements and
  * the reference point for the parity tests).  GPG_FACTOR_TILE64 / GPG_FACTOR_TILE128 force one kernel. */
 enum gpg_factor_mode { GPG_FACTOR_AUTO = 0, GPG_FACTOR_BLOCKED = 1, GPG_FACTOR_TILE64 = 2, GPG_FACTOR_TILE128 = 3 };
@@ -179,12 +180,16 @@ int gpg_set_factor_mode(gpg_ctx* ctx, int mode);
  * blocked schedule and keeps the context on it until gpg_set_factor_mode is called again.  Returns how often that
  * happened (results are unaffected; rc -4 is only returned if the blocked repeat fails too). */
 int gpg_factor_fallbacks(gpg_ctx* ctx);
+/* Schedule of the most recent factorisation launch (for logs / bench): *kernel = 0 blocked, 1 dataflow with 64 x 64
+ * tiles, 2 dataflow with 128 x 128 tiles; *matrices = how many matrices that launch factorised.  Either may be NULL. */
+int gpg_last_factor(gpg_ctx* ctx, int* kernel, int* matrices);
 
 /* gpg_lkd_batch: up to max_matrices restart rows are assembled into separate workspaces and factorised by ONE
  * dataflow launch (task lists interleaved tile column by tile column).  A single small factorisation is
  * latency-bound and leaves most of the chip idle; a large one does so at its two ends.  Results are bit-identical to
- * the one-at-a-time path.  -1 (default): automatic (8 .. 64 rows up to 9216 padded columns, 8 rows up to 32768
- * columns, 1 above); 0 / 1: off. */
+ * the one-at-a-time path.  -1 (default): automatic (8 .. 64 rows, fewer the larger the matrix, 8 from ~18000 padded
+ * columns up to 32768, 1 above); 0 / 1: off.  With enough rows per launch (rows x Npad / 128 >= 320, Npad >= 2048)
+ * the 128 x 128-tile kernel is used whatever the single-matrix choice of GPG_FACTOR_AUTO would be. */
 int gpg_set_batch(gpg_ctx* ctx, int max_matrices);
 /* Allocates the batch workspaces a gpg_lkd_batch call with `rows` rows will use (otherwise done by the first such
  * call): setup, like gpg_set_data, for callers that time gpg_lkd_batch. */

@@ -42,9 +42,9 @@ int main(int argc, char** argv) {
 #endif
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const size_t total = (size_t)c.ld * n;
-  const int B = impl == 5 ? 8 : 1;
+  const int B = (impl == 5 || impl == 6) ? (argc > 3 ? atoi(argv[3]) : 8) : 1;   // 5: batched 128-tile kernel, 6: batched 64-tile kernel
   double* bA = nullptr; double* bD = nullptr; int* binfo = nullptr;
-  if (B > 1) { hipMalloc(&bA, sizeof(double) * (size_t)c.ld * n * B); hipMalloc(&bD, sizeof(double) * (size_t)n * B); hipMalloc(&binfo, sizeof(int) * B); hipMemset(binfo, 0, sizeof(int) * B); c.chol_impl = 1; }
+  if (B > 1) { hipMalloc(&bA, sizeof(double) * (size_t)c.ld * n * B); hipMalloc(&bD, sizeof(double) * (size_t)n * B); hipMalloc(&binfo, sizeof(int) * B); hipMemset(binfo, 0, sizeof(int) * B); c.chol_impl = 1; c.tail_cols = impl == 6 ? n : 0; }
   float best = 1e30f;
   for (int rep = 0; rep < 3; ++rep) {
     if (B > 1) for (int b = 0; b < B; ++b) hipLaunchKernelGGL(fill_spd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c.stream, bA + (size_t)b * total, c.ld, n);
@@ -60,7 +60,7 @@ int main(int argc, char** argv) {
   int info = -1, ab = -1;
   hipMemcpy(&info, c.info, sizeof(int), hipMemcpyDeviceToHost);
   if (c.tile_flags) {   // abort word: after the Mt x Rt tile flags
-    const int T = impl == 1 ? 128 : 64;
+    const int T = (impl == 1 || impl == 5) ? 128 : 64;
     hipMemcpy(&ab, c.tile_flags + (size_t)(c.Npad / T) * (c.ld / T), sizeof(int), hipMemcpyDeviceToHost);
   }
   printf("n=%d impl=%d: %.3f ms, %.2f TFLOP/s (n^3/3), info=%d abort=%d\n", n, impl, best, (double)B * n * n * n / 3.0 / best * 1e-9, info, ab);
