@@ -188,6 +188,8 @@ void gpg_destroy(gpg_ctx* c) {
   if (c->gpos) (void)hipFree(c->gpos);
   if (c->h_scal) (void)hipHostFree(c->h_scal);
   if (c->h_info) (void)hipHostFree(c->h_info);
+  if (c->items_dev) (void)hipFree(c->items_dev);
+  if (c->items_host) (void)hipHostFree(c->items_host);
   for (auto& kv : c->tilemaps) if (kv.second.dev) (void)hipFree(kv.second.dev);
   for (auto e : c->ev_panel) (void)hipEventDestroy(e);
   for (auto e : c->ev_upd) (void)hipEventDestroy(e);
@@ -358,6 +360,14 @@ static int gpg_lkd_batch_once(gpg_ctx* c, int m, const double* hp_rows, int row_
   GPG_HIP_OK(c, hipSetDevice(c->device));
   int rc = ensure_scal(c, m);
   if (rc) return rc;
+  if (m > c->items_cap) {
+    if (c->items_dev) (void)hipFree(c->items_dev);
+    if (c->items_host) (void)hipHostFree(c->items_host);
+    c->items_dev = c->items_host = nullptr; c->items_cap = 0;
+    GPG_HIP_OK(c, hipMalloc(&c->items_dev, sizeof(gpg_batch_item) * m));
+    GPG_HIP_OK(c, hipHostMalloc(&c->items_host, sizeof(gpg_batch_item) * m));
+    c->items_cap = m;
+  }
   std::vector<gpg_hp> hps(m);
   for (int i = 0; i < m; ++i) {
     const double* row = hp_rows + (size_t)i * row_len;
@@ -382,26 +392,32 @@ static int gpg_lkd_batch_once(gpg_ctx* c, int m, const double* hp_rows, int row_
     int* info0 = c->info;
     for (int r0 = 0; r0 < m; r0 += B) {
       const int Bg = (m - r0) < B ? (m - r0) : B;
-      for (int b = 0; b < Bg; ++b) {
-        c->A = c->batchA + (size_t)b * c->A_elems;
-        c->dvec = c->batchV + (size_t)(3 * b) * c->Npad;
-        c->invp = c->dvec + c->Npad;
-        c->dinv = c->invp + c->Npad;
-        AsmParams p = make_params(c, &hps[r0 + b], 0);
-        c->last_precon = p.precon;
-        gpg_launch_prep(c, p, hps[r0 + b].var_fval, hps[r0 + b].var_fgrad, 1.0, 0.0, 0.0, 1.0);
-        gpg_launch_assembly(c, p);
-      }
-      if (Bg > 1) {
+      // matrix b of the group: workspace batchA + b A_elems, vectors dvec | invp | dinv at batchV + 3 b Npad
+      c->A = c->batchA;
+      c->dvec = c->batchV;
+      c->invp = c->dvec + c->Npad;
+      c->dinv = c->invp + c->Npad;
+      if (Bg > 1) {   // ONE launch each of prep_diag / prep_rows / assemble / factorise / reduce for the whole group
+        for (int b = 0; b < Bg; ++b) {
+          gpg_batch_item& it = c->items_host[r0 + b];
+          it.p = make_params(c, &hps[r0 + b], 0);
+          it.var_fval = hps[r0 + b].var_fval;
+          it.var_fgrad = hps[r0 + b].var_fgrad;
+        }
+        c->last_precon = c->items_host[r0].p.precon;             // wellcond is shared by the rows of a call
+        GPG_HIP_OK(c, hipMemcpyAsync(c->items_dev + r0, c->items_host + r0, sizeof(gpg_batch_item) * Bg, hipMemcpyHostToDevice,
+                                     c->stream));
+        gpg_launch_prep_assembly_batch(c, c->items_host[r0].p, Bg, c->items_dev + r0, 3 * (size_t)c->Npad, c->A_elems);
         gpg_launch_tile_chol_batch(c, Bg, c->batchA, c->A_elems, c->batchV + 2 * (size_t)c->Npad, 3 * c->Npad, info0 + r0);
+        gpg_launch_lkd_reduce_batch(c, r0, Bg, 3 * (size_t)c->Npad, c->A_elems);
       } else {
+        AsmParams p = make_params(c, &hps[r0], 0);
+        c->last_precon = p.precon;
+        gpg_launch_prep(c, p, hps[r0].var_fval, hps[r0].var_fgrad, 1.0, 0.0, 0.0, 1.0);
+        gpg_launch_assembly(c, p);
         c->info = info0 + r0;
         gpg_cholesky(c);
-      }
-      for (int b = 0; b < Bg; ++b) {
-        c->A = c->batchA + (size_t)b * c->A_elems;
-        c->dvec = c->batchV + (size_t)(3 * b) * c->Npad;
-        gpg_launch_lkd_reduce(c, r0 + b);
+        gpg_launch_lkd_reduce(c, r0);
       }
     }
     c->A = A0; c->dvec = dvec0; c->invp = invp0; c->dinv = dinv0; c->info = info0;

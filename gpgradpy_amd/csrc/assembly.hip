@@ -24,8 +24,16 @@ __device__ __forceinline__ double kdiag_of(int kernel, int blk, const double* th
 }
 
 // dvec = diag(Kern) + noise / varK ; invp = 1/sqrt(dvec) (Kernel.py:218,224-226)
+// Batched launches (gpg_lkd_batch): items != nullptr, workgroup coordinate `bz` selects the matrix; its parameters
+// come from items[bz] and its buffers sit at bz * stride behind the base pointers.
 __global__ void prep_diag_kernel(AsmParams P, const double* __restrict__ noise, double var_fval, double var_fgrad,
-                                 double* __restrict__ dvec, double* __restrict__ invp) {
+                                 double* __restrict__ dvec, double* __restrict__ invp,
+                                 const gpg_batch_item* __restrict__ items, size_t v_stride) {
+  if (items) {
+    const int bz = blockIdx.y;
+    P = items[bz].p; var_fval = items[bz].var_fval; var_fgrad = items[bz].var_fgrad;
+    dvec += bz * v_stride; invp += bz * v_stride;
+  }
   int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= P.Npad) return;
   if (r >= P.N) { dvec[r] = 1.0; invp[r] = 1.0; return; }
@@ -40,7 +48,13 @@ __global__ void prep_diag_kernel(AsmParams P, const double* __restrict__ noise, 
 // rows [N, ld) of every column: identity padding and the right-hand-side rows
 //   rhs row 0 = (s0 V + t0 y) P^-1, rhs row 1 = (s1 V + t1 y) P^-1, V = [1_n; 0] (GpMeanFun.py:172-191)
 __global__ void prep_rows_kernel(AsmParams P, const double* __restrict__ y, const double* __restrict__ invp,
-                                 double s0, double t0, double s1, double t1, double* __restrict__ A) {
+                                 double s0, double t0, double s1, double t1, double* __restrict__ A,
+                                 const gpg_batch_item* __restrict__ items, size_t v_stride, size_t a_stride) {
+  if (items) {
+    const int bz = blockIdx.y;
+    P = items[bz].p;
+    invp += bz * v_stride; A += bz * a_stride;
+  }
   int c = blockIdx.x;
   size_t col = (size_t)c * P.ld;
   for (int r = P.N + threadIdx.x; r < P.ld; r += blockDim.x) {
@@ -60,7 +74,14 @@ __global__ void prep_rows_kernel(AsmParams P, const double* __restrict__ y, cons
 template <int KERN, int D>
 __global__ void __launch_bounds__(256) assemble_kernel(AsmParams P, const double* __restrict__ Xt,
                                                        const double* __restrict__ dvec,
-                                                       const double* __restrict__ invp, double* __restrict__ A) {
+                                                       const double* __restrict__ invp, double* __restrict__ A,
+                                                       const gpg_batch_item* __restrict__ items, size_t v_stride,
+                                                       size_t a_stride) {
+  if (items) {
+    const int bz = blockIdx.z;
+    P = items[bz].p;
+    dvec += bz * v_stride; invp += bz * v_stride; A += bz * a_stride;
+  }
   __shared__ double xb[kTB][D];
   __shared__ double ipb[kTB][D + 1];
   __shared__ int gpb[kTB];
@@ -227,12 +248,12 @@ __global__ void __launch_bounds__(256) cross_kernel(AsmParams P, const double* _
 }
 
 template <int KERN>
-void launch_assemble_d(gpg_ctx* c, const AsmParams& p) {
-  dim3 grid((p.n + 255) / 256, (p.n + kTB - 1) / kTB);
+void launch_assemble_d(gpg_ctx* c, const AsmParams& p, int B, const gpg_batch_item* items, size_t v_stride, size_t a_stride) {
+  dim3 grid((p.n + 255) / 256, (p.n + kTB - 1) / kTB, B);
 #define CASE_D(DD)                                                                                  \
   case DD:                                                                                          \
     hipLaunchKernelGGL((assemble_kernel<KERN, DD>), grid, dim3(256), 0, c->stream, p, c->Xt, c->dvec, \
-                       c->invp, c->A);                                                              \
+                       c->invp, c->A, items, v_stride, a_stride);                                   \
     break;
   switch (p.d) {
     CASE_D(1) CASE_D(2) CASE_D(3) CASE_D(4) CASE_D(5) CASE_D(6) CASE_D(7) CASE_D(8)
@@ -262,15 +283,32 @@ void launch_cross_d(gpg_ctx* c, const AsmParams& p, int nx, int nxp) {
 void gpg_launch_prep(gpg_ctx* c, const AsmParams& p, double var_fval, double var_fgrad, double s0, double t0,
                      double s1, double t1) {
   hipLaunchKernelGGL(prep_diag_kernel, dim3((p.Npad + 255) / 256), dim3(256), 0, c->stream, p, c->noise, var_fval,
-                     var_fgrad, c->dvec, c->invp);
-  hipLaunchKernelGGL(prep_rows_kernel, dim3(p.Npad), dim3(256), 0, c->stream, p, c->y, c->invp, s0, t0, s1, t1, c->A);
+                     var_fgrad, c->dvec, c->invp, (const gpg_batch_item*)nullptr, (size_t)0);
+  hipLaunchKernelGGL(prep_rows_kernel, dim3(p.Npad), dim3(256), 0, c->stream, p, c->y, c->invp, s0, t0, s1, t1, c->A,
+                     (const gpg_batch_item*)nullptr, (size_t)0, (size_t)0);
 }
 
 void gpg_launch_assembly(gpg_ctx* c, const AsmParams& p) {
   double bytes = 8.0 * (double)p.N * ((double)p.N + 1.0) / 2.0;
   gpg_prof_begin(c, GPG_PROF_ASSEMBLY, bytes);
-  if (p.kernel == GPG_KERNEL_SQEXP) launch_assemble_d<GPG_KERNEL_SQEXP>(c, p);
-  else launch_assemble_d<GPG_KERNEL_MA5F2>(c, p);
+  if (p.kernel == GPG_KERNEL_SQEXP) launch_assemble_d<GPG_KERNEL_SQEXP>(c, p, 1, nullptr, 0, 0);
+  else launch_assemble_d<GPG_KERNEL_MA5F2>(c, p, 1, nullptr, 0, 0);
+  gpg_prof_end(c);
+}
+
+// The three launches above for B matrices at once: c->dvec / c->invp / c->A are the buffers of matrix 0, matrix b
+// sits b * v_stride / b * a_stride behind them, items[b] (device) carries its parameters; p = the parameters of any
+// of them (shape only).  rhs rows as for a likelihood evaluation: row 0 = V P^-1, row 1 = y P^-1.
+void gpg_launch_prep_assembly_batch(gpg_ctx* c, const AsmParams& p, int B, const gpg_batch_item* items, size_t v_stride,
+                                    size_t a_stride) {
+  hipLaunchKernelGGL(prep_diag_kernel, dim3((p.Npad + 255) / 256, B), dim3(256), 0, c->stream, p, c->noise, 0.0, 0.0, c->dvec,
+                     c->invp, items, v_stride);
+  hipLaunchKernelGGL(prep_rows_kernel, dim3(p.Npad, B), dim3(256), 0, c->stream, p, c->y, c->invp, 1.0, 0.0, 0.0, 1.0, c->A,
+                     items, v_stride, a_stride);
+  double bytes = 8.0 * (double)p.N * ((double)p.N + 1.0) / 2.0 * B;
+  gpg_prof_begin(c, GPG_PROF_ASSEMBLY, bytes);
+  if (p.kernel == GPG_KERNEL_SQEXP) launch_assemble_d<GPG_KERNEL_SQEXP>(c, p, B, items, v_stride, a_stride);
+  else launch_assemble_d<GPG_KERNEL_MA5F2>(c, p, B, items, v_stride, a_stride);
   gpg_prof_end(c);
 }
 

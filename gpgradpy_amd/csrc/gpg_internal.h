@@ -24,6 +24,9 @@ struct AsmParams {
   double theta[GPG_MAX_DIM];
 };
 
+// One matrix of a batched likelihood evaluation (gpg_lkd_batch): what the small kernels need besides the shape.
+struct gpg_batch_item { AsmParams p; double var_fval, var_fgrad; };
+
 struct TileMap { int* dev; int n; };
 
 struct ProfEvent { hipEvent_t e0, e1; int cat; };
@@ -78,6 +81,9 @@ struct gpg_ctx {
   double* batchV = nullptr;     // [batch_cap x 3 x Npad] dvec / invp / dinv of each batched matrix
   int batch_cap = 0;
   int batch_max = -1;           // matrices per batched launch (-1: auto, 0 / 1: off)
+  gpg_batch_item* items_dev = nullptr;   // [items_cap] per-row parameters of a batched call (device / pinned host)
+  gpg_batch_item* items_host = nullptr;
+  int items_cap = 0;
   double* dense_tmp = nullptr;  // [N x N] materialisation buffer (on request)
   double* Wfull = nullptr;      // [Npad x Npad] L^-T (likelihood gradient, on first use)
   double* Minv = nullptr;       // [Npad x Npad] -(L L^T)^-1, lower triangle
@@ -108,6 +114,9 @@ struct gpg_ctx {
 void gpg_launch_prep(gpg_ctx* c, const AsmParams& p, double var_fval, double var_fgrad,
                      double s0, double t0, double s1, double t1);
 void gpg_launch_assembly(gpg_ctx* c, const AsmParams& p);
+void gpg_launch_prep_assembly_batch(gpg_ctx* c, const AsmParams& p, int B, const gpg_batch_item* items, size_t v_stride,
+                                    size_t a_stride);
+void gpg_launch_lkd_reduce_batch(gpg_ctx* c, int slot0, int B, size_t v_stride, size_t a_stride);
 void gpg_launch_cross(gpg_ctx* c, const AsmParams& p, int nx, int nxp);   // Wt <- P^-1 Kyx (transposed)
 void gpg_launch_tile_chol(gpg_ctx* c, int c0);                          // dataflow factorisation of A[c0:, c0:], 64-tiles
 void gpg_launch_tile128_chol(gpg_ctx* c);

@@ -37,7 +37,8 @@ __device__ void block_sum(double (&v)[NV], double* sh /* [NV * 16] */) {
 // scal[0] = ln_det, [1] = beta, [2] = r'K^-1 r, [3] = V'K^-1 V, [4] = V'K^-1 y
 __global__ void __launch_bounds__(1024) lkd_reduce_kernel(const double* __restrict__ A, int ld, int N, int Npad,
                                                           const double* __restrict__ dvec, int precon,
-                                                          double* __restrict__ scal) {
+                                                          double* __restrict__ scal, size_t v_stride, size_t a_stride) {
+  A += blockIdx.x * a_stride; dvec += blockIdx.x * v_stride; scal += blockIdx.x * 8;   // batched: one workgroup per matrix
   __shared__ double sh[4 * 16];
   double v[4] = {0.0, 0.0, 0.0, 0.0};
   for (int c = threadIdx.x; c < N; c += blockDim.x) {
@@ -488,7 +489,14 @@ __global__ void extract_kernel(const double* __restrict__ A, int ld, int N, cons
 void gpg_launch_lkd_reduce(gpg_ctx* c, int slot) {
   gpg_prof_begin(c, GPG_PROF_REDUCE, 0.0);
   hipLaunchKernelGGL(lkd_reduce_kernel, dim3(1), dim3(1024), 0, c->stream, c->A, c->ld, c->N, c->Npad, c->dvec,
-                     c->last_precon, c->scal + (size_t)slot * 8);
+                     c->last_precon, c->scal + (size_t)slot * 8, (size_t)0, (size_t)0);
+  gpg_prof_end(c);
+}
+
+void gpg_launch_lkd_reduce_batch(gpg_ctx* c, int slot0, int B, size_t v_stride, size_t a_stride) {
+  gpg_prof_begin(c, GPG_PROF_REDUCE, 0.0);
+  hipLaunchKernelGGL(lkd_reduce_kernel, dim3(B), dim3(1024), 0, c->stream, c->A, c->ld, c->N, c->Npad, c->dvec,
+                     c->last_precon, c->scal + (size_t)slot0 * 8, v_stride, a_stride);
   gpg_prof_end(c);
 }
 
