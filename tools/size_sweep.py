@@ -2,8 +2,7 @@
 at the schedule thresholds)."""
 import sys, time, os, numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
-import gpgradpy_amd
-from oracle import gp_oracle as orc          # synthetic design only
+import bench, gpgradpy_amd
 
 
 def best(f, reps=3):
@@ -16,7 +15,7 @@ def best(f, reps=3):
 
 print('%6s %3s %7s | %9s %9s %9s %9s %9s %9s' % ('n', 'd', 'N', 'lkd', 'lkd+grad', 'batch8/8', 'setup', 'eval(1)', 'eval(64)'))
 for n, d in [(50, 2), (100, 4), (250, 4), (500, 4), (700, 8), (1000, 8), (1023, 8), (1030, 8), (1500, 8), (2000, 8), (1200, 16)]:
-    X, f, g = orc.synthetic_design(n, d, seed=n)
+    X, f, g, _ = bench.make_workload(n, d)
     GP = gpgradpy_amd.GaussianProcess(d, True, 'SqExp', 'precon')
     GP.set_data(X, f, np.zeros(n), g, np.zeros((n, d)))
     rng = np.random.default_rng(n)
