@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgpgrad_hip.so")
 
-GPG_KERNEL = {"SqExp": 0, "Ma5f2": 1}
+GPG_KERNEL = {"SqExp": 0, "Ma5f2": 1, "RatQu": 2}
 GPG_WELLCOND = {"base": 0, "precon": 1}
 PROF_CATS = ("assembly", "potrf", "trsm", "gemm_panel", "gemm_trail", "reduce")
 PROF_NCAT = len(PROF_CATS)
@@ -26,7 +26,7 @@ ABI_SYMBOLS = (
 class GpgHp(C.Structure):
     _fields_ = [("theta", C.POINTER(C.c_double)), ("varK_mat", C.c_double), ("var_fval", C.c_double),
                 ("var_fgrad", C.c_double), ("eta", C.c_double), ("wellcond", C.c_int),
-                ("closed_form_varK", C.c_int)]
+                ("closed_form_varK", C.c_int), ("hp_kernel", C.c_double)]
 
 
 class GpgLkdOut(C.Structure):

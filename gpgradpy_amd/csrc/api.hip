@@ -44,6 +44,7 @@ static AsmParams make_params(const gpg_ctx* c, const gpg_hp* hp, int mode) {
   p.varK = hp->varK_mat;
   p.eta = hp->eta;
   for (int k = 0; k < c->d; ++k) p.theta[k] = hp->theta[k];
+  p.hp_kernel = hp->hp_kernel;
   return p;
 }
 
@@ -54,6 +55,7 @@ static int check_hp(gpg_ctx* c, const gpg_hp* hp) {
   for (int k = 0; k < c->d; ++k)
     if (std::isnan(hp->theta[k])) { c->err = "There are nan values in theta"; return -1; }  // Kernel.py:201
   if (!(hp->varK_mat > 0.0)) { c->err = "varK must be positive"; return -1; }               // Kernel.py:199
+  if (c->kernel == GPG_KERNEL_RATQU && !(hp->hp_kernel > 0.0)) { c->err = "hp_kernel (alpha of RatQu) must be positive"; return -1; }
   if (hp->wellcond == GPG_WELLCOND_PRECON && !c->use_grad) {
     c->err = "wellcond 'precon' requires use_grad (Kernel.py:222)";
     return -1;
@@ -118,7 +120,7 @@ int gpg_create(gpg_ctx** out, int device, int n_eval, int dim, int use_grad, int
   if (!out) return -1;
   *out = nullptr;
   if (n_eval < 1 || dim < 1 || dim > GPG_MAX_DIM) { g_create_err = "n_eval >= 1 and 1 <= dim <= 16 required"; return -1; }
-  if (kernel != GPG_KERNEL_SQEXP && kernel != GPG_KERNEL_MA5F2) { g_create_err = "unknown kernel id"; return -1; }
+  if (kernel != GPG_KERNEL_SQEXP && kernel != GPG_KERNEL_MA5F2 && kernel != GPG_KERNEL_RATQU) { g_create_err = "unknown kernel id"; return -1; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_create_err = "no HIP device visible"; return -2; }
   if (device < 0 || device >= ndev) { g_create_err = "device index out of range"; return -1; }
@@ -273,6 +275,7 @@ static int gpg_lkd_grad_once(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out, dou
   int rc = check_hp(c, hp);
   if (rc) return rc;
   if (!out || !g_aa || !g_inv) { c->err = "out / g_aa / g_inv is NULL"; return -1; }
+  if (c->kernel == GPG_KERNEL_RATQU) { c->err = "likelihood gradient is not available for the RatQu kernel"; return -1; }
   GPG_HIP_OK(c, hipSetDevice(c->device));
   const size_t nn = (size_t)c->Npad * c->Npad;
   if (!c->Wfull) {
@@ -378,6 +381,7 @@ static int gpg_lkd_batch_once(gpg_ctx* c, int m, const double* hp_rows, int row_
     hps[i].eta = eta;
     hps[i].wellcond = wellcond;
     hps[i].closed_form_varK = closed_form_varK;
+    hps[i].hp_kernel = row_len >= c->d + 4 ? row[c->d + 3] : 0.0;   // RatQu: alpha in column d + 3
     rc = check_hp(c, &hps[i]);
     if (rc) return rc;
   }
@@ -519,6 +523,7 @@ int gpg_predict(gpg_ctx* c, int nx, const double* xq, double varK, double* mu, d
 int gpg_predict_grad(gpg_ctx* c, int nx, const double* xq, double varK, double* mu, double* sig, double* sig2_raw,
                      double* dmudx, double* dsigdx) {
   if (c && (!dmudx || !dsigdx)) { c->err = "dmudx / dsigdx is NULL"; return -1; }
+  if (c && c->kernel == GPG_KERNEL_RATQU) { c->err = "posterior derivatives are not available for the RatQu kernel"; return -1; }
   return with_fallback(c, [&] { return predict_impl(c, nx, xq, varK, mu, sig, sig2_raw, dmudx, dsigdx); });
 }
 
@@ -593,6 +598,7 @@ static int predict_hess_once(gpg_ctx* c, const double* xq, double varK, double* 
 int gpg_predict_hess(gpg_ctx* c, const double* xq, double varK, double* mu, double* sig, double* dmudx, double* dsigdx,
                      double* d2mudx2, double* d2sigdx2) {
   if (c && (!d2mudx2 || !d2sigdx2 || !dmudx || !dsigdx)) { c->err = "Hessian / gradient output is NULL"; return -1; }
+  if (c && c->kernel == GPG_KERNEL_RATQU) { c->err = "posterior derivatives are not available for the RatQu kernel"; return -1; }
   return with_fallback(c, [&] { return predict_hess_once(c, xq, varK, mu, sig, dmudx, dsigdx, d2mudx2, d2sigdx2); });
 }
 

@@ -20,7 +20,7 @@ constexpr int kTB = 16;  // columns (points b) per workgroup
 
 __device__ __forceinline__ double kdiag_of(int kernel, int blk, const double* theta) {
   if (blk == 0) return 1.0;
-  return kernel == GPG_KERNEL_SQEXP ? 2.0 * theta[blk - 1] : theta[blk - 1] * (5.0 / 3.0);
+  return kernel == GPG_KERNEL_MA5F2 ? theta[blk - 1] * (5.0 / 3.0) : 2.0 * theta[blk - 1];   // SqExp and RatQu: 2 theta
 }
 
 // dvec = diag(Kern) + noise / varK ; invp = 1/sqrt(dvec) (Kernel.py:218,224-226)
@@ -120,6 +120,7 @@ __global__ void __launch_bounds__(256) assemble_kernel(AsmParams P, const double
   const double varK = P.varK, eta = P.eta;
   const int bend = min(kTB, n - b0);
   const double sqrt5 = sqrt(5.0);
+  const double rq_alpha = P.hp_kernel, rq_const = 4.0 * (1.0 + 1.0 / P.hp_kernel);   // KernelRatQuad.py:529
 
   for (int bb = 0; bb < bend; ++bb) {
     const int b = b0 + bb;
@@ -131,6 +132,14 @@ __global__ void __launch_bounds__(256) assemble_kernel(AsmParams P, const double
       for (int k = 0; k < D; ++k) { R[k] = xa[k] - xb[bb][k]; s -= th[k] * (R[k] * R[k]); }
       E = exp(s);
       K00 = E;
+    } else if (KERN == GPG_KERNEL_RATQU) {   // KernelRatQuad.py:463-476: B = 1 + sum theta R^2 / alpha
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) { R[k] = xa[k] - xb[bb][k]; s += th[k] * (R[k] * R[k]); }
+      const double Bq = 1.0 + s / rq_alpha;
+      K00 = pow(Bq, -rq_alpha);
+      M1 = pow(Bq, -rq_alpha - 1.0);
+      E = pow(Bq, -rq_alpha - 2.0);            // B^(-alpha-2) takes the place of E in the second derivatives
     } else {
       double s = 0.0;
 #pragma unroll
@@ -180,6 +189,9 @@ __global__ void __launch_bounds__(256) assemble_kernel(AsmParams P, const double
         if (KERN == GPG_KERNEL_SQEXP) {
           vi0 = ((-2.0 * th[i]) * R[i]) * E;
           vii = (2.0 * th[i] - (4.0 * (th[i] * th[i])) * (R[i] * R[i])) * E;
+        } else if (KERN == GPG_KERNEL_RATQU) {   // KernelRatQuad.py:539-544
+          vi0 = ((-2.0 * th[i]) * R[i]) * M1;
+          vii = (2.0 * th[i]) * M1 - ((rq_const * (th[i] * th[i])) * (R[i] * R[i])) * E;
         } else {
           vi0 = ((-th[i]) * R[i]) * M1;
           vii = th[i] * M1 - (((25.0 / 3.0) * (th[i] * th[i])) * (R[i] * R[i])) * E;
@@ -191,6 +203,7 @@ __global__ void __launch_bounds__(256) assemble_kernel(AsmParams P, const double
           if (j < i) {  // block row i+1 > block column j+1; the reference's (lo, hi) = (j, i) ordering
             double vij;
             if (KERN == GPG_KERNEL_SQEXP) vij = ((-4.0 * th[j]) * th[i]) * ((R[j] * R[i]) * E);
+            else if (KERN == GPG_KERNEL_RATQU) vij = (((((-rq_const) * th[j]) * th[i]) * R[j]) * R[i]) * E;   // :554
             else vij = (((((-(25.0 / 3.0)) * th[j]) * th[i]) * R[j]) * R[i]) * E;
             emit(i + 1, j + 1, vij);
           }
@@ -222,6 +235,14 @@ __global__ void __launch_bounds__(256) cross_kernel(AsmParams P, const double* _
       for (int k = 0; k < D; ++k) { R[k] = Xt[(size_t)k * n + a] - Xq[(size_t)k * nxp + j]; s -= P.theta[k] * (R[k] * R[k]); }
       E = exp(s);
       K00 = E;
+    } else if (KERN == GPG_KERNEL_RATQU) {
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) { R[k] = Xt[(size_t)k * n + a] - Xq[(size_t)k * nxp + j]; s += P.theta[k] * (R[k] * R[k]); }
+      const double Bq = 1.0 + s / P.hp_kernel;
+      K00 = pow(Bq, -P.hp_kernel);
+      M1 = pow(Bq, -P.hp_kernel - 1.0);
+      E = 0.0;
     } else {
       double s = 0.0;
 #pragma unroll
@@ -240,6 +261,7 @@ __global__ void __launch_bounds__(256) cross_kernel(AsmParams P, const double* _
     if (j < nx) {
       if (I == 0) v = K00;
       else if (KERN == GPG_KERNEL_SQEXP) v = ((-2.0 * P.theta[I - 1]) * R[I - 1]) * E;
+      else if (KERN == GPG_KERNEL_RATQU) v = ((-2.0 * P.theta[I - 1]) * R[I - 1]) * M1;   // KernelRatQuad.py:540
       else v = ((-P.theta[I - 1]) * R[I - 1]) * M1;
       v *= invp[c];
     }
@@ -292,6 +314,7 @@ void gpg_launch_assembly(gpg_ctx* c, const AsmParams& p) {
   double bytes = 8.0 * (double)p.N * ((double)p.N + 1.0) / 2.0;
   gpg_prof_begin(c, GPG_PROF_ASSEMBLY, bytes);
   if (p.kernel == GPG_KERNEL_SQEXP) launch_assemble_d<GPG_KERNEL_SQEXP>(c, p, 1, nullptr, 0, 0);
+  else if (p.kernel == GPG_KERNEL_RATQU) launch_assemble_d<GPG_KERNEL_RATQU>(c, p, 1, nullptr, 0, 0);
   else launch_assemble_d<GPG_KERNEL_MA5F2>(c, p, 1, nullptr, 0, 0);
   gpg_prof_end(c);
 }
@@ -308,11 +331,13 @@ void gpg_launch_prep_assembly_batch(gpg_ctx* c, const AsmParams& p, int B, const
   double bytes = 8.0 * (double)p.N * ((double)p.N + 1.0) / 2.0 * B;
   gpg_prof_begin(c, GPG_PROF_ASSEMBLY, bytes);
   if (p.kernel == GPG_KERNEL_SQEXP) launch_assemble_d<GPG_KERNEL_SQEXP>(c, p, B, items, v_stride, a_stride);
+  else if (p.kernel == GPG_KERNEL_RATQU) launch_assemble_d<GPG_KERNEL_RATQU>(c, p, B, items, v_stride, a_stride);
   else launch_assemble_d<GPG_KERNEL_MA5F2>(c, p, B, items, v_stride, a_stride);
   gpg_prof_end(c);
 }
 
 void gpg_launch_cross(gpg_ctx* c, const AsmParams& p, int nx, int nxp) {
   if (p.kernel == GPG_KERNEL_SQEXP) launch_cross_d<GPG_KERNEL_SQEXP>(c, p, nx, nxp);
+  else if (p.kernel == GPG_KERNEL_RATQU) launch_cross_d<GPG_KERNEL_RATQU>(c, p, nx, nxp);
   else launch_cross_d<GPG_KERNEL_MA5F2>(c, p, nx, nxp);
 }

@@ -21,6 +21,7 @@ struct AsmParams {
   int precon;      // 1: write varK*(P^-1 Kw P^-1 + eta I); 0: varK*(Kw + eta I)
   int mode;        // 0: matrix to factorise, 1: raw Kern, 2: Kcov (P Kp P for precon)
   double varK, eta;
+  double hp_kernel; // alpha of the rational quadratic kernel
   double theta[GPG_MAX_DIM];
 };
 

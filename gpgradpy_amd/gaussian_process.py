@@ -51,7 +51,7 @@ class GaussianProcess(HparaOptz):
     _time_chofac = 0
     _last_hp_vec = None
 
-    kernel_types = ('SqExp', 'Ma5f2')
+    kernel_types = ('SqExp', 'Ma5f2', 'RatQu')
 
     def __init__(self, dim, use_grad, kernel_type='SqExp', wellcond_mtd='precon', mean_fun_type='poly_ord_0',
                  path_data_surr='baye_data_surr', surr_name='obj_', device=0):
@@ -64,14 +64,17 @@ class GaussianProcess(HparaOptz):
         self.set_wellcond_mtd(wellcond_mtd)
         self.path_data_surr = path_data_surr
         self.surr_name = surr_name
-        if kernel_type == 'RatQu':
-            raise NotImplementedError("kernel 'RatQu' is outside the accelerated path (SURVEY.md 8f4)")
         if kernel_type not in self.kernel_types:
             raise Exception('Kernel type is not available')                       # Kernel.py:108-109
         self.kernel_type = kernel_type
-        self.hp_kernel_default = None                                           # KernelSqExp.py:577, KernelMatern5f2.py:651
-        self.kernel_has_hp = False
-        self.hp_kernel = None
+        if kernel_type == 'RatQu':                                              # KernelRatQuad.py:849-850, Kernel.py:84-85
+            self.hp_kernel_default = 2                                          # (value + posterior mean / std only here:
+            self.hp_kernel_range = [1e-3, 10]                                   #  no likelihood / posterior derivatives)
+        else:
+            self.hp_kernel_default = None                                       # KernelSqExp.py:577, KernelMatern5f2.py:651
+            self.hp_kernel_range = None
+        self.kernel_has_hp = self.hp_kernel_default is not None                 # Kernel.py:111-112
+        self.hp_kernel = self.hp_kernel_default
         if mean_fun_type != 'poly_ord_0':
             raise Exception(f'mean_fun_type = {mean_fun_type} not available')     # GpMeanFun.py:203-204
         self.mean_fun_type = mean_fun_type
@@ -107,10 +110,11 @@ class GaussianProcess(HparaOptz):
 
     def theta2gamma(self, theta):
         # KernelSqExp.py:580-583 / KernelMatern5f2.py:654-657
-        return np.sqrt(2 * theta) if self.kernel_type == 'SqExp' else np.sqrt((5.0 / 3.0) * theta)
+        # (RatQu as SqExp: KernelRatQuad.py:853-860)
+        return np.sqrt((5.0 / 3.0) * theta) if self.kernel_type == 'Ma5f2' else np.sqrt(2 * theta)
 
     def gamma2theta(self, gamma):
-        return 0.5 * gamma ** 2 if self.kernel_type == 'SqExp' else (3.0 / 5.0) * gamma ** 2
+        return (3.0 / 5.0) * gamma ** 2 if self.kernel_type == 'Ma5f2' else 0.5 * gamma ** 2
 
     def calc_nugget_Kbase(self, n_eval, cond_max=None):
         # GpWellCond.py:109-114
@@ -129,7 +133,7 @@ class GaussianProcess(HparaOptz):
             return eta_Kbase, eta_Kbase
         if self.wellcond_mtd == 'precon':
             dim = self.dim
-            if self.kernel_type == 'SqExp':
+            if self.kernel_type == 'SqExp' or self.kernel_type == 'RatQu':        # GpWellCond.py:129
                 ub = 0.5 * (n_eval - 1) * (1 + np.sqrt(1 + 4 * dim)) * np.exp(-(1 + 2 * dim - np.sqrt(1 + 4 * dim)) / (4 * dim))
             else:
                 al = (np.sqrt(3 * dim) - 1 + np.sqrt(15 * dim + 2 * np.sqrt(3 * dim) + 1)) / (2 * (3 * dim + np.sqrt(3 * dim)))
@@ -171,6 +175,10 @@ class GaussianProcess(HparaOptz):
                 bvec[idx_theta] = 1
         if has_kernel:
             assert self.kernel_has_hp, 'Kernel must have hyperaparamters if b_optz_hp_kernel is set to True'
+            idx_kernel = np.array([cnt])                                        # GpHparaOptz.py:90-96
+            cnt += 1
+            if self.optz_log_hp_kernel:
+                bvec[idx_kernel] = 1
         if has_varK:
             idx_varK = cnt
             cnt += 1
@@ -205,6 +213,7 @@ class GaussianProcess(HparaOptz):
         b = hp_optz_info.bvec_log_optz
         v[b] = 10 ** (v[b])
         theta = v[hp_optz_info.idx_theta] if hp_optz_info.has_theta else None
+        hp_kernel = v[hp_optz_info.idx_kernel] if hp_optz_info.has_kernel else None     # GpHpara.py:80-83
         varK = var_fval = var_fgrad = None
         if hp_optz_info.has_varK:
             assert self.b_has_noisy_data
@@ -215,7 +224,7 @@ class GaussianProcess(HparaOptz):
         if hp_optz_info.has_var_fgrad:
             assert self.b_optz_var_fgrad
             var_fgrad = v[hp_optz_info.idx_var_fgrad]
-        return self.make_hp_class(None, theta, None, varK, var_fval, var_fgrad)
+        return self.make_hp_class(None, theta, hp_kernel, varK, var_fval, var_fgrad)
 
     # ---- data ingest ---------------------------------------------------------------------------------
     def set_data(self, x_eval, fval, std_fval, grad=None, std_grad=None, bvec_use_grad=None):
@@ -367,6 +376,11 @@ class GaussianProcess(HparaOptz):
         hp.eta = float(self._etaK)
         hp.wellcond = _lib.GPG_WELLCOND[self.wellcond_mtd]
         hp.closed_form_varK = int(closed_form)
+        if self.kernel_has_hp:
+            assert hp_vals.kernel is not None, 'hp_vals.kernel (alpha of RatQu) must be set'
+            hp.hp_kernel = float(np.asarray(hp_vals.kernel).reshape(-1)[0])
+        else:
+            hp.hp_kernel = 0.0
         if not self.cond_eta_is_const:
             raise NotImplementedError('cond_eta_is_const=False (row-sum nugget) is outside the accelerated path')
         return hp, theta   # keep theta alive
@@ -428,6 +442,8 @@ class GaussianProcess(HparaOptz):
     # ---- likelihood ------------------------------------------------------------------------------------
     def calc_lkd_all(self, hp_vals, calc_lkd=True, calc_cond=False, calc_grad=False, lkd_use_adj_mtd=None):
         """One marginal-log-likelihood evaluation -- reference CalcLkd.py:270-346 (value path)."""
+        if calc_grad and self.kernel_type == 'RatQu':
+            raise NotImplementedError("likelihood gradient is not available for kernel 'RatQu' (SURVEY.md 8f4: value only)")
         if calc_grad and self.bvec_use_grad is not None and not np.all(self.bvec_use_grad):
             # the reference itself fails here (shape bug KernelSqExp.py:552-554, SURVEY.md section 4): nothing to pin against
             raise NotImplementedError('likelihood gradient with a bvec_use_grad mask is not supported')
@@ -499,7 +515,8 @@ class GaussianProcess(HparaOptz):
         v = hp_x0.copy()
         v[:, info.bvec_log_optz] = 10.0 ** v[:, info.bvec_log_optz]
         m, d = v.shape[0], self.dim
-        rows = np.empty((m, d + 3))
+        rows = np.empty((m, d + 4))
+        rows[:, d + 3] = (v[:, info.idx_kernel[0]] if info.has_kernel else self.hp_kernel_default) if self.kernel_has_hp else 0.0
         rows[:, :d] = v[:, info.idx_theta]
         rows[:, d] = v[:, info.idx_varK] if info.has_varK else 1.0
         rows[:, d + 1] = v[:, info.idx_var_fval] if info.has_var_fval else -1.0
@@ -591,6 +608,8 @@ class GaussianProcess(HparaOptz):
         """GpEvalModel.py:59-198: returns (mu, sig, dmudx, dsigdx, d2mudx2, d2sigdx2); the Hessians are
         evaluated one point per call, as in the reference (GpEvalModel.py:358,369)."""
         assert self.KernEta_chofac is not None, 'To evaluate the surr the Cholesky decomposition is required'
+        if calc_grad and self.kernel_type == 'RatQu':
+            raise NotImplementedError("posterior derivatives are not available for kernel 'RatQu' (SURVEY.md 8f4)")
         if calc_hess:
             assert calc_grad, 'To return the hessian calc_grad must also be set to True'      # GpEvalModel.py:126-127
             if self.bvec_use_grad is not None and not np.all(self.bvec_use_grad):

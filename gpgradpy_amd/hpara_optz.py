@@ -287,6 +287,9 @@ class HparaOptz:
     def optz_hp(self, i_optz):
         if 'rescale' in self.wellcond_mtd:
             raise NotImplementedError('rescale well-conditioning methods are outside the accelerated path')
+        if self.kernel_type == 'RatQu' and self.n_eval > self.hp_const_n_eval:
+            raise NotImplementedError("hyperparameter optimisation needs the likelihood gradient, which is not built for kernel "
+                                      "'RatQu' (value and posterior mean / std only, SURVEY.md 8f4)")
         if self.n_eval <= self.hp_const_n_eval:
             hp_vals = self.get_init_hp_vals()
             surr_optz_info, cond_val = None, np.nan

@@ -27,7 +27,9 @@ extern "C" {
 
 typedef struct gpg_ctx gpg_ctx;
 
-enum { GPG_KERNEL_SQEXP = 0, GPG_KERNEL_MA5F2 = 1 };
+/* RatQu (KernelRatQuad.py:439-554): likelihood value and posterior mean / std only -- gpg_lkd_grad, gpg_predict_grad
+ * and gpg_predict_hess return -1 for it. */
+enum { GPG_KERNEL_SQEXP = 0, GPG_KERNEL_MA5F2 = 1, GPG_KERNEL_RATQU = 2 };
 enum { GPG_WELLCOND_BASE = 0, GPG_WELLCOND_PRECON = 1 };
 
 /* Hyperparameters + regularisation of ONE evaluation.
@@ -44,6 +46,8 @@ typedef struct {
   int wellcond;        /* GPG_WELLCOND_PRECON (Kernel.py:220-266) or _BASE (Kernel.py:268-302)  */
   int closed_form_varK;/* 1: noise-free path, varK = max(1e-32, r'K^-1 r / N) (CalcLkd.py:159); */
                        /* 0: noisy path, ln_lkd = -(ln_det + r'K^-1 r)/2 (CalcLkd.py:226)       */
+  double hp_kernel;    /* hyperparameter of the kernel itself (HparaOptzVal.kernel): alpha > 0   */
+                       /* of GPG_KERNEL_RATQU (KernelRatQuad.py:468); ignored by the others      */
 } gpg_hp;
 
 /* Result of one likelihood evaluation = the scalar fields of LkdInfo (CalcLkd.py:14-26). */
@@ -97,8 +101,8 @@ int gpg_lkd_grad(gpg_ctx* ctx, const gpg_hp* hp, gpg_lkd_out* out, double* g_aa,
 
 /* Replaces the serial restart loop of GpHparaX0.select_hp_optz_x0 (GpHparaX0.py:33-59) on ONE
  * device: m hyperparameter rows, hp_rows [m, row_len] with row = [theta(d), varK_mat, var_fval,
- * var_fgrad] already decoded from log10 (GpHpara.py:56-103); eta / wellcond / closed_form_varK are
- * shared.  out [m].  Rows whose factorisation fails get info > 0 and NaN ln_lkd (GpHparaX0.py:34,
+ * var_fgrad (, hp_kernel if row_len >= d + 4: alpha of GPG_KERNEL_RATQU)] already decoded from log10
+ * (GpHpara.py:56-103); eta / wellcond / closed_form_varK are shared.  out [m].  Rows whose factorisation fails get info > 0 and NaN ln_lkd (GpHparaX0.py:34,
  * 43-45).  Returns 0 unless an argument / runtime error occurred.  All m evaluations are queued on
  * the stream back-to-back and synchronised once. */
 int gpg_lkd_batch(gpg_ctx* ctx, int m, const double* hp_rows, int row_len, double eta, int wellcond,

@@ -22,8 +22,16 @@ from dataclasses import dataclass, field
 import numpy as np
 from scipy.linalg import cho_factor, cho_solve
 
-SQEXP, MA5F2 = 0, 1
-_KERNEL_ID = {"SqExp": SQEXP, "Ma5f2": MA5F2}
+SQEXP, MA5F2, RATQU = 0, 1, 2
+_KERNEL_ID = {"SqExp": SQEXP, "Ma5f2": MA5F2, "RatQu": RATQU}
+
+
+def _kern_split(kernel):
+    """`kernel` is a name, or for the rational quadratic kernel the pair ("RatQu", alpha) -- alpha is
+    HparaOptzVal.kernel of the reference (KernelRatQuad.py:468, default 2: :849)."""
+    if isinstance(kernel, (tuple, list)):
+        return kernel[0], float(kernel[1])
+    return kernel, (2.0 if kernel == "RatQu" else None)
 
 
 # --------------------------------------------------------------------------------------------
@@ -39,7 +47,8 @@ def calc_nugget(n_eval: int, dim: int, kernel: str, use_grad: bool, wellcond: st
         return eta_base, eta_base
     if wellcond == "precon":
         d = float(dim)
-        if kernel == "SqExp":
+        kernel = _kern_split(kernel)[0]
+        if kernel in ("SqExp", "RatQu"):                       # GpWellCond.py:129
             s = np.sqrt(1.0 + 4.0 * d)
             ub = 0.5 * (n_eval - 1) * (1.0 + s) * np.exp(-(1.0 + 2.0 * d - s) / (4.0 * d))
         elif kernel == "Ma5f2":
@@ -87,8 +96,11 @@ def kern_base(X, Y, theta, kernel):
     """Gradient-free kernel matrix -- reference KernelSqExp.py:16-46, KernelMatern5f2.py:16-52."""
     R = _rtensor(X, Y)
     s = np.tensordot(theta, R ** 2, axes=1)
+    kernel, alpha = _kern_split(kernel)
     if kernel == "SqExp":
         return np.exp(-s)
+    if kernel == "RatQu":                                      # KernelRatQuad.py:16-48
+        return (1.0 + s / alpha) ** (-alpha)
     nu = np.sqrt(s)
     r5 = np.sqrt(5.0)
     return (1.0 + r5 * nu + (5.0 / 3.0) * nu ** 2) * np.exp(-r5 * nu)
@@ -117,7 +129,17 @@ def kern_grad(X, Y, theta, kernel, grad_cols=True, mask1=None, mask2=None):
     n2 = Y.shape[0]
     R = _rtensor(X, Y)
     s = np.tensordot(theta, R ** 2, axes=1)
-    if kernel == "SqExp":
+    kernel, alpha = _kern_split(kernel)
+    if kernel == "RatQu":                                      # KernelRatQuad.py:439-554
+        B = 1.0 + s / alpha
+        K00 = B ** (-alpha)
+        m1 = B ** (-alpha - 1.0)
+        m2 = B ** (-alpha - 2.0)
+        const = 4.0 * (1.0 + 1.0 / alpha)
+        c1 = 2.0 * theta[:, None, None] * R * m1
+        diag_add = [2.0 * theta[i] * m1 for i in range(d)]
+        cross = lambda i, j: -const * theta[i] * theta[j] * R[i] * R[j] * m2
+    elif kernel == "SqExp":
         E = np.exp(-s)
         K00 = E
         c1 = 2.0 * theta[:, None, None] * R * E                     # +2 th_i R_i E  (block [0, i+1])

@@ -33,6 +33,8 @@ def load_case(path):
             c[k] = float(c[k])
     if "bvec_use_grad" in c:
         c["bvec_use_grad"] = c["bvec_use_grad"].astype(bool)
+    # what the oracle takes as `kernel`: the name, or ("RatQu", alpha) for the kernel with a hyperparameter of its own
+    c["kernel_o"] = (c["kernel"], float(c["hp_kernel"])) if c.get("kernel") == "RatQu" else c.get("kernel")
     c["std_f"] = None if c["std_f"].size == 0 else c["std_f"]
     c["std_g"] = None if c["std_g"].size == 0 else c["std_g"]
     return c

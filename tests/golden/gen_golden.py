@@ -65,7 +65,7 @@ def rosenbrock(x, a=10.0):
 
 def make_case(GaussianProcess, name, n, d, kernel, noise, use_grad=True, wellcond='precon', seed=0,
               theta=None, varK=None, var_fval=None, var_fgrad=None, nq=8, near_dup=False, etaK=None,
-              store_mats=False, pnlt=None, mask=False):
+              store_mats=False, pnlt=None, mask=False, hp_kernel=None):
     rng = np.random.default_rng(seed)
     x = rng.uniform(-2, 2, (n, d))
     if near_dup and n > 2:
@@ -119,7 +119,8 @@ def make_case(GaussianProcess, name, n, d, kernel, noise, use_grad=True, wellcon
     if noise == 'unknown':
         var_fval = 1e-4 if var_fval is None else var_fval
         var_fgrad = (1e-2 if var_fgrad is None else var_fgrad) if use_grad else None
-    hp = GP.make_hp_class(theta=theta, kernel=GP.hp_kernel_default, varK=varK if noisy else None,
+    hp = GP.make_hp_class(theta=theta, kernel=GP.hp_kernel_default if hp_kernel is None else hp_kernel,
+                          varK=varK if noisy else None,
                           var_fval=var_fval, var_fgrad=var_fgrad)
 
     lkd, ok = GP.calc_lkd_all(hp, calc_lkd=True, calc_cond=False, calc_grad=False)
@@ -132,10 +133,12 @@ def make_case(GaussianProcess, name, n, d, kernel, noise, use_grad=True, wellcon
                var_fgrad=np.nan if var_fgrad is None else var_fgrad,
                etaK=GP._etaK, b_has_noisy_data=noisy, b_chofac_good=bool(ok), xq=xq,
                n_data=GP.n_data, bvec_use_grad=np.ones(n, dtype=bool) if bvec is None else bvec, pnlt=np.array([np.nan, np.nan] if pnlt is None else pnlt))
+    if hp.kernel is not None:                 # kernels with a hyperparameter of their own (RatQu: alpha)
+        out['hp_kernel'] = float(hp.kernel)
     if not ok:
         return out
 
-    if not mask:
+    if not mask and kernel != 'RatQu':        # (RatQu: value path only in the build)
         lkd_g, ok_g = GP.calc_lkd_all(hp, calc_lkd=True, calc_cond=False, calc_grad=True)
         out['ln_lkd_grad'] = np.asarray(lkd_g.ln_lkd_grad, dtype=float)
     out.update(hp_beta=np.asarray(lkd.hp_beta, dtype=float),

@@ -29,7 +29,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layout_matches_header():
     assert ctypes.sizeof(_lib.GpgLkdOut) == 5 * 8 + 2 * 4
-    assert ctypes.sizeof(_lib.GpgHp) == 8 + 4 * 8 + 2 * 4
+    assert ctypes.sizeof(_lib.GpgHp) == 8 + 4 * 8 + 2 * 4 + 8          # ... + hp_kernel (alpha of RatQu), appended last
+    assert _lib.GpgHp.hp_kernel.offset == 48
 
 
 def _no_gpu():
@@ -91,9 +92,27 @@ def test_nugget_table_matches_reference():
         assert np.isclose(b, eb, rtol=1e-15) and np.isclose(g, eg, rtol=1e-14)
 
 
+def test_hp_index_map_with_kernel_hyperparameter():
+    """RatQu carries its own hyperparameter between theta and varK (GpHparaOptz.py:90-96); values probed from the
+    reference (d=3, known noise): n_hp = 5, idx_kernel = [3], idx_varK = 4, all log10, etaK as SqExp."""
+    GP = _gp_host_only(3, 'RatQu', 6, 'known')
+    i = GP.hp_info_optz_lkd
+    assert i.n_hp == 5 and list(i.idx_theta) == [0, 1, 2] and list(i.idx_kernel) == [3] and i.idx_varK == 4
+    assert i.bvec_log_optz.all()
+    hp = GP.hp_vec2dataclass(i, np.array([-1.0, -0.5, -0.2, 0.3, 0.1]))
+    np.testing.assert_allclose(hp.theta, [0.1, 0.31622777, 0.63095734], rtol=1e-7)
+    np.testing.assert_allclose(hp.kernel, [1.99526231], rtol=1e-8)
+    np.testing.assert_allclose(hp.varK, 1.2589254117941673, rtol=1e-14)
+    assert np.isclose(GP._etaK, 9.677056687390654e-10, rtol=1e-14)
+    rows = GP._rows_from_hp_x0(np.array([[-1.0, -0.5, -0.2, 0.3, 0.1]]))
+    np.testing.assert_allclose(rows[0], [0.1, 0.31622777, 0.63095734, 1.2589254117941673, -1.0, -1.0, 1.99526231], rtol=1e-7)
+
+
 def test_out_of_scope_features_raise():
-    with pytest.raises(NotImplementedError):
-        gpgradpy_amd.GaussianProcess(2, True, 'RatQu')
+    GPr = gpgradpy_amd.GaussianProcess(2, True, 'RatQu')               # value path only: its own hyperparameter alpha
+    assert GPr.kernel_has_hp and GPr.hp_kernel_default == 2 and GPr.hp_kernel_range == [1e-3, 10]   # KernelRatQuad.py:849-850
+    with pytest.raises(Exception):
+        gpgradpy_amd.GaussianProcess(2, True, 'Cubic')                  # Kernel.py:108-109
     with pytest.raises(NotImplementedError):
         gpgradpy_amd.GaussianProcess(2, True, 'SqExp', 'rescale_origin')
     with pytest.raises(AssertionError):

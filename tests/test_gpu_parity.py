@@ -39,7 +39,7 @@ def _oracle_cond(c):
     nv = orc.calc_noise_vec(c["n"], c["d"], c["use_grad"], c["std_f"], c["std_g"] if c["use_grad"] else None, vf, vg,
                             n_grad=int(c["bvec_use_grad"].sum()))
     gm = None if c["bvec_use_grad"].all() else c["bvec_use_grad"]
-    fac = orc.calc_all_K_w_chofac(c["x"], c["theta"], c["kernel"], c["use_grad"], c["wellcond"] if c["use_grad"] else "base",
+    fac = orc.calc_all_K_w_chofac(c["x"], c["theta"], c["kernel_o"], c["use_grad"], c["wellcond"] if c["use_grad"] else "base",
                                   c["etaK"], nv, varK=c["varK_in"] if c["b_has_noisy_data"] else 1.0, grad_mask=gm)
     return np.linalg.cond(fac.Kcov)
 
@@ -48,7 +48,8 @@ def _hp_from_case(GP, c):
     noisy = c["b_has_noisy_data"]
     vf = None if np.isnan(c["var_fval"]) else c["var_fval"]
     vg = None if np.isnan(c["var_fgrad"]) else c["var_fgrad"]
-    return GP.make_hp_class(theta=c["theta"], varK=c["varK_in"] if noisy else None, var_fval=vf, var_fgrad=vg)
+    return GP.make_hp_class(theta=c["theta"], kernel=float(c["hp_kernel"]) if "hp_kernel" in c else None,
+                            varK=c["varK_in"] if noisy else None, var_fval=vf, var_fgrad=vg)
 
 
 @pytest.mark.parametrize("path", CASES, ids=case_id)
@@ -101,6 +102,10 @@ def test_golden_case(path):
     mu, sig = GP.eval_model(c["xq"])[:2]
     np.testing.assert_allclose(mu, c["mu"], rtol=tol.MU_RTOL, atol=tol.MU_ATOL_SCALE * max(1.0, np.abs(c["mu"]).max()))
     np.testing.assert_allclose(sig, c["sig"], rtol=tol.SIG_RTOL, atol=tol.SIG_ATOL_SCALE * np.sqrt(hp2.varK))
+    if c["kernel"] == "RatQu":            # value + posterior mean / std only
+        with pytest.raises(NotImplementedError):
+            GP.eval_model(c["xq"], calc_grad=True)
+        return
     # posterior gradients (reference GpEvalModel.py:170-172, 319-354)
     mu_g, sig_g, dmudx, dsigdx, h1, h2 = GP.eval_model(c["xq"], calc_grad=True)
     assert h1 is None and h2 is None and np.allclose(mu_g, mu, rtol=1e-12) and np.allclose(sig_g, sig, rtol=1e-9, atol=1e-14)
@@ -340,6 +345,40 @@ def test_random_small_shapes_against_oracle():
         assert ok and r.ok, (case, n, d, kernel, noise)
         ref = dict(hp_beta=r.hp_beta, hp_varK=r.hp_varK, ln_det_Kmat=r.ln_det_Kmat, ln_lkd=r.ln_lkd)
         tol.check_scalars(info.hp_beta[0], info.hp_varK, info.ln_det_Kmat, info.ln_lkd, ref, y.size, noise != 'none')
+
+
+def test_ratqu_against_oracle_and_batched_rows():
+    """Rational quadratic kernel (KernelRatQuad.py:439-554) at a multi-tile size against the oracle, and restart rows
+    [log10 theta, log10 alpha] through the batched path against one-at-a-time evaluations."""
+    import gpgradpy_amd
+    from oracle import gp_oracle as orc
+    n, d = 300, 6
+    X, f, g = orc.synthetic_design(n, d, seed=3)
+    GP = gpgradpy_amd.GaussianProcess(d, True, 'RatQu', 'precon')
+    GP.set_data(X, f, np.zeros(n), g, np.zeros((n, d)))
+    assert GP.hp_info_optz_lkd.n_hp == d + 1
+    rng = np.random.default_rng(4)
+    rows = np.hstack((rng.uniform(-2.2, -0.6, (6, d)), rng.uniform(-0.5, 0.8, (6, 1))))     # alpha in [0.3, 6.3]
+    ln_b = GP.calc_lkd_batch(rows)
+    y = orc.make_data_vec(f, g)
+    nv = orc.calc_noise_vec(n, d, True, np.zeros(n), np.zeros((n, d)))
+    for i in (0, 3, 5):
+        hp = GP.hp_vec2dataclass(GP.hp_info_optz_lkd, rows[i])
+        info, ok = GP.calc_lkd_all(hp)
+        assert ok and info.ln_lkd == ln_b[i]                                     # batched == one at a time, bitwise
+        r = orc.calc_lkd(X, y, hp.theta, ("RatQu", float(hp.kernel[0])), True, "precon", GP._etaK, nv, False)
+        ref = dict(hp_beta=r.hp_beta, hp_varK=r.hp_varK, ln_det_Kmat=r.ln_det_Kmat, ln_lkd=r.ln_lkd)
+        tol.check_scalars(info.hp_beta[0], info.hp_varK, info.ln_det_Kmat, info.ln_lkd, ref, y.size, False)
+    hp2 = GP.optz_closed_form_hp(hp)
+    GP.set_hpara('set', 0, hp_vals=hp2)
+    m = orc.setup_eval_model(X, y, hp.theta, ("RatQu", float(hp.kernel[0])), True, "precon", GP._etaK, nv, r.hp_beta, hp2.varK)
+    xq = rng.uniform(-2, 2, (70, d))
+    mu, sig = GP.eval_model(xq)[:2]
+    mu_o, sig_o = orc.eval_model(m, xq)
+    np.testing.assert_allclose(mu, mu_o, rtol=tol.MU_RTOL, atol=tol.MU_ATOL_SCALE * max(1.0, np.abs(mu_o).max()))
+    np.testing.assert_allclose(sig, sig_o, rtol=tol.SIG_RTOL, atol=tol.SIG_ATOL_SCALE * np.sqrt(hp2.varK))
+    with pytest.raises(NotImplementedError):
+        GP.calc_lkd_all(hp, calc_grad=True)
 
 
 def test_many_query_points_split_over_launches():

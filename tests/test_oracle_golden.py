@@ -27,12 +27,12 @@ def test_oracle_matches_reference(path):
     assert y.size == c["n_data"]
     # nugget (reference GpWellCond.py:116-154); the chofail case overrides it by hand
     if "chofail" not in c["name"]:
-        eb, eg = orc.calc_nugget(c["n"], c["d"], c["kernel"], c["use_grad"], c["wellcond"])
+        eb, eg = orc.calc_nugget(c["n"], c["d"], c["kernel_o"], c["use_grad"], c["wellcond"])
         assert np.isclose(eg if c["use_grad"] else eb, c["etaK"], rtol=1e-14)
     noisy = c["b_has_noisy_data"]
     wc = c["wellcond"] if c["use_grad"] else "base"
     gm = None if c["bvec_use_grad"].all() else c["bvec_use_grad"]
-    r = orc.calc_lkd(c["x"], y, c["theta"], c["kernel"], c["use_grad"], wc, c["etaK"], nv, noisy,
+    r = orc.calc_lkd(c["x"], y, c["theta"], c["kernel_o"], c["use_grad"], wc, c["etaK"], nv, noisy,
                      varK=c["varK_in"] if noisy else None, grad_mask=gm)
     assert r.ok == c["b_chofac_good"]
     if not r.ok:
@@ -51,7 +51,7 @@ def test_oracle_matches_reference(path):
         np.testing.assert_allclose(r.factor.Kern, c["Kern"], rtol=1e-14, atol=1e-16)
         np.testing.assert_allclose(r.factor.Kcov, c["Kcov"], rtol=1e-13, atol=1e-16)
     # as-written variant (dense diagonal products) gives the same values
-    r2 = orc.calc_lkd(c["x"], y, c["theta"], c["kernel"], c["use_grad"], wc, c["etaK"], nv, noisy,
+    r2 = orc.calc_lkd(c["x"], y, c["theta"], c["kernel_o"], c["use_grad"], wc, c["etaK"], nv, noisy,
                       varK=c["varK_in"] if noisy else None, as_written=True, grad_mask=gm)
     if np.isnan(c["pnlt"][0]):
         np.testing.assert_allclose(r2.ln_lkd, c["ln_lkd"], rtol=tol.LN_LKD_RTOL)
@@ -60,7 +60,7 @@ def test_oracle_matches_reference(path):
     if "ln_lkd_grad" in c and np.isnan(c["pnlt"][0]) and c["n_data"] <= 200:
         vf = None if np.isnan(c["var_fval"]) else c["var_fval"]
         vg = None if np.isnan(c["var_fgrad"]) else c["var_fgrad"]
-        g = orc.calc_lkd_grad(c["x"], y, c["theta"], c["kernel"], c["use_grad"], wc, c["etaK"], c["std_f"],
+        g = orc.calc_lkd_grad(c["x"], y, c["theta"], c["kernel_o"], c["use_grad"], wc, c["etaK"], c["std_f"],
                               c["std_g"] if c["use_grad"] else None, noisy, varK=c["varK_in"] if noisy else None,
                               var_fval=vf, var_fgrad=vg)
         sl = tol.lkd_grad_slots_to_check(c)
@@ -70,7 +70,7 @@ def test_oracle_matches_reference(path):
     beta = r.hp_beta
     varK_model = c["varK_in"] if noisy else r.hp_varK
     np.testing.assert_allclose(varK_model, c["varK_model"], rtol=tol.VARK_RTOL)
-    m = orc.setup_eval_model(c["x"], y, c["theta"], c["kernel"], c["use_grad"], wc, c["etaK"], nv, beta, varK_model, gm)
+    m = orc.setup_eval_model(c["x"], y, c["theta"], c["kernel_o"], c["use_grad"], wc, c["etaK"], nv, beta, varK_model, gm)
     scale = np.linalg.norm(c["alpha"])
     assert np.linalg.norm(m.alpha - c["alpha"]) <= tol.ALPHA_NORMWISE * scale
     mu, sig = orc.eval_model(m, c["xq"])
