@@ -184,7 +184,7 @@ void gpg_destroy(gpg_ctx* c) {
   for (auto& pe : c->prof_pending) { (void)hipEventDestroy(pe.e0); (void)hipEventDestroy(pe.e1); }
   for (auto& ev : c->prof_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   double* bufs[] = {c->A, c->Xt, c->y, c->noise, c->dvec, c->invp, c->zvec, c->tmpv, c->dinv, c->scal, c->Wt, c->xq_dev,
-                    c->musig, c->gradbuf, c->dense_tmp, c->Wfull, c->Minv, c->gpartial, c->batchA, c->batchV, c->vec_rows, c->vec_x};
+                    c->musig, c->gradbuf, c->dense_tmp, c->Wfull, c->Minv, c->gpartial, c->batchA, c->batchV, c->vec_rows, c->vec_x, c->apply_buf};
   for (double* b : bufs) if (b) (void)hipFree(b);
   if (c->info) (void)hipFree(c->info);
   if (c->gpos) (void)hipFree(c->gpos);
@@ -660,6 +660,26 @@ int gpg_get_matrix(gpg_ctx* c, const gpg_hp* hp, int which, double* out) {
                                c->stream));
   GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
   GPG_HIP_OK(c, hipGetLastError());
+  return 0;
+}
+
+int gpg_factor_apply(gpg_ctx* c, int op, const double* v, double* out) {
+  if (!c) return -1;
+  if (!v || !out || (op != 0 && op != 1)) { c->err = "bad factor_apply arguments"; return -1; }
+  if (!c->factor_valid) { c->err = "no valid factor on the device (gpg_lkd / gpg_setup_eval first)"; return -1; }
+  GPG_HIP_OK(c, hipSetDevice(c->device));
+  if (!c->apply_buf) GPG_HIP_OK(c, hipMalloc(&c->apply_buf, sizeof(double) * 2 * (size_t)c->vec_rows_cols));
+  double* dv = c->apply_buf;
+  double* dout = c->apply_buf + c->vec_rows_cols;
+  GPG_HIP_OK(c, hipMemsetAsync(dv, 0, sizeof(double) * c->Npad, c->stream));
+  GPG_HIP_OK(c, hipMemcpyAsync(dv, v, sizeof(double) * c->N, hipMemcpyHostToDevice, c->stream));
+  GPG_HIP_OK(c, hipMemsetAsync(c->info, 0, sizeof(int), c->stream));
+  if (gpg_factor_apply_dev(c, op, dv, dout) != 0) { c->err = "factor_apply launch failed"; return -2; }
+  GPG_HIP_OK(c, hipMemcpyAsync(out, dout, sizeof(double) * c->N, hipMemcpyDeviceToHost, c->stream));
+  GPG_HIP_OK(c, hipMemcpyAsync(c->h_info, c->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
+  GPG_HIP_OK(c, hipGetLastError());
+  if (solve_failure(c)) return -4;
   return 0;
 }
 

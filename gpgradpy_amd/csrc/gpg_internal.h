@@ -70,6 +70,7 @@ struct gpg_ctx {
   int* info = nullptr;       // device: first failing pivot (0 = none)
   double* vec_rows = nullptr;   // [64 x vec_rows_cols] carrier tile of the single-vector backward solve (on first use)
   int vec_rows_cols = 0;        // = Npad of the full-gradient shape (allocation size)
+  double* apply_buf = nullptr;  // [2 x Npad] vectors of gpg_factor_apply (on first use)
   double* vec_x = nullptr;      // [4 x vec_x_cols] compact solution rows of the vector solves (on first use)
   int vec_x_cols = 0;
   double* Wt = nullptr;      // prediction RHS rows [wt_rows x Npad]
@@ -141,6 +142,7 @@ void gpg_launch_identity(gpg_ctx* c, double* W, int ldw);
 void gpg_inverse_from_factor(gpg_ctx* c, double* W, double* Minv);       // Minv <- -(L L^T)^-1 (lower)
 void gpg_launch_grad_contract(gpg_ctx* c, const AsmParams& p, double* partial, double* out_dev);
 int gpg_grad_partial_blocks(const gpg_ctx* c);
+int gpg_factor_apply_dev(gpg_ctx* c, int op, double* v, double* out);       // (L L^T) v or (L L^T)^-1 v, device vectors [Npad]
 void gpg_launch_extract(gpg_ctx* c, int which);                          // dense_tmp <- sym / P L
 
 // profiling helpers

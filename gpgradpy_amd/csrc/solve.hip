@@ -564,6 +564,64 @@ void gpg_launch_hess_stage(gpg_ctx* c, const AsmParams& p, int nxp, double* h1, 
   else launch_hess_d<GPG_KERNEL_MA5F2>(c, p, nxp, h1, h2, T, stage);
 }
 
+// ---- products with the factor in place (condition number) ------------------------------------
+// w = L^T v: one wave per column j (column-major storage: the column is contiguous), w[j] = sum_{i >= j} L[i][j] v[i]
+__global__ void __launch_bounds__(256) trmv_t_kernel(const double* __restrict__ A, int ld, int n, const double* __restrict__ v,
+                                                     double* __restrict__ w) {
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (j >= n) return;
+  const double* col = A + (size_t)j * ld;
+  double s = 0.0;
+  for (int i = j + lane; i < n; i += 64) s += col[i] * v[i];
+  s = wave_sum(s);
+  if (lane == 0) w[j] = s;
+}
+
+// u = L w: thread <-> row i of a block of 256 rows, columns streamed in chunks of 256 (w chunk in LDS; every load of
+// L is coalesced over the rows), u[i] = sum_{j <= i} L[i][j] w[j]
+__global__ void __launch_bounds__(256) trmv_n_kernel(const double* __restrict__ A, int ld, int n, const double* __restrict__ w,
+                                                     double* __restrict__ u) {
+  __shared__ double ws[256];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int jend = min(n, (int)(blockIdx.x + 1) * 256);
+  double s = 0.0;
+  for (int j0 = 0; j0 < jend; j0 += 256) {
+    __syncthreads();
+    ws[threadIdx.x] = (j0 + (int)threadIdx.x < n) ? w[j0 + threadIdx.x] : 0.0;
+    __syncthreads();
+    if (i < n) {
+      const int jm = min(256, i - j0 + 1);               // columns j0 .. j0 + jm - 1 are <= i
+      const double* p = A + (size_t)i + (size_t)j0 * ld;
+#pragma unroll 8
+      for (int jj = 0; jj < jm; ++jj) s += p[(size_t)jj * ld] * ws[jj];
+    }
+  }
+  if (i < n) u[i] = s;
+}
+
+// out (device, Npad) <- (L L^T) v (op 0) or (L L^T)^-1 v (op 1) with the factor in A; v (device, Npad, zero tail) is
+// overwritten.  The solves run through the single-row dataflow kernels on a carrier tile.
+int gpg_factor_apply_dev(gpg_ctx* c, int op, double* v, double* out) {
+  const int Npad = c->Npad;
+  if (op == 0) {
+    hipLaunchKernelGGL(trmv_t_kernel, dim3((Npad + 3) / 4), dim3(256), 0, c->stream, c->A, c->ld, Npad, v, out);   // out = L^T v
+    hipLaunchKernelGGL(trmv_n_kernel, dim3((Npad + 255) / 256), dim3(256), 0, c->stream, c->A, c->ld, Npad, out, v);  // v = L out
+    return hipMemcpyAsync(out, v, sizeof(double) * Npad, hipMemcpyDeviceToDevice, c->stream) == hipSuccess ? 0 : -2;
+  }
+  if (!c->vec_rows && hipMalloc(&c->vec_rows, sizeof(double) * 64 * (size_t)c->vec_rows_cols) != hipSuccess) return -2;
+  (void)hipMemsetAsync(c->vec_rows, 0, sizeof(double) * 64 * (size_t)Npad, c->stream);
+  (void)hipMemcpy2DAsync(c->vec_rows, 64 * sizeof(double), v, sizeof(double), sizeof(double), Npad, hipMemcpyDeviceToDevice,
+                         c->stream);                                              // row 0 of the carrier <- v
+  if (c->chol_impl != 0 || c->tail_cols != 0) {
+    if (!gpg_launch_rows_fwd(c, c->vec_rows, 64, 64, 1) || !gpg_launch_rows_bwd(c, c->vec_rows, 64, 64, 1)) return -2;
+  } else {
+    gpg_forward_rows(c, c->vec_rows, 64, 64, 1);
+    gpg_backward_rows(c, c->vec_rows, 64, 1, c->gradbuf ? c->gradbuf : v);
+  }
+  return hipMemcpy2DAsync(out, sizeof(double), c->vec_rows, 64 * sizeof(double), sizeof(double), Npad, hipMemcpyDeviceToDevice,
+                          c->stream) == hipSuccess ? 0 : -2;
+}
+
 void gpg_launch_alpha(gpg_ctx* c, double* alpha_dev) {
   hipLaunchKernelGGL(alpha_kernel, dim3((c->N + 255) / 256), dim3(256), 0, c->stream, c->zvec, c->invp, c->N,
                      alpha_dev);

@@ -401,8 +401,6 @@ class GaussianProcess(HparaOptz):
         materialize=True; Kcor is never formed (None)."""
         if noise_vec is not None:
             raise NotImplementedError('a caller-supplied noise_vec is outside the accelerated path')
-        if calc_cond:
-            raise NotImplementedError('calc_cond=True (dense condition number) is outside the accelerated path')
         if varK is None:
             assert hp_vals.varK is not None, f'varK is not provided and hp_vals.varK is None, hp_vals = {hp_vals}'
             varK = hp_vals.varK
@@ -437,7 +435,10 @@ class GaussianProcess(HparaOptz):
                 print(f'Failure of the Cholesky decomposition, first non-positive pivot = {rc}')   # Kernel.py:255
         self._time_chofac += time.time() - t0
         self._eval_ready = False
-        return Kern, None, Kcov, chofac, None, self._etaK, None
+        condK = None
+        if calc_cond:                                         # Kernel.py:239-245 / 279-285 (needs the factor here)
+            condK = self.calc_cond_device() if chofac is not None else np.nan
+        return Kern, None, Kcov, chofac, condK, self._etaK, None
 
     # ---- likelihood ------------------------------------------------------------------------------------
     def calc_lkd_all(self, hp_vals, calc_lkd=True, calc_cond=False, calc_grad=False, lkd_use_adj_mtd=None):
@@ -449,8 +450,8 @@ class GaussianProcess(HparaOptz):
             raise NotImplementedError('likelihood gradient with a bvec_use_grad mask is not supported')
         if calc_grad and not (lkd_use_adj_mtd is None or lkd_use_adj_mtd) and not self.lkd_use_adj_mtd:
             raise NotImplementedError('only the adjoint gradient method is on the accelerated path')
-        if calc_cond:
-            raise NotImplementedError('calc_cond=True is outside the accelerated path (SURVEY.md 8f4)')
+        if calc_cond and calc_grad:
+            raise NotImplementedError('the gradient of the condition number (GpHparaCon.py:163-261) is outside the accelerated path')
         noisy = self.b_has_noisy_data
         if noisy:
             assert hp_vals.varK is not None, f'varK is not provided and hp_vals.varK is None, hp_vals = {hp_vals}'
@@ -473,6 +474,14 @@ class GaussianProcess(HparaOptz):
         if rc > 0:
             # CalcLkd.py:308-311 / 330-333: the reference reports the SVD condition number here; not computed
             return LkdInfo(cond=np.nan), False
+        cond = None
+        if calc_cond:
+            cond = self.calc_cond_device()
+            if self.wellcond_mtd == 'precon':
+                if cond > 1.1 * self.cond_max:                                   # Kernel.py:242-243
+                    print(f'*** WARNING: condK = {cond:.2e} which is greater than cond_max = {self.cond_max:.2e} ***')
+            elif cond > self.cond_max_abs:                                       # Kernel.py:282-283, CalcLkd.py:308-311
+                return LkdInfo(cond=cond), False
         ln_lkd = out.ln_lkd
         if not noisy:
             ln_lkd -= self.calc_lkd_varK_pnlt(out.varK, self._fval_in)[0]        # CalcLkd.py:162,168
@@ -496,7 +505,7 @@ class GaussianProcess(HparaOptz):
         info = LkdInfo(hp_beta=np.array([out.beta]), hp_varK=None if noisy else out.varK,
                        ln_det_Kmat=out.ln_det if calc_lkd or not noisy else None,
                        ln_lkd=ln_lkd if calc_lkd else None, ln_lkd_grad=ln_lkd_grad,
-                       data_vec=self._data_vec if noisy else None, cond=None)
+                       data_vec=self._data_vec if noisy else None, cond=cond)
         return info, True
 
     def calc_lkd_varK_pnlt(self, varK, fval_vec):
@@ -707,6 +716,24 @@ class GaussianProcess(HparaOptz):
         """How often a dataflow factorisation timed out (device shared with another such launch) and the call was
         repeated with the blocked schedule; the context stays on 'blocked' until set_factor_mode is called."""
         return int(self._lib.gpg_factor_fallbacks(self._ctx)) if self._ctx else 0
+
+    def calc_cond_device(self):
+        """2-norm condition number of the matrix factorised last -- Kcov_precon = varK (Kcor + eta I) for 'precon',
+        Kcov for 'base' (what Kernel.py:239-245, 279-285 pass to np.linalg.cond) -- from Lanczos runs on
+        v -> (L L^T) v and v -> (L L^T)^-1 v through the factor in HBM (gpgradpy_amd/cond_number.py)."""
+        from .cond_number import cond_from_factor
+        N = self.n_data
+
+        def op(which):
+            def f(v):
+                v = np.ascontiguousarray(v, dtype=np.float64)
+                out = np.empty(N)
+                rc = self._lib.gpg_factor_apply(self._ctx, which, _lib.as_dp(v), _lib.as_dp(out))
+                if rc != 0:
+                    raise _lib.GpgError(f'gpg_factor_apply failed ({rc}): {self._err()}')
+                return out
+            return f
+        return cond_from_factor(op(0), op(1), N)
 
     def last_factor(self):
         """(schedule, matrices) of the most recent factorisation launch: 'blocked' | 'tile64' | 'tile128'."""

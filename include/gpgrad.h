@@ -146,6 +146,13 @@ int gpg_predict_hess(gpg_ctx* ctx, const double* xq, double varK, double* mu, do
  *     scipy.linalg.cho_solve((out, True), b). */
 int gpg_get_matrix(gpg_ctx* ctx, const gpg_hp* hp, int which, double* out);
 
+/* Products with the matrix that was factorised last (gpg_lkd / gpg_setup_eval), through its factor in HBM:
+ * op 0: out = (L L^T) v, op 1: out = (L L^T)^-1 v; v, out host [N].  L L^T is Kcov_precon = varK (Kcor + eta I)
+ * for 'precon' and Kcov for 'base' -- the matrices whose 2-norm condition number Kernel.py:239-245, 279-285 report.
+ * The host side runs a Lanczos iteration on these two operators to get lambda_max and 1 / lambda_min
+ * (gpgradpy_amd/cond_number.py; replaces np.linalg.cond of an N x N matrix). */
+int gpg_factor_apply(gpg_ctx* ctx, int op, const double* v, double* out);
+
 /* Instrumentation (replaces the wall-clock accumulator _time_chofac, Kernel.py:247,304-305) ------- */
 
 enum {

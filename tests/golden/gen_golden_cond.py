@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Condition numbers of the golden cases from the *reference*: LkdInfo.cond of calc_lkd_all(..., calc_cond=True)
+(Kernel.py:239-245 for 'precon': np.linalg.cond(Kcov_precon, 2); :279-285 for 'base': np.linalg.cond(Kcov, 2)),
+on the inputs stored in the existing fixtures.  Writes tests/golden/cond_table.npz (names, cond).
+Runs only in the build container (reference mounted at /root/reference).
+
+Usage:  python tests/golden/gen_golden_cond.py
+"""
+import glob
+import os
+
+import numpy as np
+
+import gen_golden as gg
+
+
+def main():
+    GaussianProcess = gg._import_reference()
+    names, conds = [], []
+    skip = ("multistart_", "nugget_", "optz_", "hess_", "cond_", "micro_")
+    for path in sorted(glob.glob(os.path.join(gg.HERE, "*.npz"))):
+        base = os.path.basename(path)
+        if base.startswith(skip):
+            continue
+        z = np.load(path, allow_pickle=False)
+        if not bool(z["b_chofac_good"]) or int(z["n_data"]) > 700:
+            continue
+        d, use_grad, kernel = int(z["d"]), bool(z["use_grad"]), str(z["kernel"])
+        GP = GaussianProcess(d, use_grad, kernel, str(z["wellcond"]) if use_grad else "base")
+        std_f = None if z["std_f"].size == 0 else z["std_f"]
+        std_g = None if z["std_g"].size == 0 else z["std_g"]
+        bvec = z["bvec_use_grad"].astype(bool)
+        if use_grad:
+            GP.set_data(z["x"], z["f"], std_f, z["g"], std_g, None if bvec.all() else bvec)
+        else:
+            GP.set_data(z["x"], z["f"], std_f)
+        if not np.isnan(z["pnlt"][0]):
+            continue
+        noisy = bool(z["b_has_noisy_data"])
+        nanv = lambda k: None if np.isnan(float(z[k])) else float(z[k])
+        hp = GP.make_hp_class(theta=z["theta"], kernel=float(z["hp_kernel"]) if "hp_kernel" in z.files else GP.hp_kernel_default,
+                              varK=float(z["varK_in"]) if noisy else None, var_fval=nanv("var_fval"), var_fgrad=nanv("var_fgrad"))
+        lkd, ok = GP.calc_lkd_all(hp, calc_lkd=True, calc_cond=True, calc_grad=False)
+        assert ok and np.isclose(lkd.ln_lkd, float(z["ln_lkd"]), rtol=1e-10), base
+        names.append(base[:-4])
+        conds.append(float(lkd.cond))
+        print(f"{base[:-4]:36s} cond = {lkd.cond:.10e}")
+    np.savez_compressed(os.path.join(gg.HERE, "cond_table.npz"), names=np.array(names), cond=np.array(conds))
+
+
+if __name__ == "__main__":
+    main()

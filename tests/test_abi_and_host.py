@@ -120,7 +120,7 @@ def test_out_of_scope_features_raise():
     GP = _gp_host_only(2, 'SqExp', 4, 'none')
     hp = GP.make_hp_class(theta=np.array([0.5, 0.5]))
     with pytest.raises(NotImplementedError):
-        GP.calc_lkd_all(hp, calc_cond=True)
+        GP.calc_lkd_all(hp, calc_cond=True, calc_grad=True)            # gradient of the condition number
 
 
 def test_data_vec_layout():
