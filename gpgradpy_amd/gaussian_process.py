@@ -444,7 +444,16 @@ class GaussianProcess(HparaOptz):
     def calc_lkd_all(self, hp_vals, calc_lkd=True, calc_cond=False, calc_grad=False, lkd_use_adj_mtd=None):
         """One marginal-log-likelihood evaluation -- reference CalcLkd.py:270-346 (value path)."""
         if calc_grad and self.kernel_type == 'RatQu':
-            raise NotImplementedError("likelihood gradient is not available for kernel 'RatQu' (SURVEY.md 8f4: value only)")
+            # the derivative kernels of RatQu (KernelRatQuad.py:636-843) are not built: central differences of the
+            # device likelihood, all 2 n_hp evaluations in one batched call
+            if calc_cond:
+                raise NotImplementedError('the gradient of the condition number (GpHparaCon.py:163-261) is outside the accelerated path')
+            info, ok = self.calc_lkd_all(hp_vals, calc_lkd=True, calc_cond=calc_cond, calc_grad=False)
+            if ok:
+                info.ln_lkd_grad = self._lkd_grad_central_differences(hp_vals)
+                if not calc_lkd:
+                    info.ln_lkd = None
+            return info, ok
         if calc_grad and self.bvec_use_grad is not None and not np.all(self.bvec_use_grad):
             # the reference itself fails here (shape bug KernelSqExp.py:552-554, SURVEY.md section 4): nothing to pin against
             raise NotImplementedError('likelihood gradient with a bvec_use_grad mask is not supported')
@@ -716,6 +725,39 @@ class GaussianProcess(HparaOptz):
         """How often a dataflow factorisation timed out (device shared with another such launch) and the call was
         repeated with the blocked schedule; the context stays on 'blocked' until set_factor_mode is called."""
         return int(self._lib.gpg_factor_fallbacks(self._ctx)) if self._ctx else 0
+
+    def _lkd_grad_central_differences(self, hp_vals, rel_step=1e-4):
+        """d ln_lkd / d hp_k for the optimised hyperparameters (hp_info_optz_lkd order, derivatives with respect to the
+        hyperparameter VALUES like CalcLkd.py:170-177, not their log10) by central differences of the device likelihood;
+        the closed-form varK of the noise-free path is re-evaluated in every term, i.e. this is the total derivative the
+        reference's adjoint formula gives.  Used where no derivative kernel is built (kernel 'RatQu')."""
+        hi = self.hp_info_optz_lkd
+        x = np.zeros(hi.n_hp)
+        x[hi.idx_theta] = hp_vals.theta
+        if hi.has_kernel:
+            x[hi.idx_kernel] = np.asarray(hp_vals.kernel, dtype=float).reshape(-1)[0]
+        if hi.has_varK:
+            x[hi.idx_varK] = hp_vals.varK
+        if hi.has_var_fval:
+            x[hi.idx_var_fval] = hp_vals.var_fval
+        if hi.has_var_fgrad:
+            x[hi.idx_var_fgrad] = hp_vals.var_fgrad
+        b = hi.bvec_log_optz
+
+        def to_optz(v):
+            v = v.copy()
+            v[b] = np.log10(v[b])
+            return v
+        rows, steps = [], []
+        for k in range(hi.n_hp):
+            h = rel_step * abs(x[k]) if x[k] != 0.0 else 1e-10
+            xp, xm = x.copy(), x.copy()
+            xp[k] += h
+            xm[k] -= h
+            rows += [to_optz(xp), to_optz(xm)]
+            steps.append(h)
+        ln = self.calc_lkd_batch(np.array(rows))
+        return (ln[0::2] - ln[1::2]) / (2.0 * np.array(steps))
 
     def calc_cond_device(self):
         """2-norm condition number of the matrix factorised last -- Kcov_precon = varK (Kcor + eta I) for 'precon',

@@ -97,7 +97,7 @@ class HparaOptz:
         self.time_pick_hp0_all[idx] = time_pick_hp0
         self.hp_beta_all[idx, :] = hp_vals.beta
         self.hp_theta_all[idx, :] = hp_vals.theta
-        self.hp_kernel_all[idx] = np.nan if hp_vals.kernel is None else hp_vals.kernel
+        self.hp_kernel_all[idx] = np.nan if hp_vals.kernel is None else float(np.asarray(hp_vals.kernel, dtype=float).reshape(-1)[0])
         self.hp_varK_all[idx] = np.nan if hp_vals.varK is None else hp_vals.varK
         self.hp_var_fval_all[idx] = np.nan if hp_vals.var_fval is None else hp_vals.var_fval
         self.hp_var_fgrad_all[idx] = np.nan if hp_vals.var_fgrad is None else hp_vals.var_fgrad
@@ -154,8 +154,9 @@ class HparaOptz:
 
         if hp_optz_info.has_theta:
             fill(hp_optz_info.idx_theta, _nanmedian(self.hp_theta_all[idx_min:idx_max, :], self.dim), self.hp_theta_range, self.hp_theta_init)
-        if hp_optz_info.has_kernel:
-            raise NotImplementedError('kernels with their own hyperparameter are outside the accelerated path')
+        if hp_optz_info.has_kernel:                                              # GpHparaX0.py:100-111
+            fill(hp_optz_info.idx_kernel, _nanmedian(self.hp_kernel_all[idx_min:idx_max]), self.hp_kernel_range,
+                 self.hp_kernel_default)
         if hp_optz_info.has_varK:
             fill(hp_optz_info.idx_varK, _nanmedian(self.hp_varK_all[idx_min:idx_max]), self.hp_varK_range, self.hp_varK_init)
         if hp_optz_info.has_var_fval:
@@ -287,9 +288,6 @@ class HparaOptz:
     def optz_hp(self, i_optz):
         if 'rescale' in self.wellcond_mtd:
             raise NotImplementedError('rescale well-conditioning methods are outside the accelerated path')
-        if self.kernel_type == 'RatQu' and self.n_eval > self.hp_const_n_eval:
-            raise NotImplementedError("hyperparameter optimisation needs the likelihood gradient, which is not built for kernel "
-                                      "'RatQu' (value and posterior mean / std only, SURVEY.md 8f4)")
         if self.n_eval <= self.hp_const_n_eval:
             hp_vals = self.get_init_hp_vals()
             surr_optz_info, cond_val = None, np.nan

@@ -92,7 +92,8 @@ def run_case(GaussianProcess, name, n, d, kernel, noise, seed, n_hist=2, start_m
         out[f'it{it}_beta'] = np.array(hv.beta, dtype=float)
         out[f'it{it}_var_fval'] = np.nan if hv.var_fval is None else float(hv.var_fval)
         out[f'it{it}_var_fgrad'] = np.nan if hv.var_fgrad is None else float(hv.var_fgrad)
-        hp_final = GP.make_hp_class(theta=hv.theta, varK=hv.varK if GP.b_has_noisy_data else None,
+        out[f'it{it}_kernel'] = np.nan if hv.kernel is None else float(np.asarray(hv.kernel, dtype=float).reshape(-1)[0])
+        hp_final = GP.make_hp_class(theta=hv.theta, kernel=hv.kernel, varK=hv.varK if GP.b_has_noisy_data else None,
                                     var_fval=hv.var_fval, var_fgrad=hv.var_fgrad)
         out[f'it{it}_ln_lkd'] = GP.calc_lkd_all(hp_final)[0].ln_lkd
         out[f'it{it}_iter_max'] = GP.hp_optz_iter_max[it]
@@ -100,12 +101,15 @@ def run_case(GaussianProcess, name, n, d, kernel, noise, seed, n_hist=2, start_m
         print(f"{name} it{it}: n={ni} theta={hv.theta} varK={hv.varK:.6e} ln_lkd={out[f'it{it}_ln_lkd']:.10e} nit={GP.hp_optz_iter_max[it]}")
     out.update(name=name, n=n, d=d, kernel=kernel, noise=noise, x=x, f=f, g=g, n_hist=n_hist, start_mtd=start_mtd, n_best=n_best,
                std_f=np.full(n, np.nan) if std_f is None else std_f, std_g=np.full((n, d), np.nan) if std_g is None else std_g,
-               theta_hist0=GP.hp_theta_all[0], varK_hist0=GP.hp_varK_all[0])
+               theta_hist0=GP.hp_theta_all[0], varK_hist0=GP.hp_varK_all[0], kernel_hist0=GP.hp_kernel_all[0])
     np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
 
 
 def main():
     GaussianProcess = _import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == 'ratqu':      # only the rational quadratic case (kernel with its own hyperparameter)
+        run_case(GaussianProcess, 'optz_RatQu_none_n12_d2', 12, 2, 'RatQu', 'none', seed=36)
+        return
     run_case(GaussianProcess, 'optz_SqExp_none_n10_d1', 10, 1, 'SqExp', 'none', seed=31)
     run_case(GaussianProcess, 'optz_SqExp_none_n14_d3', 14, 3, 'SqExp', 'none', seed=32)
     run_case(GaussianProcess, 'optz_Ma5f2_known_n12_d2', 12, 2, 'Ma5f2', 'known', seed=33)

@@ -55,6 +55,8 @@ def test_start_rows_and_bounds_from_history(path):
             pass                                               # CPU-only box: host state is complete
         GP.hp_theta_all[0] = c["theta_hist0"]
         GP.hp_varK_all[0] = c["varK_hist0"]
+        if "kernel_hist0" in c:                                 # kernels with a hyperparameter of their own (RatQu)
+            GP.hp_kernel_all[0] = c["kernel_hist0"]
         if c["noise"] == "unknown":
             GP.hp_var_fval_all[0] = GP.hp_var_fval_init
             GP.hp_var_fgrad_all[0] = GP.hp_var_fgrad_init
@@ -65,6 +67,8 @@ def test_start_rows_and_bounds_from_history(path):
         # feed the reference's optimum of this iteration into the history for the next one
         GP.hp_theta_all[it] = c[f"it{it}_theta"]
         GP.hp_varK_all[it] = c[f"it{it}_varK"]
+        if f"it{it}_kernel" in c:
+            GP.hp_kernel_all[it] = c[f"it{it}_kernel"]
         GP.hp_var_fval_all[it] = c[f"it{it}_var_fval"]
         GP.hp_var_fgrad_all[it] = c[f"it{it}_var_fgrad"]
 
@@ -102,12 +106,14 @@ def test_optz_hp_flow_matches_reference(path):
         mu, sig = GP.eval_model(c["x"][:2])[:2]
         assert np.all(np.isfinite(mu)) and np.all(sig >= 0)
         ln_ref = c[f"it{it}_ln_lkd"]
-        hp_final = GP.make_hp_class(theta=hv.theta, varK=hv.varK if GP.b_has_noisy_data else None,
+        hp_final = GP.make_hp_class(theta=hv.theta, kernel=hv.kernel, varK=hv.varK if GP.b_has_noisy_data else None,
                                     var_fval=hv.var_fval, var_fgrad=hv.var_fgrad)
         ln_here = GP.calc_lkd_all(hp_final)[0].ln_lkd
         # the same local optimum: objective equal to 1e-6 relative, log10(theta) to 1e-3
         assert abs(ln_here - ln_ref) <= 1e-6 * abs(ln_ref) + 1e-6, (it, ln_here, ln_ref)
         np.testing.assert_allclose(np.log10(hv.theta), np.log10(c[f"it{it}_theta"]), atol=2e-3)
+        if GP.kernel_has_hp:      # RatQu: alpha is optimised too (here with central differences of the device likelihood)
+            np.testing.assert_allclose(np.log10(hv.kernel), np.log10(c[f"it{it}_kernel"]), atol=2e-3)
         assert np.isclose(hv.varK, c[f"it{it}_varK"], rtol=5e-3)
         assert np.isclose(hv.beta[0], c[f"it{it}_beta"][0], rtol=1e-3, atol=1e-6 * max(1.0, abs(c[f"it{it}_beta"][0])))
         assert GP.hp_optz_success[it] == c[f"it{it}_success"]
