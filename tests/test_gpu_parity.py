@@ -105,9 +105,14 @@ def test_golden_case(path):
     mu, sig = GP.eval_model(c["xq"])[:2]
     np.testing.assert_allclose(mu, c["mu"], rtol=tol.MU_RTOL, atol=tol.MU_ATOL_SCALE * max(1.0, np.abs(c["mu"]).max()))
     np.testing.assert_allclose(sig, c["sig"], rtol=tol.SIG_RTOL, atol=tol.SIG_ATOL_SCALE * np.sqrt(hp2.varK))
-    if c["kernel"] == "RatQu":            # value + posterior mean / std only
+    if c["kernel"] == "RatQu":            # no d/dx kernels: central differences of the device posterior
+        mu_g, sig_g, dmudx, dsigdx, h1, h2 = GP.eval_model(c["xq"], calc_grad=True)
+        assert h1 is None and h2 is None and np.allclose(mu_g, mu, rtol=1e-12)
+        scale = max(1.0, np.abs(c["dmudx"]).max())
+        np.testing.assert_allclose(dmudx, c["dmudx"], rtol=1e-4, atol=1e-5 * scale)
+        np.testing.assert_allclose(dsigdx, c["dsigdx"], rtol=1e-3, atol=1e-4 * max(1.0, np.abs(c["dsigdx"]).max()))
         with pytest.raises(NotImplementedError):
-            GP.eval_model(c["xq"], calc_grad=True)
+            GP.eval_model(c["xq"][0], calc_grad=True, calc_hess=True, squeeze_nx=True)
         return
     # posterior gradients (reference GpEvalModel.py:170-172, 319-354)
     mu_g, sig_g, dmudx, dsigdx, h1, h2 = GP.eval_model(c["xq"], calc_grad=True)
