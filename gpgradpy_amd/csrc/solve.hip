@@ -103,6 +103,15 @@ __global__ void alpha_kernel(const double* __restrict__ z, const double* __restr
   if (r < N) alpha[r] = z[r] * invp[r];
 }
 
+// Neumaier's compensated accumulation: s + comp carries the sum to ~eps |result| + eps^2 sum |terms|.  The mean
+// mu = beta + sum_c Wt[j, c] z[c] cancels by a factor ~kappa on ill-conditioned cases (|alpha| ~ kappa |mu|), so the
+// order of a plain summation shows up at eps kappa (measured 4e-8 .. 2e-7 at kappa = 7e9 depending on the slicing).
+__device__ __forceinline__ void kb_add(double& s, double& comp, double x) {
+  const double t = s + x;
+  comp += (fabs(s) >= fabs(x)) ? (s - t) + x : (x - t) + s;
+  s = t;
+}
+
 // phase 0: out[j] = beta + sum_c Wt[j, c] z[c] ; phase 1: out[j] = 1 - sum_c Wt[j, c]^2
 __global__ void __launch_bounds__(1024) predict_reduce_kernel(const double* __restrict__ Wt, int nxp, int N,
                                                               const double* __restrict__ z, double beta, int phase,
@@ -110,17 +119,18 @@ __global__ void __launch_bounds__(1024) predict_reduce_kernel(const double* __re
   __shared__ double sh[16][64];
   const int jl = threadIdx.x & 63, cg = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + jl;
-  double acc = 0.0;
+  double acc = 0.0, comp = 0.0;
   if (phase == 0) {
-    for (int c = cg; c < N; c += 16) acc += Wt[(size_t)c * nxp + j] * z[c];
+    for (int c = cg; c < N; c += 16) kb_add(acc, comp, Wt[(size_t)c * nxp + j] * z[c]);
   } else {
     for (int c = cg; c < N; c += 16) { double w = Wt[(size_t)c * nxp + j]; acc += w * w; }
   }
-  sh[cg][jl] = acc;
+  sh[cg][jl] = acc + comp;
   __syncthreads();
   if (cg == 0) {
-    double s = 0.0;
-    for (int q = 0; q < 16; ++q) s += sh[q][jl];
+    double s = 0.0, cs = 0.0;
+    for (int q = 0; q < 16; ++q) kb_add(s, cs, sh[q][jl]);
+    s += cs;
     out[j] = phase == 0 ? beta + s : 1.0 - s;
   }
 }
@@ -135,18 +145,18 @@ __global__ void __launch_bounds__(1024) predict_partial_kernel(const double* __r
   const int jl = threadIdx.x & 63, cg = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + jl;
   const int c0 = blockIdx.y * chunk, c1 = min(N, c0 + chunk);
-  double acc = 0.0;
+  double acc = 0.0, comp = 0.0;
   if (phase == 0) {
-    for (int c = c0 + cg; c < c1; c += 16) acc += Wt[(size_t)c * nxp + j] * z[c];
+    for (int c = c0 + cg; c < c1; c += 16) kb_add(acc, comp, Wt[(size_t)c * nxp + j] * z[c]);
   } else {
     for (int c = c0 + cg; c < c1; c += 16) { double w = Wt[(size_t)c * nxp + j]; acc += w * w; }
   }
-  sh[cg][jl] = acc;
+  sh[cg][jl] = acc + comp;
   __syncthreads();
   if (cg == 0) {
-    double s = 0.0;
-    for (int q = 0; q < 16; ++q) s += sh[q][jl];
-    partial[(size_t)blockIdx.y * nxp + j] = s;
+    double s = 0.0, cs = 0.0;
+    for (int q = 0; q < 16; ++q) kb_add(s, cs, sh[q][jl]);
+    partial[(size_t)blockIdx.y * nxp + j] = s + cs;
   }
 }
 
@@ -155,13 +165,14 @@ __global__ void __launch_bounds__(1024) predict_final_kernel(const double* __res
   __shared__ double sh[16][64];
   const int jl = threadIdx.x & 63, cg = threadIdx.x >> 6;
   const int j = blockIdx.x * 64 + jl;
-  double acc = 0.0;
-  for (int q = cg; q < S; q += 16) acc += partial[(size_t)q * nxp + j];
-  sh[cg][jl] = acc;
+  double acc = 0.0, comp = 0.0;
+  for (int q = cg; q < S; q += 16) kb_add(acc, comp, partial[(size_t)q * nxp + j]);
+  sh[cg][jl] = acc + comp;
   __syncthreads();
   if (cg == 0) {
-    double s = 0.0;
-    for (int q = 0; q < 16; ++q) s += sh[q][jl];
+    double s = 0.0, cs = 0.0;
+    for (int q = 0; q < 16; ++q) kb_add(s, cs, sh[q][jl]);
+    s += cs;
     out[j] = phase == 0 ? beta + s : 1.0 - s;
   }
 }
