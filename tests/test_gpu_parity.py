@@ -499,3 +499,46 @@ def test_full_size_properties():
     GP2.set_data(X[perm], f[perm], np.zeros(n), g[perm], np.zeros((n, d)))
     ln_p = GP2.calc_lkd_batch(hp_x0[1:2])
     assert np.isclose(ln_p[0], ln[1], rtol=tol.LN_LKD_RTOL)
+
+
+def test_cfg5_size_properties():
+    """BASELINE cfg5 size (n=4000, d=16, Matern 5/2, known noise, N=68000, 37 GB workspace): no oracle finishes here, so
+    (1) theta -> large decouples the points: the factorised matrix is varK (1 + eta) I, ln det and the GLS mean are
+        analytic;
+    (2) the dataflow and the blocked schedule (independent kernels) agree at real hyperparameters;
+    (3) permuting the data points leaves ln_lkd unchanged to rounding * kappa."""
+    import gpgradpy_amd
+    import bench
+    n, d = 4000, 16
+    X, f, g, tab = bench.make_workload(n, d, "cfg5")
+    std_f, std_g = np.full(n, 1e-2), np.full((n, d), 1e-1)
+    GP = gpgradpy_amd.GaussianProcess(d, True, 'Ma5f2', 'precon')
+    GP.set_data(X, f, std_f, g, std_g)
+    N = n * (d + 1)
+    varK = 2.5
+    theta_big = np.full(d, 1e8)
+    info, ok = GP.calc_lkd_all(GP.make_hp_class(theta=theta_big, varK=varK))
+    assert ok
+    eta = GP._etaK
+    p2 = np.concatenate((1.0 + std_f ** 2 / varK, ((5.0 / 3.0) * theta_big[:, None] + (std_g.T ** 2) / varK).ravel()))   # diag(Kw)
+    ln_det_exact = N * np.log(varK * (1.0 + eta)) + np.sum(np.log(p2))
+    assert abs(info.ln_det_Kmat - ln_det_exact) <= 1e-9 * N
+    w = 1.0 / p2[:n]                                           # GLS mean of a diagonal covariance: weights 1 / p_i^2
+    assert np.isclose(info.hp_beta[0], np.sum(w * f) / np.sum(w), rtol=1e-10)
+
+    row = tab[0]
+    hp = GP.hp_vec2dataclass(GP.hp_info_optz_lkd, row)
+    ln_df = GP.calc_lkd_all(hp)[0].ln_lkd
+    assert GP.last_factor() == ('tile128', 1)
+    GP.set_factor_mode('blocked')
+    ln_bl = GP.calc_lkd_all(hp)[0].ln_lkd
+    assert GP.last_factor()[0] == 'blocked'
+    assert np.isclose(ln_df, ln_bl, rtol=tol.LN_LKD_RTOL)
+    del GP
+
+    perm = np.random.default_rng(2).permutation(n)
+    GP2 = gpgradpy_amd.GaussianProcess(d, True, 'Ma5f2', 'precon')
+    GP2.set_data(X[perm], f[perm], std_f, g[perm], std_g)
+    ln_p = GP2.calc_lkd_all(GP2.hp_vec2dataclass(GP2.hp_info_optz_lkd, row))[0].ln_lkd
+    assert np.isclose(ln_p, ln_df, rtol=tol.LN_LKD_RTOL)
+
