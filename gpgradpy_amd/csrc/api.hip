@@ -264,6 +264,7 @@ static int gpg_lkd_once(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out) {
   GPG_HIP_OK(c, hipMemcpyAsync(c->h_info, c->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
   GPG_HIP_OK(c, hipGetLastError());
+  GPG_LAUNCH_OK(c);
   if (internal_failure(c, c->h_info, 1)) return -4;
   c->factor_valid = (c->h_info[0] == 0);
   c->eval_ready = false;
@@ -291,6 +292,7 @@ static int gpg_lkd_grad_once(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out, dou
   GPG_HIP_OK(c, hipMemcpyAsync(c->h_info, c->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
   GPG_HIP_OK(c, hipGetLastError());
+  GPG_LAUNCH_OK(c);
   if (internal_failure(c, c->h_info, 1)) return -4;
   c->eval_ready = false;
   c->factor_valid = (c->h_info[0] == 0);
@@ -307,6 +309,7 @@ static int gpg_lkd_grad_once(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out, dou
   GPG_HIP_OK(c, hipMemcpyAsync(h.data(), res, sizeof(double) * 2 * (c->d + 3), hipMemcpyDeviceToHost, c->stream));
   GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
   GPG_HIP_OK(c, hipGetLastError());
+  GPG_LAUNCH_OK(c);
   for (int k = 0; k < c->d + 3; ++k) { g_aa[k] = h[k]; g_inv[k] = h[c->d + 3 + k]; }
   return 0;
 }
@@ -432,6 +435,7 @@ static int gpg_lkd_batch_once(gpg_ctx* c, int m, const double* hp_rows, int row_
   GPG_HIP_OK(c, hipMemcpyAsync(c->h_info, c->info, sizeof(int) * m, hipMemcpyDeviceToHost, c->stream));
   GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
   GPG_HIP_OK(c, hipGetLastError());
+  GPG_LAUNCH_OK(c);
   if (internal_failure(c, c->h_info, m)) return -4;
   for (int i = 0; i < m; ++i) finish_lkd(c, &hps[i], c->h_scal + (size_t)8 * i, c->h_info[i], &out[i]);
   c->factor_valid = c->eval_ready = false;
@@ -452,6 +456,7 @@ static int gpg_setup_eval_once(gpg_ctx* c, const gpg_hp* hp, double beta, double
   GPG_HIP_OK(c, hipMemcpyAsync(c->h_info, c->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
   GPG_HIP_OK(c, hipGetLastError());
+  GPG_LAUNCH_OK(c);
   if (internal_failure(c, c->h_info, 1)) return -4;
   if (c->h_info[0] != 0) { c->factor_valid = false; return c->h_info[0]; }
   c->factor_valid = true;
@@ -462,6 +467,7 @@ static int gpg_setup_eval_once(gpg_ctx* c, const gpg_hp* hp, double beta, double
   }
   GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
   GPG_HIP_OK(c, hipGetLastError());
+  GPG_LAUNCH_OK(c);
   c->eval_ready = true;
   c->eval_beta = beta;
   c->eval_params = p;   // theta etc. for the cross kernel
@@ -574,6 +580,7 @@ static int predict_impl(gpg_ctx* c, int nx, const double* xq, double varK, doubl
   GPG_HIP_OK(c, hipMemcpyAsync(c->h_info, c->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
   GPG_HIP_OK(c, hipGetLastError());
+  GPG_LAUNCH_OK(c);
   if (solve_failure(c)) return -4;
   const double sigK = sqrt(varK);
   for (int j = 0; j < nx; ++j) {
@@ -623,6 +630,7 @@ static int predict_hess_once(gpg_ctx* c, const double* xq, double varK, double* 
   GPG_HIP_OK(c, hipMemcpyAsync(c->h_info, c->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
   GPG_HIP_OK(c, hipGetLastError());
+  GPG_LAUNCH_OK(c);
   if (solve_failure(c)) return -4;
   const double* H1 = h.data();
   const double* H2 = H1 + GPG_MAX_DIM * GPG_MAX_DIM;
@@ -660,6 +668,7 @@ int gpg_get_matrix(gpg_ctx* c, const gpg_hp* hp, int which, double* out) {
                                c->stream));
   GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
   GPG_HIP_OK(c, hipGetLastError());
+  GPG_LAUNCH_OK(c);
   return 0;
 }
 
@@ -679,6 +688,7 @@ int gpg_factor_apply(gpg_ctx* c, int op, const double* v, double* out) {
   GPG_HIP_OK(c, hipMemcpyAsync(c->h_info, c->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
   GPG_HIP_OK(c, hipGetLastError());
+  GPG_LAUNCH_OK(c);
   if (solve_failure(c)) return -4;
   return 0;
 }

@@ -522,7 +522,10 @@ const TileMap& get_tilemap(gpg_ctx* c, int Mt, int Nt, int skipT) {
   tm.n = (int)list.size();
   tm.dev = nullptr;
   if (tm.n > 0) {
-    (void)hipMalloc(&tm.dev, sizeof(int) * list.size());
+    if (!gpg_dev_alloc(c, &tm.dev, sizeof(int) * list.size())) {
+      static const TileMap none{nullptr, 0};     // nothing to launch; the API call reports the failure
+      return none;
+    }
     (void)hipMemcpy(tm.dev, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice);
   }
   return c->tilemaps.emplace(key, tm).first->second;

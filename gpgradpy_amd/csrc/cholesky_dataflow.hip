@@ -753,9 +753,23 @@ const TileMap& get_tile_tasks(gpg_ctx* c, int Mt, int Rt) {
   TileMap tm;
   tm.n = (int)list.size();
   tm.dev = nullptr;
-  (void)hipMalloc(&tm.dev, sizeof(int) * list.size());
+  if (!gpg_dev_alloc(c, &tm.dev, sizeof(int) * list.size())) {
+    static const TileMap none{nullptr, 0};       // nothing to launch; the API call reports the failure
+    return none;
+  }
   (void)hipMemcpy(tm.dev, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice);
   return c->tilemaps.emplace(key, tm).first->second;
+}
+
+// Completion flags of the dataflow launches (grown on demand); false: allocation failed, nothing may be launched.
+static bool ensure_tile_flags(gpg_ctx* c, size_t nflag) {
+  if (c->tile_flags_cap >= nflag && c->tile_flags) return true;
+  if (c->tile_flags) (void)hipFree(c->tile_flags);
+  c->tile_flags = nullptr;
+  c->tile_flags_cap = 0;
+  if (!gpg_dev_alloc(c, &c->tile_flags, sizeof(int) * nflag)) return false;
+  c->tile_flags_cap = nflag;
+  return true;
 }
 
 // Factor A[c0:, c0:] (and carry the rows below the matrix) with the dataflow kernel, on c->stream.
@@ -763,12 +777,9 @@ static void launch_tile_chol(gpg_ctx* c, int c0) {
   const int Mt = (c->Npad - c0) / 64, Rt = (c->ld - c0) / 64;
   if (Mt <= 0) return;
   const TileMap& tm = get_tile_tasks(c, Mt, Rt);
+  if (!tm.dev) return;
   const size_t nflag = (size_t)Mt * Rt + 1 + 4 * (size_t)Mt;   // tile flags, abort word, four piece flags per diagonal tile
-  if (c->tile_flags_cap < nflag) {
-    if (c->tile_flags) (void)hipFree(c->tile_flags);
-    (void)hipMalloc(&c->tile_flags, sizeof(int) * nflag);
-    c->tile_flags_cap = nflag;
-  }
+  if (!ensure_tile_flags(c, nflag)) return;
   (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
   const double m = (double)(c->Npad - c0);
   gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, m * m * m / 3.0);
@@ -794,18 +805,14 @@ static void launch_tile_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a_st
         for (int i = j; i < Rt; ++i) { list.push_back(i | (j << 16)); bof.push_back(b); }
     TileMap tm;
     tm.n = (int)list.size();
-    (void)hipMalloc(&tm.dev, sizeof(int) * 2 * list.size());
+    if (!gpg_dev_alloc(c, &tm.dev, sizeof(int) * 2 * list.size())) return;
     (void)hipMemcpy(tm.dev, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice);
     (void)hipMemcpy(tm.dev + list.size(), bof.data(), sizeof(int) * bof.size(), hipMemcpyHostToDevice);
     it = c->tilemaps.emplace(key, tm).first;
   }
   const TileMap& tm = it->second;
   const size_t per = (size_t)Mt * Rt + 1 + 4 * (size_t)Mt, nflag = per * B;
-  if (c->tile_flags_cap < nflag) {
-    if (c->tile_flags) (void)hipFree(c->tile_flags);
-    (void)hipMalloc(&c->tile_flags, sizeof(int) * nflag);
-    c->tile_flags_cap = nflag;
-  }
+  if (!ensure_tile_flags(c, nflag)) return;
   (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
   const double m = (double)c->Npad;
   gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, B * m * m * m / 3.0);
@@ -820,12 +827,9 @@ static void launch_tile_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a_st
 static void launch_tile128_chol(gpg_ctx* c) {
   const int Mt = c->Npad / 128, Rt = c->ld / 128;
   const TileMap& tm = get_tile_tasks(c, Mt, Rt);
+  if (!tm.dev) return;
   const size_t nflag = (size_t)Mt * Rt + 1 + 2 * Mt;   // tile flags, abort word, two early flags per diagonal tile
-  if (c->tile_flags_cap < nflag) {
-    if (c->tile_flags) (void)hipFree(c->tile_flags);
-    (void)hipMalloc(&c->tile_flags, sizeof(int) * nflag);
-    c->tile_flags_cap = nflag;
-  }
+  if (!ensure_tile_flags(c, nflag)) return;
   (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
   const double m = (double)c->Npad;
   gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, m * m * m / 3.0);
@@ -849,18 +853,14 @@ static void launch_tile128_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a
         for (int i = j; i < Rt; ++i) { list.push_back(i | (j << 16)); bof.push_back(b); }
     TileMap tm;
     tm.n = (int)list.size();
-    (void)hipMalloc(&tm.dev, sizeof(int) * 2 * list.size());
+    if (!gpg_dev_alloc(c, &tm.dev, sizeof(int) * 2 * list.size())) return;
     (void)hipMemcpy(tm.dev, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice);
     (void)hipMemcpy(tm.dev + list.size(), bof.data(), sizeof(int) * bof.size(), hipMemcpyHostToDevice);
     it = c->tilemaps.emplace(key, tm).first;
   }
   const TileMap& tm = it->second;
   const size_t per = (size_t)Mt * Rt + 1 + 2 * (size_t)Mt, nflag = per * B;
-  if (c->tile_flags_cap < nflag) {
-    if (c->tile_flags) (void)hipFree(c->tile_flags);
-    (void)hipMalloc(&c->tile_flags, sizeof(int) * nflag);
-    c->tile_flags_cap = nflag;
-  }
+  if (!ensure_tile_flags(c, nflag)) return;
   (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
   const double m = (double)c->Npad;
   gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, B * m * m * m / 3.0);
@@ -874,13 +874,11 @@ static void launch_tile128_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a
 // W (rows x Npad, rows a multiple of 64) <- W L^-T with the dataflow kernel; returns false if it does not apply.
 static bool launch_vec_solve(gpg_ctx* c, double* W, int ldw, int R, bool bwd) {
   const int Mt = c->Npad / 64;
-  if (c->tile_flags_cap < 1) {
-    (void)hipMalloc(&c->tile_flags, sizeof(int) * 64);
-    c->tile_flags_cap = 64;
-  }
-  if (c->vec_x_cols < c->Npad) {
+  if (!ensure_tile_flags(c, 64)) return false;
+  if (c->vec_x_cols < c->Npad || !c->vec_x) {
     if (c->vec_x) (void)hipFree(c->vec_x);
-    (void)hipMalloc(&c->vec_x, sizeof(double) * 4 * (size_t)c->Npad);
+    c->vec_x_cols = 0;
+    if (!gpg_dev_alloc(c, &c->vec_x, sizeof(double) * 4 * (size_t)c->Npad)) return false;
     c->vec_x_cols = c->Npad;
   }
   (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int), c->stream);                              // abort word
@@ -900,11 +898,7 @@ static bool launch_rows_bwd(gpg_ctx* c, double* Z, int ldz, int rows, int valid)
   const int Mt = c->Npad / 64, nrt = rows / 64;
   if ((long)Mt * nrt > 4096) return false;
   const size_t nflag = (size_t)Mt * nrt + 1;
-  if (c->tile_flags_cap < nflag) {
-    if (c->tile_flags) (void)hipFree(c->tile_flags);
-    (void)hipMalloc(&c->tile_flags, sizeof(int) * nflag);
-    c->tile_flags_cap = nflag;
-  }
+  if (!ensure_tile_flags(c, nflag)) return false;
   (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
   hipLaunchKernelGGL(rows_bwd_kernel, dim3(Mt * nrt), dim3(256), 0, c->stream, (const double*)c->A, c->ld, (const double*)c->dinv, Z,
                      ldz, Mt, nrt, valid < 0 ? rows : valid, c->tile_flags, c->tile_flags + (nflag - 1), c->info);
@@ -917,11 +911,7 @@ static bool launch_rows_fwd(gpg_ctx* c, double* W, int ldw, int rows, int valid)
   const int Mt = c->Npad / 64, nrt = rows / 64;
   if ((long)Mt * nrt > 4096) return false;             // many rows: the blocked sweep is throughput-bound, not latency-bound
   const size_t nflag = (size_t)Mt * nrt + 1;
-  if (c->tile_flags_cap < nflag) {
-    if (c->tile_flags) (void)hipFree(c->tile_flags);
-    (void)hipMalloc(&c->tile_flags, sizeof(int) * nflag);
-    c->tile_flags_cap = nflag;
-  }
+  if (!ensure_tile_flags(c, nflag)) return false;
   (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
   hipLaunchKernelGGL(rows_fwd_kernel, dim3(Mt * nrt), dim3(256), 0, c->stream, (const double*)c->A, c->ld, (const double*)c->dinv, W,
                      ldw, Mt, nrt, valid < 0 ? rows : valid, c->tile_flags, c->tile_flags + (nflag - 1), c->info);

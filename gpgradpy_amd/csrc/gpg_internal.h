@@ -47,6 +47,7 @@ struct gpg_ctx {
   size_t A_elems = 0;        // allocated size of A (doubles), sized for all gradients
   int panel_impl = 1;                // 1: fused panel_solve_kernel for B_p, 0: trsm64 + small gemm launches (A/B runs)
   int nb_outer = 256;   // panel width
+  bool launch_error = false;  // a launch helper could not allocate its scratch / task list: nothing was launched (checked by the API call)
   int factor_fallbacks = 0;   // times a dataflow launch timed out and the call was repeated with the blocked schedule
   int last_factor_kernel = 0; // schedule of the most recent factorisation launch: 0 blocked, 1 64-tile, 2 128-tile dataflow
   int last_factor_batch = 0;  // matrices it factorised
@@ -145,9 +146,32 @@ int gpg_grad_partial_blocks(const gpg_ctx* c);
 int gpg_factor_apply_dev(gpg_ctx* c, int op, double* v, double* out);       // (L L^T) v or (L L^T)^-1 v, device vectors [Npad]
 void gpg_launch_extract(gpg_ctx* c, int which);                          // dense_tmp <- sym / P L
 
+// Device allocation inside a launch helper (task lists, flags, carrier tiles): on failure the pointer stays null, the
+// context is marked and the helper returns WITHOUT launching; the API call reports it (GPG_LAUNCH_OK) instead of a
+// kernel dereferencing a null pointer.
+template <typename T>
+inline bool gpg_dev_alloc(gpg_ctx* c, T** p, size_t bytes) {
+  *p = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(p), bytes) == hipSuccess && *p != nullptr) return true;
+  (void)hipGetLastError();
+  *p = nullptr;
+  c->launch_error = true;
+  return false;
+}
+
 // profiling helpers
 void gpg_prof_begin(gpg_ctx* c, int cat, double work);
 void gpg_prof_end(gpg_ctx* c);
+
+#define GPG_LAUNCH_OK(c)                                                                 \
+  do {                                                                                   \
+    if ((c)->launch_error) {                                                             \
+      (c)->launch_error = false;                                                         \
+      (c)->factor_valid = (c)->eval_ready = false;                                       \
+      (c)->err = "out of device memory inside a launch helper (task list / flags / carrier tile)"; \
+      return -2;                                                                         \
+    }                                                                                    \
+  } while (0)
 
 #define GPG_HIP_OK(c, call)                                                              \
   do {                                                                                   \

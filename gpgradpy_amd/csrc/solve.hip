@@ -516,7 +516,7 @@ void gpg_backward_solve(gpg_ctx* c) {
   if (c->chol_impl != 0 || c->tail_cols != 0) {
     // the vector rides as row 0 of a zeroed 64-row tile through the dataflow backward solve (one launch instead of
     // 2 Npad / 64 dependent ones)
-    if (!c->vec_rows) (void)hipMalloc(&c->vec_rows, sizeof(double) * 64 * (size_t)c->vec_rows_cols);
+    if (!c->vec_rows) (void)gpg_dev_alloc(c, &c->vec_rows, sizeof(double) * 64 * (size_t)c->vec_rows_cols);
     if (c->vec_rows) {
       (void)hipMemsetAsync(c->vec_rows, 0, sizeof(double) * 64 * (size_t)Npad, c->stream);
       // right-hand side: the forward-solved RHS row 0 of the factorisation workspace (row Npad of A)
@@ -619,7 +619,7 @@ int gpg_factor_apply_dev(gpg_ctx* c, int op, double* v, double* out) {
     hipLaunchKernelGGL(trmv_n_kernel, dim3((Npad + 255) / 256), dim3(256), 0, c->stream, c->A, c->ld, Npad, out, v);  // v = L out
     return hipMemcpyAsync(out, v, sizeof(double) * Npad, hipMemcpyDeviceToDevice, c->stream) == hipSuccess ? 0 : -2;
   }
-  if (!c->vec_rows && hipMalloc(&c->vec_rows, sizeof(double) * 64 * (size_t)c->vec_rows_cols) != hipSuccess) return -2;
+  if (!c->vec_rows && !gpg_dev_alloc(c, &c->vec_rows, sizeof(double) * 64 * (size_t)c->vec_rows_cols)) return -2;
   (void)hipMemsetAsync(c->vec_rows, 0, sizeof(double) * 64 * (size_t)Npad, c->stream);
   (void)hipMemcpy2DAsync(c->vec_rows, 64 * sizeof(double), v, sizeof(double), sizeof(double), Npad, hipMemcpyDeviceToDevice,
                          c->stream);                                              // row 0 of the carrier <- v
