@@ -529,7 +529,6 @@ int gpg_predict(gpg_ctx* c, int nx, const double* xq, double varK, double* mu, d
 int gpg_predict_grad(gpg_ctx* c, int nx, const double* xq, double varK, double* mu, double* sig, double* sig2_raw,
                      double* dmudx, double* dsigdx) {
   if (c && (!dmudx || !dsigdx)) { c->err = "dmudx / dsigdx is NULL"; return -1; }
-  if (c && c->kernel == GPG_KERNEL_RATQU) { c->err = "posterior derivatives are not available for the RatQu kernel"; return -1; }
   return with_fallback(c, [&] { return predict_impl(c, nx, xq, varK, mu, sig, sig2_raw, dmudx, dsigdx); });
 }
 
@@ -605,7 +604,7 @@ static int predict_hess_once(gpg_ctx* c, const double* xq, double varK, double* 
 int gpg_predict_hess(gpg_ctx* c, const double* xq, double varK, double* mu, double* sig, double* dmudx, double* dsigdx,
                      double* d2mudx2, double* d2sigdx2) {
   if (c && (!d2mudx2 || !d2sigdx2 || !dmudx || !dsigdx)) { c->err = "Hessian / gradient output is NULL"; return -1; }
-  if (c && c->kernel == GPG_KERNEL_RATQU) { c->err = "posterior derivatives are not available for the RatQu kernel"; return -1; }
+  if (c && c->kernel == GPG_KERNEL_RATQU) { c->err = "posterior Hessians are not available for the RatQu kernel"; return -1; }
   return with_fallback(c, [&] { return predict_hess_once(c, xq, varK, mu, sig, dmudx, dsigdx, d2mudx2, d2sigdx2); });
 }
 

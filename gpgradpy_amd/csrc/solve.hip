@@ -237,6 +237,7 @@ __global__ void __launch_bounds__(256) cross_grad_kernel(AsmParams P, const doub
 #pragma unroll
   for (int k = 0; k < D; ++k) { xq[k] = Xq[(size_t)k * nxp + q]; th[k] = P.theta[k]; }
   const double sqrt5 = sqrt(5.0);
+  const double rq_const = 4.0 * (1.0 + 1.0 / P.hp_kernel);       // KernelRatQuad.py:529 (unused by the other kernels)
   for (int a = threadIdx.x; a < n; a += 256) {
     double R[D], E, M1 = 0.0;
     if (KERN == GPG_KERNEL_SQEXP) {
@@ -244,6 +245,13 @@ __global__ void __launch_bounds__(256) cross_grad_kernel(AsmParams P, const doub
 #pragma unroll
       for (int k = 0; k < D; ++k) { R[k] = Xt[(size_t)k * n + a] - xq[k]; s -= th[k] * (R[k] * R[k]); }
       E = exp(s);
+    } else if (KERN == GPG_KERNEL_RATQU) {       // KernelRatQuad.py:463-476: M1 = B^(-alpha-1), E <- B^(-alpha-2)
+      double s = 0.0;
+#pragma unroll
+      for (int k = 0; k < D; ++k) { R[k] = Xt[(size_t)k * n + a] - xq[k]; s += th[k] * (R[k] * R[k]); }
+      const double Bq = 1.0 + s / P.hp_kernel;
+      M1 = pow(Bq, -P.hp_kernel - 1.0);
+      E = pow(Bq, -P.hp_kernel - 2.0);
     } else {
       double s = 0.0;
 #pragma unroll
@@ -258,7 +266,8 @@ __global__ void __launch_bounds__(256) cross_grad_kernel(AsmParams P, const doub
       const double wa = zvec[a] * invp[a], ws = Z[(size_t)a * nxp + q] * invp[a];
 #pragma unroll
       for (int jp = 0; jp < D; ++jp) {
-        const double v = KERN == GPG_KERNEL_SQEXP ? ((2.0 * th[jp]) * R[jp]) * E : (th[jp] * R[jp]) * M1;
+        const double v = KERN == GPG_KERNEL_SQEXP ? ((2.0 * th[jp]) * R[jp]) * E
+                         : KERN == GPG_KERNEL_RATQU ? ((2.0 * th[jp]) * R[jp]) * M1 : (th[jp] * R[jp]) * M1;   // RatQu: :541
         g[jp] += v * wa;
         g[D + jp] += v * ws;
       }
@@ -275,6 +284,9 @@ __global__ void __launch_bounds__(256) cross_grad_kernel(AsmParams P, const doub
           if (KERN == GPG_KERNEL_SQEXP) {
             v = (i == jp) ? (2.0 * th[i] - (4.0 * (th[i] * th[i])) * (R[i] * R[i])) * E
                           : ((-4.0 * th[i]) * th[jp]) * ((R[i] * R[jp]) * E);
+          } else if (KERN == GPG_KERNEL_RATQU) {     // KernelRatQuad.py:544, 554
+            v = (i == jp) ? (2.0 * th[i]) * M1 - ((rq_const * (th[i] * th[i])) * (R[i] * R[i])) * E
+                          : (((((-rq_const) * th[i]) * th[jp]) * R[i]) * R[jp]) * E;
           } else {
             v = (i == jp) ? th[i] * M1 - (((25.0 / 3.0) * (th[i] * th[i])) * (R[i] * R[i])) * E
                           : (((((-(25.0 / 3.0)) * th[i]) * th[jp]) * R[i]) * R[jp]) * E;
@@ -566,6 +578,7 @@ void gpg_backward_rows(gpg_ctx* c, double* Z, int ldz, int nrhs, double* tbuf) {
 
 void gpg_launch_cross_grad(gpg_ctx* c, const AsmParams& p, int nx, int nxp, double* g1, double* g2) {
   if (p.kernel == GPG_KERNEL_SQEXP) launch_cross_grad_d<GPG_KERNEL_SQEXP>(c, p, nx, nxp, g1, g2);
+  else if (p.kernel == GPG_KERNEL_RATQU) launch_cross_grad_d<GPG_KERNEL_RATQU>(c, p, nx, nxp, g1, g2);
   else launch_cross_grad_d<GPG_KERNEL_MA5F2>(c, p, nx, nxp, g1, g2);
 }
 

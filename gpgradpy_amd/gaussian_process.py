@@ -626,28 +626,9 @@ class GaussianProcess(HparaOptz):
         """GpEvalModel.py:59-198: returns (mu, sig, dmudx, dsigdx, d2mudx2, d2sigdx2); the Hessians are
         evaluated one point per call, as in the reference (GpEvalModel.py:358,369)."""
         assert self.KernEta_chofac is not None, 'To evaluate the surr the Cholesky decomposition is required'
-        if calc_grad and self.kernel_type == 'RatQu':
-            # the d/dx kernels of RatQu (KernelRatQuad.py:82-437, 556-632) are not built: central differences of the
-            # device posterior, the 2 dim shifted copies of every query point ride in the same call
-            if calc_hess:
-                raise NotImplementedError("posterior Hessians are not available for kernel 'RatQu' (SURVEY.md 8f4)")
-            xq = np.atleast_2d(np.asarray(x2model_in, dtype=np.float64))
-            nx, dim, h = xq.shape[0], self.dim, 1e-3     # rounding of mu ~ eps |k||alpha| (kappa-amplified) against h^2 f'''/6
-            pts = [xq]
-            for k in range(dim):
-                e = np.zeros(dim)
-                e[k] = h
-                pts += [xq + e, xq - e]
-            mu_all, sig_all = self.eval_model(np.vstack(pts))[:2]
-            mu, sig = mu_all[:nx], sig_all[:nx]
-            dmudx, dsigdx = np.empty((nx, dim)), np.empty((nx, dim))
-            for k in range(dim):
-                lo = nx * (1 + 2 * k)
-                dmudx[:, k] = (mu_all[lo:lo + nx] - mu_all[lo + nx:lo + 2 * nx]) / (2 * h)
-                dsigdx[:, k] = (sig_all[lo:lo + nx] - sig_all[lo + nx:lo + 2 * nx]) / (2 * h)
-            if squeeze_nx:
-                return mu[0], sig[0], dmudx[0, :], dsigdx[0, :], None, None
-            return mu, sig, dmudx, dsigdx, None, None
+        if calc_hess and self.kernel_type == 'RatQu':
+            # the second / third derivative kernels of RatQu (KernelRatQuad.py:51-136, 556-632) are not built
+            raise NotImplementedError("posterior Hessians are not available for kernel 'RatQu' (SURVEY.md 8f4)")
         if calc_hess:
             assert calc_grad, 'To return the hessian calc_grad must also be set to True'      # GpEvalModel.py:126-127
             if self.bvec_use_grad is not None and not np.all(self.bvec_use_grad):

@@ -27,8 +27,8 @@ extern "C" {
 
 typedef struct gpg_ctx gpg_ctx;
 
-/* RatQu (KernelRatQuad.py:439-554): likelihood value and posterior mean / std only -- gpg_lkd_grad, gpg_predict_grad
- * and gpg_predict_hess return -1 for it (the host side differentiates gpg_lkd_batch numerically instead). */
+/* RatQu (KernelRatQuad.py:439-554): likelihood value, posterior mean / std and their first derivatives -- gpg_lkd_grad
+ * and gpg_predict_hess return -1 for it (the host side differentiates gpg_lkd_batch numerically for the former). */
 enum { GPG_KERNEL_SQEXP = 0, GPG_KERNEL_MA5F2 = 1, GPG_KERNEL_RATQU = 2 };
 enum { GPG_WELLCOND_BASE = 0, GPG_WELLCOND_PRECON = 1 };
 
