@@ -276,7 +276,6 @@ static int gpg_lkd_grad_once(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out, dou
   int rc = check_hp(c, hp);
   if (rc) return rc;
   if (!out || !g_aa || !g_inv) { c->err = "out / g_aa / g_inv is NULL"; return -1; }
-  if (c->kernel == GPG_KERNEL_RATQU) { c->err = "likelihood gradient is not available for the RatQu kernel"; return -1; }
   GPG_HIP_OK(c, hipSetDevice(c->device));
   const size_t nn = (size_t)c->Npad * c->Npad;
   if (!c->Wfull) {
@@ -284,7 +283,7 @@ static int gpg_lkd_grad_once(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out, dou
     GPG_HIP_OK(c, hipMalloc(&c->Minv, sizeof(double) * nn));
   }
   const int nblk = gpg_grad_partial_blocks(c);
-  const int nval = 2 * (GPG_MAX_DIM + 3);
+  const int nval = 2 * GPG_GRAD_SLOTS_MAX;
   if (!c->gpartial) GPG_HIP_OK(c, hipMalloc(&c->gpartial, sizeof(double) * (size_t)nval * (nblk + 1)));
   GPG_HIP_OK(c, hipMemsetAsync(c->info, 0, sizeof(int), c->stream));
   enqueue_lkd(c, hp, 0);                                   // factor + beta + r'K^-1 r + ln det (scal slot 0)
@@ -306,11 +305,13 @@ static int gpg_lkd_grad_once(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out, dou
   double* res = c->gpartial + (size_t)nval * nblk;
   gpg_launch_grad_contract(c, p, c->gpartial, res);
   std::vector<double> h(nval);
-  GPG_HIP_OK(c, hipMemcpyAsync(h.data(), res, sizeof(double) * 2 * (c->d + 3), hipMemcpyDeviceToHost, c->stream));
+  const int ns = c->d + 3 + (c->kernel == GPG_KERNEL_RATQU ? 1 : 0);
+  GPG_HIP_OK(c, hipMemcpyAsync(h.data(), res, sizeof(double) * 2 * ns, hipMemcpyDeviceToHost, c->stream));
   GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
   GPG_HIP_OK(c, hipGetLastError());
   GPG_LAUNCH_OK(c);
-  for (int k = 0; k < c->d + 3; ++k) { g_aa[k] = h[k]; g_inv[k] = h[c->d + 3 + k]; }
+  g_aa[c->d + 3] = g_inv[c->d + 3] = 0.0;                  // hp_kernel slot: RatQu only
+  for (int k = 0; k < ns; ++k) { g_aa[k] = h[k]; g_inv[k] = h[ns + k]; }
   return 0;
 }
 

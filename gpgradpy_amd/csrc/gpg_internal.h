@@ -7,6 +7,7 @@
 #include "../../include/gpgrad.h"
 
 #define GPG_MAX_DIM 16
+#define GPG_GRAD_SLOTS_MAX (GPG_MAX_DIM + 4)   // theta(d), varK, var_fval, var_fgrad, hp_kernel
 #define GPG_TILE 128      // padding / GEMM tile granularity
 #define GPG_NBI 64        // inner (diagonal block) width of the panel factorisation
 #define GPG_INFO_INTERNAL 0x7fffffff   // info value: dataflow factorisation aborted (dependency wait timed out)

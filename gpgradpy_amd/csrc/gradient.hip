@@ -46,7 +46,8 @@ __global__ void __launch_bounds__(256) grad_contract_kernel(AsmParams P, const d
                                                             const double* __restrict__ zvec,
                                                             const double* __restrict__ Minv, int ldm,
                                                             double* __restrict__ partial) {
-  constexpr int NS = D + 3;                 // theta_0..D-1, varK, var_fval, var_fgrad
+  constexpr int RQ = KERN == GPG_KERNEL_RATQU ? 1 : 0;
+  constexpr int NS = D + 3 + RQ;            // theta_0..D-1, varK, var_fval, var_fgrad (, alpha of RatQu)
   __shared__ double xb[kTBg][D];
   __shared__ double ipb[kTBg][D + 1];
   __shared__ double alb[kTBg][D + 1];
@@ -98,19 +99,37 @@ __global__ void __launch_bounds__(256) grad_contract_kernel(AsmParams P, const d
     const int precon = P.precon;
     const int bend = min(kTBg, n - b0);
     const double sqrt5 = sqrt(5.0);
+    const double rq_alpha = P.hp_kernel, rq_s1 = 1.0 + 1.0 / P.hp_kernel, rq_s2 = rq_s1 * (1.0 + 2.0 / P.hp_kernel);   // scalar1, scalar2 (:704-705)
+    const double rq_c = 4.0 * rq_s1, rq_dc = 4.0 / (P.hp_kernel * P.hp_kernel);          // const (:529) and -d const / d alpha
 
     for (int bb = 0; bb < bend; ++bb) {
       const int b = b0 + bb;
       if (b > a) continue;                                   // lower triangle of point pairs only ...
       const bool diag_pt = (a == b);
       const int gpbb = gpb[bb];
-      double R[D], E, M1 = 0.0, inu = 0.0, K00;
+      double R[D], E, M1 = 0.0, inu = 0.0, K00, F3 = 0.0, G0 = 0.0, G1 = 0.0, G2 = 0.0;
       if (KERN == GPG_KERNEL_SQEXP) {
         double s = 0.0;
 #pragma unroll
         for (int k = 0; k < D; ++k) { R[k] = xa[k] - xb[bb][k]; s -= th[k] * (R[k] * R[k]); }
         E = exp(s);
         K00 = E;
+      } else if (KERN == GPG_KERNEL_RATQU) {
+        // KernelRatQuad.py:656-667, 770-790: f_p = B^(-alpha-p), B = 1 + sum theta R^2 / alpha;
+        //   d f_p / d theta_k = -(1 + p/alpha) R_k^2 f_(p+1),   d f_p / d alpha = f_p g_p,
+        //   g_p = -ln B + (1 + p/alpha) (1 - 1/B)
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) { R[k] = xa[k] - xb[bb][k]; s += th[k] * (R[k] * R[k]); }
+        const double Bq = 1.0 + s / rq_alpha;
+        K00 = pow(Bq, -rq_alpha);
+        M1 = pow(Bq, -rq_alpha - 1.0);          // f_1
+        E = pow(Bq, -rq_alpha - 2.0);           // f_2
+        F3 = pow(Bq, -rq_alpha - 3.0);          // f_3
+        const double lnB = log(Bq), om = 1.0 - 1.0 / Bq;
+        G0 = -lnB + om;
+        G1 = -lnB + (1.0 + 1.0 / rq_alpha) * om;
+        G2 = -lnB + (1.0 + 2.0 / rq_alpha) * om;
       } else {
         double s = 0.0;
 #pragma unroll
@@ -122,7 +141,7 @@ __global__ void __launch_bounds__(256) grad_contract_kernel(AsmParams P, const d
         inu = 1.0 / fmax(nu, 1e-16);                         // KernelMatern5f2.py:592
       }
       // one matrix entry (I, J) at the point pair (a, b): value v, d v / d theta_k in dv[k]
-      auto contract = [&](int I, int J, double v, const double (&dv)[D], double wgt) {
+      auto contract = [&](int I, int J, double v, const double (&dv)[D], double wgt, double da = 0.0) {
         const size_t r = I == 0 ? (size_t)a : (size_t)n + (size_t)(I - 1) * ng + gpa;
         const size_t c = J == 0 ? (size_t)b : (size_t)n + (size_t)(J - 1) * ng + gpbb;
         const size_t rr = r >= c ? r : c, cc = r >= c ? c : r;            // Minv holds the lower triangle
@@ -135,6 +154,11 @@ __global__ void __launch_bounds__(256) grad_contract_kernel(AsmParams P, const d
           const double g = vK * dv[k] * dscale;                           // GpHparaGrad.py:39-51 / :100-111
           ga[k] += g * laa;
           gi[k] += g * lin;
+        }
+        if (RQ) {                                                         // d / d alpha (GpHparaGrad.py:53-66 / :113-126)
+          const double g = vK * da * dscale;
+          ga[NS - 1] += g * laa;
+          gi[NS - 1] += g * lin;
         }
         // d/d varK : Kern + eta diag(Kern) (precon) or Kern + eta I (base)   GpHparaGrad.py:128-137
         const double gv = dg ? (precon ? v * (1.0 + eta) : v + eta) : v;
@@ -151,17 +175,24 @@ __global__ void __launch_bounds__(256) grad_contract_kernel(AsmParams P, const d
       // ---- block (0, 0)
 #pragma unroll
       for (int k = 0; k < D; ++k)
-        dv[k] = KERN == GPG_KERNEL_SQEXP ? -(R[k] * R[k]) * E : -0.5 * ((R[k] * R[k]) * M1);
-      contract(0, 0, K00, dv, diag_pt ? 1.0 : 2.0);
+        dv[k] = KERN == GPG_KERNEL_SQEXP ? -(R[k] * R[k]) * E
+              : KERN == GPG_KERNEL_RATQU ? -(R[k] * R[k]) * M1 : -0.5 * ((R[k] * R[k]) * M1);
+      contract(0, 0, K00, dv, diag_pt ? 1.0 : 2.0, K00 * G0);
       if (nblk > 1) {
 #pragma unroll
         for (int i = 0; i < D; ++i) {
           // ---- block (i+1, 0) at (a, b)  and, for a != b, block (i+1, 0) at (b, a) = -value (R -> -R)
-          double v;
+          double v, dav = 0.0;
           if (KERN == GPG_KERNEL_SQEXP) {
             v = ((-2.0 * th[i]) * R[i]) * E;
 #pragma unroll
             for (int k = 0; k < D; ++k) dv[k] = -(R[k] * R[k]) * v + (k == i ? -2.0 * R[i] * E : 0.0);
+          } else if (KERN == GPG_KERNEL_RATQU) {
+            v = ((-2.0 * th[i]) * R[i]) * M1;
+#pragma unroll
+            for (int k = 0; k < D; ++k)
+              dv[k] = (2.0 * rq_s1) * th[i] * R[i] * (R[k] * R[k]) * E + (k == i ? -2.0 * R[i] * M1 : 0.0);   // :712-722
+            dav = v * G1;
           } else {
             v = ((-th[i]) * R[i]) * M1;
 #pragma unroll
@@ -170,7 +201,7 @@ __global__ void __launch_bounds__(256) grad_contract_kernel(AsmParams P, const d
           }
           // entry (row (i+1, a), col (0, b)) and its mirror (row (i+1, b), col (0, a)) carry opposite signs;
           // each is an off-diagonal matrix entry (weight 2 for the symmetric pair)
-          if (gpa >= 0) contract(i + 1, 0, v, dv, 2.0);
+          if (gpa >= 0) contract(i + 1, 0, v, dv, 2.0, dav);
           if (!diag_pt && gpbb >= 0) {
             // mirror: swap the roles of a and b.  value and derivative change sign; alpha / invp / Minv
             // indices are those of row (i+1, b), column (0, a)
@@ -183,6 +214,11 @@ __global__ void __launch_bounds__(256) grad_contract_kernel(AsmParams P, const d
               ga[k] += g * laa;
               gi[k] += g * lin;
             }
+            if (RQ) {
+              const double g = vK * (-dav);
+              ga[NS - 1] += g * laa;
+              gi[NS - 1] += g * lin;
+            }
             ga[D] += (-v) * laa;
             gi[D] += (-v) * lin;
           }
@@ -191,8 +227,26 @@ __global__ void __launch_bounds__(256) grad_contract_kernel(AsmParams P, const d
 #pragma unroll
             for (int j = 0; j < D; ++j) {
               if (j > i) continue;
-              double w;
-              if (KERN == GPG_KERNEL_SQEXP) {
+              double w, daw = 0.0;
+              if (KERN == GPG_KERNEL_RATQU) {
+                if (i == j) {                                             // KernelRatQuad.py:544 / :709,729-736 / :820-830
+                  w = (2.0 * th[i]) * M1 - ((rq_c * (th[i] * th[i])) * (R[i] * R[i])) * E;
+#pragma unroll
+                  for (int k = 0; k < D; ++k)
+                    dv[k] = -(2.0 * rq_s1) * th[i] * (R[k] * R[k]) * E +
+                            (4.0 * rq_s2) * (th[i] * th[i]) * (R[i] * R[i]) * (R[k] * R[k]) * F3 +
+                            (k == i ? 2.0 * M1 - (8.0 * rq_s1) * th[i] * (R[i] * R[i]) * E : 0.0);
+                  daw = (2.0 * th[i]) * M1 * G1 + (rq_dc - rq_c * G2) * (th[i] * th[i]) * (R[i] * R[i]) * E;
+                } else {                                                  // :554 / :724-727,738-743
+                  w = (((((-rq_c) * th[j]) * th[i]) * R[j]) * R[i]) * E;
+#pragma unroll
+                  for (int k = 0; k < D; ++k)
+                    dv[k] = (4.0 * rq_s2) * th[i] * th[j] * (R[i] * R[j]) * (R[k] * R[k]) * F3 +
+                            (k == i ? -(4.0 * rq_s1) * th[j] * (R[i] * R[j]) * E : 0.0) +
+                            (k == j ? -(4.0 * rq_s1) * th[i] * (R[i] * R[j]) * E : 0.0);
+                  daw = (rq_dc - rq_c * G2) * th[i] * th[j] * (R[i] * R[j]) * E;
+                }
+              } else if (KERN == GPG_KERNEL_SQEXP) {
                 if (i == j) {
                   w = (2.0 * th[i] - (4.0 * (th[i] * th[i])) * (R[i] * R[i])) * E;
 #pragma unroll
@@ -225,9 +279,9 @@ __global__ void __launch_bounds__(256) grad_contract_kernel(AsmParams P, const d
               // matrix entries of this (a, b, i, j) orbit: (i+1,a ; j+1,b), (j+1,a ; i+1,b) and their two
               // transposes.  Blocks are symmetric in (a, b), so every distinct entry has the same value.
               if (i == j) {
-                contract(i + 1, i + 1, w, dv, diag_pt ? 1.0 : 2.0);
+                contract(i + 1, i + 1, w, dv, diag_pt ? 1.0 : 2.0, daw);
               } else {
-                contract(i + 1, j + 1, w, dv, 2.0);                      // (i+1,a ; j+1,b) + transpose
+                contract(i + 1, j + 1, w, dv, 2.0, daw);                 // (i+1,a ; j+1,b) + transpose
                 if (!diag_pt) {                                          // (j+1,a ; i+1,b) + transpose
                   const size_t r = (size_t)n + (size_t)i * ng + gpbb, c = (size_t)n + (size_t)j * ng + gpa;
                   const double laa = 2.0 * (alb[bb][i + 1] * ala[j + 1]);
@@ -237,6 +291,11 @@ __global__ void __launch_bounds__(256) grad_contract_kernel(AsmParams P, const d
                     const double g = vK * dv[k];
                     ga[k] += g * laa;
                     gi[k] += g * lin;
+                  }
+                  if (RQ) {
+                    const double g = vK * daw;
+                    ga[NS - 1] += g * laa;
+                    gi[NS - 1] += g * lin;
                   }
                   ga[D] += w * laa;
                   gi[D] += w * lin;
@@ -258,7 +317,7 @@ __global__ void __launch_bounds__(256) grad_contract_kernel(AsmParams P, const d
   __syncthreads();
   if (threadIdx.x < 2 * NS) {
     const double s = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
-    partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (2 * (GPG_MAX_DIM + 3)) + threadIdx.x] = s;
+    partial[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (2 * GPG_GRAD_SLOTS_MAX) + threadIdx.x] = s;
   }
 }
 
@@ -267,7 +326,7 @@ __global__ void grad_final_reduce_kernel(const double* __restrict__ partial, int
   const int k = threadIdx.x;
   if (k >= nvals) return;
   double s = 0.0;
-  for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * (2 * (GPG_MAX_DIM + 3)) + k];
+  for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * (2 * GPG_GRAD_SLOTS_MAX) + k];
   out[k] = s;
 }
 
@@ -297,13 +356,15 @@ void gpg_launch_identity(gpg_ctx* c, double* W, int ldw) {
   hipLaunchKernelGGL(set_identity_kernel, dim3((c->Npad + 255) / 256), dim3(256), 0, c->stream, W, ldw, c->Npad);
 }
 
-// out_dev[0 .. d+3) = g_aa, out_dev[d+3 .. 2(d+3)) = g_inv
+// out_dev[0 .. ns) = g_aa, out_dev[ns .. 2 ns) = g_inv, ns = d + 3 (+ 1 for RatQu: alpha last)
 void gpg_launch_grad_contract(gpg_ctx* c, const AsmParams& p, double* partial, double* out_dev) {
   dim3 grid((p.n + 255) / 256, (p.n + kTBg - 1) / kTBg);
   if (p.kernel == GPG_KERNEL_SQEXP) launch_contract_d<GPG_KERNEL_SQEXP>(c, p, partial, grid);
+  else if (p.kernel == GPG_KERNEL_RATQU) launch_contract_d<GPG_KERNEL_RATQU>(c, p, partial, grid);
   else launch_contract_d<GPG_KERNEL_MA5F2>(c, p, partial, grid);
+  const int ns = p.d + 3 + (p.kernel == GPG_KERNEL_RATQU ? 1 : 0);
   hipLaunchKernelGGL(grad_final_reduce_kernel, dim3(1), dim3(64), 0, c->stream, partial, (int)(grid.x * grid.y),
-                     2 * (p.d + 3), out_dev);
+                     2 * ns, out_dev);
 }
 
 int gpg_grad_partial_blocks(const gpg_ctx* c) { return ((c->n + 255) / 256) * ((c->n + kTBg - 1) / kTBg); }

@@ -443,17 +443,6 @@ class GaussianProcess(HparaOptz):
     # ---- likelihood ------------------------------------------------------------------------------------
     def calc_lkd_all(self, hp_vals, calc_lkd=True, calc_cond=False, calc_grad=False, lkd_use_adj_mtd=None):
         """One marginal-log-likelihood evaluation -- reference CalcLkd.py:270-346 (value path)."""
-        if calc_grad and self.kernel_type == 'RatQu':
-            # the derivative kernels of RatQu (KernelRatQuad.py:636-843) are not built: central differences of the
-            # device likelihood, all 2 n_hp evaluations in one batched call
-            if calc_cond:
-                raise NotImplementedError('the gradient of the condition number (GpHparaCon.py:163-261) is outside the accelerated path')
-            info, ok = self.calc_lkd_all(hp_vals, calc_lkd=True, calc_cond=calc_cond, calc_grad=False)
-            if ok:
-                info.ln_lkd_grad = self._lkd_grad_central_differences(hp_vals)
-                if not calc_lkd:
-                    info.ln_lkd = None
-            return info, ok
         if calc_grad and self.bvec_use_grad is not None and not np.all(self.bvec_use_grad):
             # the reference itself fails here (shape bug KernelSqExp.py:552-554, SURVEY.md section 4): nothing to pin against
             raise NotImplementedError('likelihood gradient with a bvec_use_grad mask is not supported')
@@ -472,7 +461,7 @@ class GaussianProcess(HparaOptz):
         out = _lib.GpgLkdOut()
         t0 = time.time()
         if calc_grad:
-            g_aa, g_inv = np.zeros(self.dim + 3), np.zeros(self.dim + 3)
+            g_aa, g_inv = np.zeros(self.dim + 4), np.zeros(self.dim + 4)     # slots: theta(d), varK, var_fval, var_fgrad, hp_kernel
             rc = self._lib.gpg_lkd_grad(self._ctx, C.byref(hp), C.byref(out), _lib.as_dp(g_aa), _lib.as_dp(g_inv))
         else:
             rc = self._lib.gpg_lkd(self._ctx, C.byref(hp), C.byref(out))
@@ -505,6 +494,8 @@ class GaussianProcess(HparaOptz):
             hi, d = self.hp_info_optz_lkd, self.dim
             ln_lkd_grad = np.zeros(hi.n_hp)
             ln_lkd_grad[hi.idx_theta] = g_all[:d]
+            if hi.has_kernel:
+                ln_lkd_grad[hi.idx_kernel] = g_all[d + 3]
             if hi.has_varK:
                 ln_lkd_grad[hi.idx_varK] = g_all[d]
             if hi.has_var_fval:
@@ -731,7 +722,7 @@ class GaussianProcess(HparaOptz):
         """d ln_lkd / d hp_k for the optimised hyperparameters (hp_info_optz_lkd order, derivatives with respect to the
         hyperparameter VALUES like CalcLkd.py:170-177, not their log10) by central differences of the device likelihood;
         the closed-form varK of the noise-free path is re-evaluated in every term, i.e. this is the total derivative the
-        reference's adjoint formula gives.  Used where no derivative kernel is built (kernel 'RatQu')."""
+        reference's adjoint formula gives.  Diagnostic cross-check of the adjoint gradient (tests); not on any product path."""
         hi = self.hp_info_optz_lkd
         x = np.zeros(hi.n_hp)
         x[hi.idx_theta] = hp_vals.theta

@@ -27,8 +27,7 @@ extern "C" {
 
 typedef struct gpg_ctx gpg_ctx;
 
-/* RatQu (KernelRatQuad.py:439-554): likelihood value, posterior mean / std and their first derivatives -- gpg_lkd_grad
- * and gpg_predict_hess return -1 for it (the host side differentiates gpg_lkd_batch numerically for the former). */
+/* RatQu (KernelRatQuad.py:439-554, 636-843): everything except the posterior Hessians -- gpg_predict_hess returns -1. */
 enum { GPG_KERNEL_SQEXP = 0, GPG_KERNEL_MA5F2 = 1, GPG_KERNEL_RATQU = 2 };
 enum { GPG_WELLCOND_BASE = 0, GPG_WELLCOND_PRECON = 1 };
 
@@ -92,7 +91,9 @@ int gpg_lkd(gpg_ctx* ctx, const gpg_hp* hp, gpg_lkd_out* out);
 
 /* Replaces CalcLkd.calc_lkd_all(hp, calc_grad=True) with the adjoint method (CalcLkd.py:170-177, 230-235;
  * kernel derivatives GpHparaGrad.py:13-155, KernelSqExp.py:470-568, KernelMatern5f2.py:532-642).
- * out as gpg_lkd.  For hyperparameter slot k in [0, dim+3) = theta_0..theta_(dim-1), varK, var_fval, var_fgrad:
+ * out as gpg_lkd.  g_aa, g_inv hold dim + 4 entries: hyperparameter slot k = theta_0..theta_(dim-1), varK, var_fval,
+ * var_fgrad, hp_kernel (the last one zero unless the kernel has a hyperparameter of its own: alpha of GPG_KERNEL_RATQU,
+ * KernelRatQuad.py:752-843):
  *   g_aa[k]  = sum_{r,c} G_k[r,c] alpha_r alpha_c,    g_inv[k] = sum_{r,c} G_k[r,c] (-1/2 Kcov^-1)[r,c],
  * G_k = d Kcov / d hp_k, alpha = Kcov^-1 (y - V beta).  The caller forms ln_lkd_grad = s g_aa + g_inv with
  * s = 1/2 (noisy, CalcLkd.py:233) or pnlt'/N + 1/(2 varK) (noise-free, CalcLkd.py:173-175).  Neither the

@@ -288,7 +288,7 @@ def calc_lkd_grad(X, y, theta, kernel, use_grad, wellcond, etaK, std_f, std_g, n
     """d ln_lkd / d hp by the adjoint formula of the reference (CalcLkd.py:170-177 noise-free, :230-235 noisy)
     with the derivative tensor d Kcov / d hp_k (GpHparaGrad.py:13-155) replaced by central differences of the
     covariance matrix itself (rel. step 1e-6: truncation ~1e-12, rounding ~1e-10 relative per entry).
-    Returns the vector ordered [theta(d), varK?, var_fval?, var_fgrad?] like HparaOptzInfo."""
+    Returns the vector ordered [theta(d), alpha? (RatQu), varK?, var_fval?, var_fgrad?] like HparaOptzInfo."""
     n, d = X.shape
     nv = lambda vf=var_fval, vg=var_fgrad: calc_noise_vec(n, d, use_grad, std_f, std_g, vf, vg)
     vK = varK if noisy else 1.0
@@ -308,6 +308,12 @@ def calc_lkd_grad(X, y, theta, kernel, use_grad, wellcond, etaK, std_f, std_g, n
         tm[k] -= h
         G = dcov(_kcov_only(X, tp, kernel, use_grad, wellcond, etaK, n, d, nv, vK),
                  _kcov_only(X, tm, kernel, use_grad, wellcond, etaK, n, d, nv, vK), h)
+        out.append(np.sum(G * Lam))
+    kname, alpha = _kern_split(kernel)
+    if kname == "RatQu":                       # the kernel's own hyperparameter sits between theta and varK (GpHparaOptz.py:90-96)
+        h = rel_step * alpha
+        G = dcov(_kcov_only(X, theta, (kname, alpha + h), use_grad, wellcond, etaK, n, d, nv, vK),
+                 _kcov_only(X, theta, (kname, alpha - h), use_grad, wellcond, etaK, n, d, nv, vK), h)
         out.append(np.sum(G * Lam))
     if noisy:
         h = rel_step * varK

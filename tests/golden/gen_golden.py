@@ -138,7 +138,7 @@ def make_case(GaussianProcess, name, n, d, kernel, noise, use_grad=True, wellcon
     if not ok:
         return out
 
-    if not mask and kernel != 'RatQu':        # (RatQu: value path only in the build)
+    if not mask:
         lkd_g, ok_g = GP.calc_lkd_all(hp, calc_lkd=True, calc_cond=False, calc_grad=True)
         out['ln_lkd_grad'] = np.asarray(lkd_g.ln_lkd_grad, dtype=float)
     out.update(hp_beta=np.asarray(lkd.hp_beta, dtype=float),

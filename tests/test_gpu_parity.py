@@ -75,9 +75,6 @@ def test_golden_case(path):
         assert info_g.ln_lkd_grad.shape == c["ln_lkd_grad"].shape
         cond = np.linalg.cond(c["Kcov"]) if "Kcov" in c else _oracle_cond(c)
         tol.check_lkd_grad(info_g.ln_lkd_grad, c["ln_lkd_grad"], tol.lkd_grad_slots_to_check(c), cond=cond)
-    elif c["kernel"] == "RatQu":          # central differences of the device likelihood: shape / finiteness here,
-        g = GP.calc_lkd_all(hp, calc_grad=True)[0].ln_lkd_grad        # values in test_ratqu_against_oracle_and_batched_rows
-        assert g.shape == (GP.hp_info_optz_lkd.n_hp,) and np.all(np.isfinite(g))
     else:
         with pytest.raises(NotImplementedError):
             GP.calc_lkd_all(hp, calc_grad=True)
@@ -380,10 +377,12 @@ def test_ratqu_against_oracle_and_batched_rows():
     mu_o, sig_o = orc.eval_model(m, xq)
     np.testing.assert_allclose(mu, mu_o, rtol=tol.MU_RTOL, atol=tol.MU_ATOL_SCALE * max(1.0, np.abs(mu_o).max()))
     np.testing.assert_allclose(sig, sig_o, rtol=tol.SIG_RTOL, atol=tol.SIG_ATOL_SCALE * np.sqrt(hp2.varK))
-    # likelihood gradient of RatQu: central differences of the device likelihood (no derivative kernel is built) against
-    # central differences of the oracle, entries [theta (d), alpha]
+    # adjoint likelihood gradient of RatQu, entries [theta (d), alpha], against central differences of the oracle's and
+    # of the device's own likelihood
     g = GP.calc_lkd_all(hp, calc_grad=True)[0].ln_lkd_grad
     assert g.shape == (d + 1,)
+    g_fd = GP._lkd_grad_central_differences(hp)
+    np.testing.assert_allclose(g, g_fd, rtol=1e-4, atol=1e-6 * np.abs(g).max())
     al = float(hp.kernel[0])
     for k in (int(np.argmax(np.abs(g[:d]))), d):
         def ln_o(dx):
