@@ -605,7 +605,6 @@ static int predict_hess_once(gpg_ctx* c, const double* xq, double varK, double* 
 int gpg_predict_hess(gpg_ctx* c, const double* xq, double varK, double* mu, double* sig, double* dmudx, double* dsigdx,
                      double* d2mudx2, double* d2sigdx2) {
   if (c && (!d2mudx2 || !d2sigdx2 || !dmudx || !dsigdx)) { c->err = "Hessian / gradient output is NULL"; return -1; }
-  if (c && c->kernel == GPG_KERNEL_RATQU) { c->err = "posterior Hessians are not available for the RatQu kernel"; return -1; }
   return with_fallback(c, [&] { return predict_hess_once(c, xq, varK, mu, sig, dmudx, dsigdx, d2mudx2, d2sigdx2); });
 }
 

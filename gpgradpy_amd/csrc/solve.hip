@@ -346,13 +346,19 @@ __global__ void __launch_bounds__(256) hess_contract_kernel(AsmParams P, const d
 #pragma unroll
   for (int i = 0; i < D; ++i) { xq[i] = Xq[(size_t)i * nxp]; th[i] = P.theta[i]; }
   const double sqrt5 = sqrt(5.0);
+  const double rq_s1 = 1.0 + 1.0 / P.hp_kernel, rq_s2 = rq_s1 * (1.0 + 2.0 / P.hp_kernel);   // RatQu only
   for (int a = threadIdx.x; a < n; a += 256) {
-    double R[D], tR[D], E, M1 = 0.0, c3 = 0.0;
+    double R[D], tR[D], E, M1 = 0.0, c3 = 0.0, F3 = 0.0;
     double s = 0.0;
 #pragma unroll
     for (int i = 0; i < D; ++i) { R[i] = Xt[(size_t)i * n + a] - xq[i]; tR[i] = th[i] * R[i]; s += tR[i] * R[i]; }
     if (KERN == GPG_KERNEL_SQEXP) {
       E = exp(-s);
+    } else if (KERN == GPG_KERNEL_RATQU) {               // f_p = B^(-alpha-p): M1 = f_1, E = f_2, F3 = f_3
+      const double Bq = 1.0 + s / P.hp_kernel;
+      M1 = pow(Bq, -P.hp_kernel - 1.0);
+      E = pow(Bq, -P.hp_kernel - 2.0);
+      F3 = pow(Bq, -P.hp_kernel - 3.0);
     } else {
       const double nu = sqrt(s);
       E = exp(-sqrt5 * nu);
@@ -366,6 +372,7 @@ __global__ void __launch_bounds__(256) hess_contract_kernel(AsmParams P, const d
       for (int i = 0; i < D; ++i) {
         double v;
         if (KERN == GPG_KERNEL_SQEXP) v = (4.0 * tR[i] * tRk - (i == k ? 2.0 * th[i] : 0.0)) * E;
+        else if (KERN == GPG_KERNEL_RATQU) v = (4.0 * rq_s1) * tR[i] * tRk * E - (i == k ? 2.0 * th[i] * M1 : 0.0);   // KernelRatQuad.py:51-136
         else v = (25.0 / 3.0) * tR[i] * tRk * E - (i == k ? th[k] * M1 : 0.0);
         g[i] += v * wa;
         g[D + i] += v * ws;
@@ -385,6 +392,9 @@ __global__ void __launch_bounds__(256) hess_contract_kernel(AsmParams P, const d
             v = 4.0 * ((i == k ? th[i] * tR[j] : 0.0) + (j == k ? th[j] * tR[i] : 0.0) + (i == j ? th[i] * tRk : 0.0))
                 - 8.0 * tR[i] * tR[j] * tRk;
             v *= E;
+          } else if (KERN == GPG_KERNEL_RATQU) {           // KernelRatQuad.py:556-632
+            v = (4.0 * rq_s1) * ((i == k ? th[i] * tR[j] : 0.0) + (j == k ? th[j] * tR[i] : 0.0) + (i == j ? th[i] * tRk : 0.0)) * E
+                - (8.0 * rq_s2) * tR[i] * tR[j] * tRk * F3;
           } else {
             v = (i == k ? th[i] * tR[j] : 0.0) + (j == k ? th[j] * tR[i] : 0.0) + (i == j ? th[i] * tRk : 0.0)
                 - c3 * tR[i] * tR[j] * tRk;
@@ -419,6 +429,10 @@ __global__ void __launch_bounds__(256) cross_dx_rows_kernel(AsmParams P, const d
   for (int i = 0; i < D; ++i) { th[i] = P.theta[i]; R[i] = Xt[(size_t)i * n + a] - Xq[(size_t)i * nxp]; s += th[i] * (R[i] * R[i]); }
   if (KERN == GPG_KERNEL_SQEXP) {
     E = exp(-s);
+  } else if (KERN == GPG_KERNEL_RATQU) {
+    const double Bq = 1.0 + s / P.hp_kernel;
+    M1 = pow(Bq, -P.hp_kernel - 1.0);
+    E = pow(Bq, -P.hp_kernel - 2.0);
   } else {
     const double nu = sqrt(s);
     E = exp(-sqrt5 * nu);
@@ -429,7 +443,8 @@ __global__ void __launch_bounds__(256) cross_dx_rows_kernel(AsmParams P, const d
     Wt[(size_t)a * nxp] = 0.0;
 #pragma unroll
     for (int jp = 0; jp < D; ++jp)
-      Wt[(size_t)a * nxp + 1 + jp] = ip * (KERN == GPG_KERNEL_SQEXP ? ((2.0 * th[jp]) * R[jp]) * E : (th[jp] * R[jp]) * M1);
+      Wt[(size_t)a * nxp + 1 + jp] = ip * (KERN == GPG_KERNEL_SQEXP ? ((2.0 * th[jp]) * R[jp]) * E
+                                          : KERN == GPG_KERNEL_RATQU ? ((2.0 * th[jp]) * R[jp]) * M1 : (th[jp] * R[jp]) * M1);
   }
   const int gpa = P.gpos[a];
   if (nblk > 1 && gpa >= 0) {
@@ -444,6 +459,10 @@ __global__ void __launch_bounds__(256) cross_dx_rows_kernel(AsmParams P, const d
         if (KERN == GPG_KERNEL_SQEXP) {
           v = (i == jp) ? (2.0 * th[i] - (4.0 * (th[i] * th[i])) * (R[i] * R[i])) * E
                         : ((-4.0 * th[i]) * th[jp]) * ((R[i] * R[jp]) * E);
+        } else if (KERN == GPG_KERNEL_RATQU) {
+          const double rq_c = 4.0 * (1.0 + 1.0 / P.hp_kernel);
+          v = (i == jp) ? (2.0 * th[i]) * M1 - ((rq_c * (th[i] * th[i])) * (R[i] * R[i])) * E
+                        : (((((-rq_c) * th[i]) * th[jp]) * R[i]) * R[jp]) * E;
         } else {
           v = (i == jp) ? th[i] * M1 - (((25.0 / 3.0) * (th[i] * th[i])) * (R[i] * R[i])) * E
                         : (((((-(25.0 / 3.0)) * th[i]) * th[jp]) * R[i]) * R[jp]) * E;
@@ -585,6 +604,7 @@ void gpg_launch_cross_grad(gpg_ctx* c, const AsmParams& p, int nx, int nxp, doub
 // stage 0: H1 / H2 contraction, 1: derivative rows into Wt rows 1..d, 2: Gram of those rows after the forward sweep
 void gpg_launch_hess_stage(gpg_ctx* c, const AsmParams& p, int nxp, double* h1, double* h2, double* T, int stage) {
   if (p.kernel == GPG_KERNEL_SQEXP) launch_hess_d<GPG_KERNEL_SQEXP>(c, p, nxp, h1, h2, T, stage);
+  else if (p.kernel == GPG_KERNEL_RATQU) launch_hess_d<GPG_KERNEL_RATQU>(c, p, nxp, h1, h2, T, stage);
   else launch_hess_d<GPG_KERNEL_MA5F2>(c, p, nxp, h1, h2, T, stage);
 }
 

@@ -617,9 +617,6 @@ class GaussianProcess(HparaOptz):
         """GpEvalModel.py:59-198: returns (mu, sig, dmudx, dsigdx, d2mudx2, d2sigdx2); the Hessians are
         evaluated one point per call, as in the reference (GpEvalModel.py:358,369)."""
         assert self.KernEta_chofac is not None, 'To evaluate the surr the Cholesky decomposition is required'
-        if calc_hess and self.kernel_type == 'RatQu':
-            # the second / third derivative kernels of RatQu (KernelRatQuad.py:51-136, 556-632) are not built
-            raise NotImplementedError("posterior Hessians are not available for kernel 'RatQu' (SURVEY.md 8f4)")
         if calc_hess:
             assert calc_grad, 'To return the hessian calc_grad must also be set to True'      # GpEvalModel.py:126-127
             if self.bvec_use_grad is not None and not np.all(self.bvec_use_grad):

@@ -27,7 +27,7 @@ extern "C" {
 
 typedef struct gpg_ctx gpg_ctx;
 
-/* RatQu (KernelRatQuad.py:439-554, 636-843): everything except the posterior Hessians -- gpg_predict_hess returns -1. */
+/* RatQu = the rational quadratic kernel of KernelRatQuad.py, with its own hyperparameter alpha (gpg_hp.hp_kernel). */
 enum { GPG_KERNEL_SQEXP = 0, GPG_KERNEL_MA5F2 = 1, GPG_KERNEL_RATQU = 2 };
 enum { GPG_WELLCOND_BASE = 0, GPG_WELLCOND_PRECON = 1 };
 

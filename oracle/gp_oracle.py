@@ -391,7 +391,21 @@ def kern_hess_x(x, Y, theta, kernel, use_grad):
     R = x[None, :] - Y                                   # [n, d]
     N = n * (d + 1) if use_grad else n
     H = np.zeros((d, d, N))
-    if kernel == "SqExp":
+    kernel, alpha = _kern_split(kernel)
+    if kernel == "RatQu":                                # KernelRatQuad.py:51-136 (base columns), :556-632 (gradient columns)
+        B = 1.0 + np.sum(theta * R ** 2, axis=1) / alpha
+        f1, f2, f3 = B ** (-alpha - 1.0), B ** (-alpha - 2.0), B ** (-alpha - 3.0)
+        s1, s2 = 1.0 + 1.0 / alpha, (1.0 + 1.0 / alpha) * (1.0 + 2.0 / alpha)
+        for k in range(d):
+            for i in range(d):
+                H[k, i, :n] = -2 * theta[i] * (i == k) * f1 + 4 * s1 * theta[i] * theta[k] * R[:, i] * R[:, k] * f2
+                if use_grad:
+                    for j in range(d):
+                        c0 = n + j * n
+                        H[k, i, c0:c0 + n] = (-4 * s1 * theta[i] * theta[j] * ((i == k) * R[:, j] + (j == k) * R[:, i])
+                                              - 4 * s1 * (i == j) * theta[i] * theta[k] * R[:, k]) * f2 \
+                            + 8 * s2 * theta[i] * theta[j] * theta[k] * R[:, i] * R[:, j] * R[:, k] * f3
+    elif kernel == "SqExp":
         K = np.exp(-np.sum(theta * R ** 2, axis=1))
         for k in range(d):
             for i in range(d):

@@ -111,10 +111,6 @@ def test_golden_case(path):
     assert np.isclose(m1, mu[0]) and np.isclose(s1, sig[0]) and dm1.shape == (c["d"],) and np.allclose(dm1, dmudx[0])
     # Hessians: one point per call (GpEvalModel.py:358), no gradient masks (reference shape bug)
     masked = c["use_grad"] and not c["bvec_use_grad"].all()
-    if c["kernel"] == "RatQu":            # second / third derivative kernels of RatQu are not built
-        with pytest.raises(NotImplementedError):
-            GP.eval_model(c["xq"][0], calc_grad=True, calc_hess=True, squeeze_nx=True)
-        return
     if masked or c["xq"].shape[0] > 1:
         with pytest.raises((AssertionError, NotImplementedError)):
             GP.eval_model(c["xq"], calc_grad=True, calc_hess=True)

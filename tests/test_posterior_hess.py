@@ -36,7 +36,8 @@ def test_oracle_hessians_match_reference(path):
     n, d, ug = int(c["n"]), int(c["d"]), bool(c["use_grad"])
     y = orc.make_data_vec(c["f"], c["g"]) if ug else c["f"]
     nv = orc.calc_noise_vec(n, d, ug, c["std_f"], c["std_g"] if ug else None)
-    m = orc.setup_eval_model(c["x"], y, c["theta"], str(c["kernel"]), ug, "precon" if ug else "base", c["etaK"], nv,
+    kern = (str(c["kernel"]), float(c["hp_kernel"])) if "hp_kernel" in c else str(c["kernel"])
+    m = orc.setup_eval_model(c["x"], y, c["theta"], kern, ug, "precon" if ug else "base", c["etaK"], nv,
                              c["beta"], c["varK"])
     for i in range(c["xq"].shape[0]):
         mu, sig, dmu, dsig, d2mu, d2sig = orc.eval_model_hess(m, c["xq"][i])
@@ -54,7 +55,8 @@ def test_device_hessians_match_reference(path):
         GP.set_data(c["x"], c["f"], c["std_f"], c["g"], c["std_g"])
     else:
         GP.set_data(c["x"], c["f"], c["std_f"])
-    hp = GP.make_hp_class(theta=c["theta"], varK=None if np.isnan(c["varK_in"]) else c["varK_in"])
+    hp = GP.make_hp_class(theta=c["theta"], kernel=float(c["hp_kernel"]) if "hp_kernel" in c else None,
+                          varK=None if np.isnan(c["varK_in"]) else c["varK_in"])
     hp = GP.optz_closed_form_hp(hp)
     GP.set_hpara('set', 0, hp_vals=hp)
     for i in range(c["xq"].shape[0]):
