@@ -11,14 +11,22 @@ import numpy as np
 from scipy.linalg import eigh_tridiagonal
 
 
-def lanczos_largest(apply, n, k_max=120, rtol=1e-9, seed=0):
-    """Largest eigenvalue of the symmetric positive definite operator `apply` (n -> n)."""
+def lanczos_largest(apply, n, k_max=120, rtol=1e-9, seed=0, want_vector=False):
+    """Largest eigenvalue (and, on request, its unit eigenvector) of the symmetric positive definite operator
+    `apply` (n -> n)."""
     k_max = min(k_max, n)
     Q = np.zeros((k_max + 1, n))
     q = np.random.default_rng(seed).standard_normal(n)
     Q[0] = q / np.linalg.norm(q)
     alpha, beta = [], []
     theta = np.nan
+    ritz = None
+
+    def done(theta, ritz, j):
+        if not want_vector:
+            return theta
+        v = Q[0].copy() if ritz is None else Q[:len(ritz)].T @ ritz
+        return theta, v / np.linalg.norm(v)
     for j in range(k_max):
         w = apply(Q[j])
         a = float(Q[j] @ w)
@@ -30,21 +38,25 @@ def lanczos_largest(apply, n, k_max=120, rtol=1e-9, seed=0):
         if j >= 1:
             ev, evec = eigh_tridiagonal(np.array(alpha), np.array(beta))
             theta = ev[-1]
+            ritz = evec[:, -1]
             if b * abs(evec[-1, -1]) <= rtol * abs(theta):   # residual bound of the largest Ritz pair
-                return theta
+                return done(theta, ritz, j)
         else:
             theta = a
         if b <= 1e-300 or j + 1 >= k_max:
-            return theta
+            return done(theta, ritz, j)
         beta.append(b)
         Q[j + 1] = w / b
-    return theta
+    return done(theta, ritz, k_max)
 
 
-def cond_from_factor(apply_mat, apply_inv, n):
-    """cond_2 = lambda_max(K) * lambda_max(K^-1), each from its own Lanczos run."""
+def cond_from_factor(apply_mat, apply_inv, n, want_vectors=False):
+    """cond_2 = lambda_max(K) * lambda_max(K^-1), each from its own Lanczos run.  With want_vectors also
+    (lambda_min, v_max, v_min): what the gradient of the condition number needs (GpHparaCon.py:175-197)."""
     if n == 1:
-        return 1.0
-    lam_max = lanczos_largest(apply_mat, n)
-    inv_lam_min = lanczos_largest(apply_inv, n, seed=1)
-    return float(lam_max * inv_lam_min)
+        return (1.0, 1.0, np.ones(1), np.ones(1)) if want_vectors else 1.0
+    if not want_vectors:
+        return float(lanczos_largest(apply_mat, n) * lanczos_largest(apply_inv, n, seed=1))
+    lam_max, v_max = lanczos_largest(apply_mat, n, rtol=1e-12, want_vector=True)
+    inv_lam_min, v_min = lanczos_largest(apply_inv, n, rtol=1e-12, seed=1, want_vector=True)
+    return float(lam_max * inv_lam_min), 1.0 / float(inv_lam_min), v_max, v_min

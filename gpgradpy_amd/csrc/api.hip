@@ -303,7 +303,7 @@ static int gpg_lkd_grad_once(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out, dou
   gpg_backward_solve(c);
   gpg_inverse_from_factor(c, c->Wfull, c->Minv);
   double* res = c->gpartial + (size_t)nval * nblk;
-  gpg_launch_grad_contract(c, p, c->gpartial, res);
+  gpg_launch_grad_contract(c, p, c->gpartial, res, c->zvec, c->Minv);
   std::vector<double> h(nval);
   const int ns = c->d + 3 + (c->kernel == GPG_KERNEL_RATQU ? 1 : 0);
   GPG_HIP_OK(c, hipMemcpyAsync(h.data(), res, sizeof(double) * 2 * ns, hipMemcpyDeviceToHost, c->stream));
@@ -668,6 +668,34 @@ int gpg_get_matrix(gpg_ctx* c, const gpg_hp* hp, int which, double* out) {
   GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
   GPG_HIP_OK(c, hipGetLastError());
   GPG_LAUNCH_OK(c);
+  return 0;
+}
+
+int gpg_dcov_quadform(gpg_ctx* c, const gpg_hp* hp, const double* v, double* out) {
+  int rc = check_hp(c, hp);
+  if (rc) return rc;
+  if (!v || !out) { c->err = "v / out is NULL"; return -1; }
+  if (!c->factor_valid) { c->err = "gpg_dcov_quadform follows a successful gpg_lkd / gpg_setup_eval with the same hp"; return -1; }
+  GPG_HIP_OK(c, hipSetDevice(c->device));
+  const int nblk = gpg_grad_partial_blocks(c);
+  const int nval = 2 * GPG_GRAD_SLOTS_MAX;
+  if (!c->gpartial) GPG_HIP_OK(c, hipMalloc(&c->gpartial, sizeof(double) * (size_t)nval * (nblk + 1)));
+  if (!c->apply_buf) GPG_HIP_OK(c, hipMalloc(&c->apply_buf, sizeof(double) * 2 * (size_t)c->vec_rows_cols));
+  double* dv = c->apply_buf;
+  double* dz = c->apply_buf + c->vec_rows_cols;
+  GPG_HIP_OK(c, hipMemcpyAsync(dv, v, sizeof(double) * c->N, hipMemcpyHostToDevice, c->stream));
+  gpg_launch_unscale(c, dv, dz);                          // the contraction kernel forms "alpha" = z * invp = v
+  AsmParams p = make_params(c, hp, 0);
+  double* res = c->gpartial + (size_t)nval * nblk;
+  gpg_launch_grad_contract(c, p, c->gpartial, res, dz, nullptr);
+  const int ns = c->d + 3 + (c->kernel == GPG_KERNEL_RATQU ? 1 : 0);
+  std::vector<double> h(ns);
+  GPG_HIP_OK(c, hipMemcpyAsync(h.data(), res, sizeof(double) * ns, hipMemcpyDeviceToHost, c->stream));
+  GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
+  GPG_HIP_OK(c, hipGetLastError());
+  GPG_LAUNCH_OK(c);
+  out[c->d + 3] = 0.0;
+  for (int k = 0; k < ns; ++k) out[k] = h[k];
   return 0;
 }
 

@@ -142,7 +142,9 @@ void gpg_launch_hess_stage(gpg_ctx* c, const AsmParams& p, int nxp, double* h1, 
 void gpg_launch_combine_rows(gpg_ctx* c, int slot);                       // RHS row 0 <- L^-1 P^-1 (y - V beta)
 void gpg_launch_identity(gpg_ctx* c, double* W, int ldw);
 void gpg_inverse_from_factor(gpg_ctx* c, double* W, double* Minv);       // Minv <- -(L L^T)^-1 (lower)
-void gpg_launch_grad_contract(gpg_ctx* c, const AsmParams& p, double* partial, double* out_dev);
+void gpg_launch_grad_contract(gpg_ctx* c, const AsmParams& p, double* partial, double* out_dev, const double* zvec,
+                              const double* Minv);
+void gpg_launch_unscale(gpg_ctx* c, const double* v, double* z);          // z = v / invp
 int gpg_grad_partial_blocks(const gpg_ctx* c);
 int gpg_factor_apply_dev(gpg_ctx* c, int op, double* v, double* out);       // (L L^T) v or (L L^T)^-1 v, device vectors [Npad]
 void gpg_launch_extract(gpg_ctx* c, int which);                          // dense_tmp <- sym / P L

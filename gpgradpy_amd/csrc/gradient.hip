@@ -40,6 +40,12 @@ __global__ void set_identity_kernel(double* __restrict__ W, int ldw, int Npad) {
   if (r < Npad) W[(size_t)r + (size_t)r * ldw] = 1.0;
 }
 
+// z[r] = v[r] / invp[r] (zero tail): the vector whose "alpha" in grad_contract_kernel is v itself
+__global__ void unscale_kernel(const double* __restrict__ v, const double* __restrict__ invp, int N, int Npad, double* __restrict__ z) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < Npad) z[r] = r < N ? v[r] / invp[r] : 0.0;
+}
+
 template <int KERN, int D>
 __global__ void __launch_bounds__(256) grad_contract_kernel(AsmParams P, const double* __restrict__ Xt,
                                                             const double* __restrict__ invp,
@@ -146,7 +152,7 @@ __global__ void __launch_bounds__(256) grad_contract_kernel(AsmParams P, const d
         const size_t c = J == 0 ? (size_t)b : (size_t)n + (size_t)(J - 1) * ng + gpbb;
         const size_t rr = r >= c ? r : c, cc = r >= c ? c : r;            // Minv holds the lower triangle
         const double laa = wgt * (ala[I] * alb[bb][J]);
-        const double lin = wgt * (0.5 * ((ipa[I] * Minv[rr + cc * (size_t)ldm]) * ipb[bb][J]));   // -1/2 Kcov^-1 = +1/2 P^-1 Minv P^-1
+        const double lin = Minv ? wgt * (0.5 * ((ipa[I] * Minv[rr + cc * (size_t)ldm]) * ipb[bb][J])) : 0.0;   // -1/2 Kcov^-1 = +1/2 P^-1 Minv P^-1
         const bool dg = (r == c);
         const double dscale = (dg && precon) ? (1.0 + eta) : 1.0;        // precon: eta * diag(d K_rr) rides along
 #pragma unroll
@@ -207,7 +213,7 @@ __global__ void __launch_bounds__(256) grad_contract_kernel(AsmParams P, const d
             // indices are those of row (i+1, b), column (0, a)
             const size_t r = (size_t)n + (size_t)i * ng + gpbb, c = (size_t)a;
             const double laa = 2.0 * (alb[bb][i + 1] * ala[0]);
-            const double lin = 2.0 * (0.5 * ((ipb[bb][i + 1] * Minv[r + c * (size_t)ldm]) * ipa[0]));
+            const double lin = Minv ? 2.0 * (0.5 * ((ipb[bb][i + 1] * Minv[r + c * (size_t)ldm]) * ipa[0])) : 0.0;
 #pragma unroll
             for (int k = 0; k < D; ++k) {
               const double g = vK * (-dv[k]);
@@ -285,7 +291,7 @@ __global__ void __launch_bounds__(256) grad_contract_kernel(AsmParams P, const d
                 if (!diag_pt) {                                          // (j+1,a ; i+1,b) + transpose
                   const size_t r = (size_t)n + (size_t)i * ng + gpbb, c = (size_t)n + (size_t)j * ng + gpa;
                   const double laa = 2.0 * (alb[bb][i + 1] * ala[j + 1]);
-                  const double lin = 2.0 * (0.5 * ((ipb[bb][i + 1] * Minv[r + c * (size_t)ldm]) * ipa[j + 1]));
+                  const double lin = Minv ? 2.0 * (0.5 * ((ipb[bb][i + 1] * Minv[r + c * (size_t)ldm]) * ipa[j + 1])) : 0.0;
 #pragma unroll
                   for (int k = 0; k < D; ++k) {
                     const double g = vK * dv[k];
@@ -331,11 +337,11 @@ __global__ void grad_final_reduce_kernel(const double* __restrict__ partial, int
 }
 
 template <int KERN>
-void launch_contract_d(gpg_ctx* c, const AsmParams& p, double* partial, dim3 grid) {
+void launch_contract_d(gpg_ctx* c, const AsmParams& p, double* partial, dim3 grid, const double* zvec, const double* Minv) {
 #define CASE_D(DD)                                                                                               \
   case DD:                                                                                                       \
-    hipLaunchKernelGGL((grad_contract_kernel<KERN, DD>), grid, dim3(256), 0, c->stream, p, c->Xt, c->invp, c->zvec, \
-                       c->Minv, c->Npad, partial);                                                               \
+    hipLaunchKernelGGL((grad_contract_kernel<KERN, DD>), grid, dim3(256), 0, c->stream, p, c->Xt, c->invp, zvec,   \
+                       Minv, c->Npad, partial);                                                                  \
     break;
   switch (p.d) {
     CASE_D(1) CASE_D(2) CASE_D(3) CASE_D(4) CASE_D(5) CASE_D(6) CASE_D(7) CASE_D(8)
@@ -357,14 +363,21 @@ void gpg_launch_identity(gpg_ctx* c, double* W, int ldw) {
 }
 
 // out_dev[0 .. ns) = g_aa, out_dev[ns .. 2 ns) = g_inv, ns = d + 3 (+ 1 for RatQu: alpha last)
-void gpg_launch_grad_contract(gpg_ctx* c, const AsmParams& p, double* partial, double* out_dev) {
+// zvec = P alpha-like vector (the kernel forms alpha = zvec * invp), Minv = -(L L^T)^-1 or nullptr (then only the
+// quadratic forms g_aa[k] = alpha^T G_k alpha are meaningful: gpg_dcov_quadform)
+void gpg_launch_grad_contract(gpg_ctx* c, const AsmParams& p, double* partial, double* out_dev, const double* zvec,
+                              const double* Minv) {
   dim3 grid((p.n + 255) / 256, (p.n + kTBg - 1) / kTBg);
-  if (p.kernel == GPG_KERNEL_SQEXP) launch_contract_d<GPG_KERNEL_SQEXP>(c, p, partial, grid);
-  else if (p.kernel == GPG_KERNEL_RATQU) launch_contract_d<GPG_KERNEL_RATQU>(c, p, partial, grid);
-  else launch_contract_d<GPG_KERNEL_MA5F2>(c, p, partial, grid);
+  if (p.kernel == GPG_KERNEL_SQEXP) launch_contract_d<GPG_KERNEL_SQEXP>(c, p, partial, grid, zvec, Minv);
+  else if (p.kernel == GPG_KERNEL_RATQU) launch_contract_d<GPG_KERNEL_RATQU>(c, p, partial, grid, zvec, Minv);
+  else launch_contract_d<GPG_KERNEL_MA5F2>(c, p, partial, grid, zvec, Minv);
   const int ns = p.d + 3 + (p.kernel == GPG_KERNEL_RATQU ? 1 : 0);
   hipLaunchKernelGGL(grad_final_reduce_kernel, dim3(1), dim3(64), 0, c->stream, partial, (int)(grid.x * grid.y),
                      2 * ns, out_dev);
+}
+
+void gpg_launch_unscale(gpg_ctx* c, const double* v, double* z) {
+  hipLaunchKernelGGL(unscale_kernel, dim3((c->Npad + 255) / 256), dim3(256), 0, c->stream, v, c->invp, c->N, c->Npad, z);
 }
 
 int gpg_grad_partial_blocks(const gpg_ctx* c) { return ((c->n + 255) / 256) * ((c->n + kTBg - 1) / kTBg); }

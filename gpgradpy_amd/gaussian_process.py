@@ -40,6 +40,7 @@ class GaussianProcess(HparaOptz):
     cond_max_target = 1e10
     cond_max = 1e10
     cond_max_abs = 1e16
+    cond_norm = 2                 # GaussianProcess.py:104 (2 or 'fro'; only 2 is on the accelerated path)
 
     b_optz_hp_kernel = True
     b_use_data_scl = False
@@ -448,8 +449,8 @@ class GaussianProcess(HparaOptz):
             raise NotImplementedError('likelihood gradient with a bvec_use_grad mask is not supported')
         if calc_grad and not (lkd_use_adj_mtd is None or lkd_use_adj_mtd) and not self.lkd_use_adj_mtd:
             raise NotImplementedError('only the adjoint gradient method is on the accelerated path')
-        if calc_cond and calc_grad:
-            raise NotImplementedError('the gradient of the condition number (GpHparaCon.py:163-261) is outside the accelerated path')
+        if calc_cond and calc_grad and self.cond_norm != 2:
+            raise NotImplementedError("only the 2-norm condition number is on the accelerated path (cond_norm = 'fro' is not)")
         noisy = self.b_has_noisy_data
         if noisy:
             assert hp_vals.varK is not None, f'varK is not provided and hp_vals.varK is None, hp_vals = {hp_vals}'
@@ -472,9 +473,14 @@ class GaussianProcess(HparaOptz):
         if rc > 0:
             # CalcLkd.py:308-311 / 330-333: the reference reports the SVD condition number here; not computed
             return LkdInfo(cond=np.nan), False
-        cond = None
+        cond = cond_grad = None
         if calc_cond:
-            cond = self.calc_cond_device()
+            if calc_grad and self.wellcond_mtd != 'precon':          # GpHparaCon.py:171-173: no gradient with 'precon'
+                cond, cond_grad = self.calc_cond_device(want_grad=True, hp_struct=hp)
+            else:
+                cond = self.calc_cond_device()
+                if calc_grad:
+                    print('Not setup to calculate the gradient of the condition number if wellcond_mtd = "precon" ')
             if self.wellcond_mtd == 'precon':
                 if cond > 1.1 * self.cond_max:                                   # Kernel.py:242-243
                     print(f'*** WARNING: condK = {cond:.2e} which is greater than cond_max = {self.cond_max:.2e} ***')
@@ -505,7 +511,7 @@ class GaussianProcess(HparaOptz):
         info = LkdInfo(hp_beta=np.array([out.beta]), hp_varK=None if noisy else out.varK,
                        ln_det_Kmat=out.ln_det if calc_lkd or not noisy else None,
                        ln_lkd=ln_lkd if calc_lkd else None, ln_lkd_grad=ln_lkd_grad,
-                       data_vec=self._data_vec if noisy else None, cond=cond)
+                       data_vec=self._data_vec if noisy else None, cond=cond, cond_grad=cond_grad)
         return info, True
 
     def calc_lkd_varK_pnlt(self, varK, fval_vec):
@@ -748,7 +754,7 @@ class GaussianProcess(HparaOptz):
         ln = self.calc_lkd_batch(np.array(rows))
         return (ln[0::2] - ln[1::2]) / (2.0 * np.array(steps))
 
-    def calc_cond_device(self):
+    def calc_cond_device(self, want_grad=False, hp_struct=None):
         """2-norm condition number of the matrix factorised last -- Kcov_precon = varK (Kcor + eta I) for 'precon',
         Kcov for 'base' (what Kernel.py:239-245, 279-285 pass to np.linalg.cond) -- from Lanczos runs on
         v -> (L L^T) v and v -> (L L^T)^-1 v through the factor in HBM (gpgradpy_amd/cond_number.py)."""
@@ -764,7 +770,33 @@ class GaussianProcess(HparaOptz):
                     raise _lib.GpgError(f'gpg_factor_apply failed ({rc}): {self._err()}')
                 return out
             return f
-        return cond_from_factor(op(0), op(1), N)
+        if not want_grad:
+            return cond_from_factor(op(0), op(1), N)
+        # gradient of the condition number (GpHparaCon.py:163-207): with the unit eigenvectors of lambda_max / lambda_min
+        #   d cond / d hp_k = (v_max^T G_k v_max - cond v_min^T G_k v_min) / lambda_min,   G_k = d Kmat / d hp_k,
+        # the quadratic forms on the device (gpg_dcov_quadform), the hyperparameter values in hp_info_optz_lkd order
+        cond, lam_min, v_max, v_min = cond_from_factor(op(0), op(1), N, want_vectors=True)
+        q = []
+        for v in (v_max, v_min):
+            out = np.zeros(self.dim + 4)
+            v = np.ascontiguousarray(v, dtype=np.float64)
+            rc = self._lib.gpg_dcov_quadform(self._ctx, C.byref(hp_struct), _lib.as_dp(v), _lib.as_dp(out))
+            if rc != 0:
+                raise _lib.GpgError(f'gpg_dcov_quadform failed ({rc}): {self._err()}')
+            q.append(out)
+        g_all = (q[0] - cond * q[1]) / max(lam_min, 1e-16)                      # eig_min_mod, GpHparaCon.py:192
+        hi, d = self.hp_info_optz_lkd, self.dim
+        cond_grad = np.zeros(hi.n_hp)
+        cond_grad[hi.idx_theta] = g_all[:d]
+        if hi.has_kernel:
+            cond_grad[hi.idx_kernel] = g_all[d + 3]
+        if hi.has_varK:
+            cond_grad[hi.idx_varK] = g_all[d]
+        if hi.has_var_fval:
+            cond_grad[hi.idx_var_fval] = g_all[d + 1]
+        if hi.has_var_fgrad:
+            cond_grad[hi.idx_var_fgrad] = g_all[d + 2]
+        return cond, cond_grad
 
     def last_factor(self):
         """(schedule, matrices) of the most recent factorisation launch: 'blocked' | 'tile64' | 'tile128'."""

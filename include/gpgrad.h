@@ -154,6 +154,13 @@ int gpg_get_matrix(gpg_ctx* ctx, const gpg_hp* hp, int which, double* out);
  * (gpgradpy_amd/cond_number.py; replaces np.linalg.cond of an N x N matrix). */
 int gpg_factor_apply(gpg_ctx* ctx, int op, const double* v, double* out);
 
+/* out[k] = v^T (d Kcov / d hp_k) v for the dim + 4 hyperparameter slots of gpg_lkd_grad (theta, varK, var_fval,
+ * var_fgrad, hp_kernel), v host [N]; call after a successful gpg_lkd / gpg_setup_eval with the same hp (it uses that
+ * call's preconditioner vector).  With the extreme eigenvectors of the host-side Lanczos runs this gives the
+ * gradient of the condition number, d cond / d hp_k = (q_k(v_max) - cond q_k(v_min)) / lambda_min
+ * (GpHparaCon.py:163-207), without the [n_hp, N, N] derivative tensor or a dense eigendecomposition. */
+int gpg_dcov_quadform(gpg_ctx* ctx, const gpg_hp* hp, const double* v, double* out);
+
 /* Instrumentation (replaces the wall-clock accumulator _time_chofac, Kernel.py:247,304-305) ------- */
 
 enum {

@@ -16,7 +16,7 @@ import gen_golden as gg
 
 def main():
     GaussianProcess = gg._import_reference()
-    names, conds = [], []
+    names, conds, grads = [], [], {}
     skip = ("multistart_", "nugget_", "optz_", "hess_", "cond_", "micro_")
     for path in sorted(glob.glob(os.path.join(gg.HERE, "*.npz"))):
         base = os.path.basename(path)
@@ -42,10 +42,16 @@ def main():
                               varK=float(z["varK_in"]) if noisy else None, var_fval=nanv("var_fval"), var_fgrad=nanv("var_fgrad"))
         lkd, ok = GP.calc_lkd_all(hp, calc_lkd=True, calc_cond=True, calc_grad=False)
         assert ok and np.isclose(lkd.ln_lkd, float(z["ln_lkd"]), rtol=1e-10), base
+        if GP.wellcond_mtd != 'precon':          # gradient of the condition number (GpHparaCon.py:163-207; not with 'precon')
+            lkd_g, ok_g = GP.calc_lkd_all(hp, calc_lkd=True, calc_cond=True, calc_grad=True)
+            assert ok_g and np.isclose(lkd_g.cond, lkd.cond, rtol=1e-12)
+            grads[base[:-4]] = np.real(np.asarray(lkd_g.cond_grad, dtype=complex)).astype(float)
+            print(f"{base[:-4]:36s} cond_grad = {grads[base[:-4]]}")
         names.append(base[:-4])
         conds.append(float(lkd.cond))
         print(f"{base[:-4]:36s} cond = {lkd.cond:.10e}")
-    np.savez_compressed(os.path.join(gg.HERE, "cond_table.npz"), names=np.array(names), cond=np.array(conds))
+    np.savez_compressed(os.path.join(gg.HERE, "cond_table.npz"), names=np.array(names), cond=np.array(conds),
+                        **{"grad_" + k: v for k, v in grads.items()})
 
 
 if __name__ == "__main__":

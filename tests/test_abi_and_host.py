@@ -119,8 +119,9 @@ def test_out_of_scope_features_raise():
         gpgradpy_amd.GaussianProcess(2, True, 'SqExp', 'req_vmin')      # rejected like GaussianProcess.py:194
     GP = _gp_host_only(2, 'SqExp', 4, 'none')
     hp = GP.make_hp_class(theta=np.array([0.5, 0.5]))
+    GP.cond_norm = 'fro'
     with pytest.raises(NotImplementedError):
-        GP.calc_lkd_all(hp, calc_cond=True, calc_grad=True)            # gradient of the condition number
+        GP.calc_lkd_all(hp, calc_cond=True, calc_grad=True)            # Frobenius-norm condition number and its gradient
 
 
 def test_data_vec_layout():
