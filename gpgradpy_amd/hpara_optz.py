@@ -22,7 +22,7 @@ from smt's, the bounds and everything downstream are the reference's.
 import time
 
 import numpy as np
-from scipy.optimize import Bounds, minimize
+from scipy.optimize import Bounds, NonlinearConstraint, minimize
 
 
 def lhs_sample(xlimits, n, seed=1):
@@ -189,9 +189,20 @@ class HparaOptz:
         else:
             raise Exception(f'Unknown lkd_optz_start_mtd: {self.lkd_optz_start_mtd}')
         hp_x0, optz_bound = self.get_hp_x0_lhs_median(i_optz, hp_optz_info, n_x0)
-        if self.lkd_optz_start_mtd == 'hp_best':
-            if self.wellcond_mtd != 'precon':
-                raise NotImplementedError("lkd_optz_start_mtd = 'hp_best' needs the condition number unless wellcond_mtd = 'precon'")
+        if self.lkd_optz_start_mtd == 'hp_best' and self.wellcond_mtd != 'precon':
+            # GpHparaX0.py:33-59 with calc_cond: rows whose condition number exceeds 1.2 cond_max drop out (at least
+            # the best-conditioned one is kept); the condition number needs each factor, so one row at a time
+            ln_lkd_all, cond_all = np.full(n_x0, np.nan), np.full(n_x0, np.nan)
+            for i in range(n_x0):
+                lkd_info, ok = self.calc_lkd_all(self.hp_vec2dataclass(self.hp_info_optz_lkd, hp_x0[i, :]), calc_cond=True)
+                if ok:
+                    ln_lkd_all[i], cond_all[i] = lkd_info.ln_lkd, lkd_info.cond
+            no_good = cond_all > (1.2 * self.cond_max)
+            if np.sum(no_good) == no_good.size:
+                no_good[np.nanargmin(cond_all)] = False
+            ln_lkd_all[no_good] = np.nan
+            hp_x0 = hp_x0[np.nanargmax(ln_lkd_all), :][None, :]
+        elif self.lkd_optz_start_mtd == 'hp_best':
             # the reference's loop over calc_lkd_all (GpHparaX0.py:39-45) = one batched device call, sharded
             # over ranks when torch.distributed is up; failed factorisations are NaN and drop out of nanargmax
             from .multistart import select_best_restart
@@ -202,30 +213,45 @@ class HparaOptz:
     def calc_store_likelihood(self, hp_vec, always_calc_cond=False, calc_grad=True):
         hp_vec = np.atleast_1d(hp_vec).ravel()
         if not np.array_equal(hp_vec, self._last_hp_vec):
-            if self.b_use_cond_cstr or always_calc_cond:
-                raise NotImplementedError('the condition-number constraint is outside the accelerated path')
             hp_vals = self.hp_vec2dataclass(self.hp_info_optz_lkd, hp_vec)
-            lkd_info, b_chofac_good = self.calc_lkd_all(hp_vals, calc_lkd=True, calc_cond=False, calc_grad=calc_grad)
+            calc_cond = self.b_use_cond_cstr or always_calc_cond                   # OptzLkd.py:51
+            lkd_info, b_chofac_good = self.calc_lkd_all(hp_vals, calc_lkd=True, calc_cond=calc_cond, calc_grad=calc_grad)
+            cond_val, cond_grad = lkd_info.cond, lkd_info.cond_grad
             if b_chofac_good:
                 ln_lkd_val = lkd_info.ln_lkd
                 ln_lkd_grad = lkd_info.ln_lkd_grad
                 if calc_grad:
                     bvec = self.hp_info_optz_lkd.bvec_log_optz
-                    ln_lkd_grad[bvec] *= 10 ** hp_vec[bvec] * np.log(10)       # log10 chain rule, OptzLkd.py:65-70
+                    transformation = 10 ** hp_vec[bvec] * np.log(10)             # log10 chain rule, OptzLkd.py:65-73
+                    ln_lkd_grad[bvec] *= transformation
+                    if self.b_use_cond_cstr and cond_grad is not None:
+                        cond_grad[bvec] *= transformation
             else:
                 # the reference falls back on minus the SVD condition number here (OptzLkd.py:74-77), which it
-                # only has when calc_cond is on; with 'precon' that is NaN / None: reproduce as NaN, zero slope
+                # computes from the matrix; here the factor is needed for it: NaN, zero slope
                 ln_lkd_val = np.nan
                 ln_lkd_grad = np.zeros(self.hp_info_optz_lkd.n_hp)
+                cond_val = np.nan if cond_val is None else cond_val
+                cond_grad = np.zeros(self.hp_info_optz_lkd.n_hp) if cond_grad is None else cond_grad
             self._last_hp_vec = hp_vec.copy()
             self._lkd_val, self._lkd_grad = ln_lkd_val, ln_lkd_grad
-        return self._lkd_val, self._lkd_grad, np.nan, None
+            self._cond_val = np.nan if cond_val is None else cond_val
+            self._cond_grad = cond_grad
+        return self._lkd_val, self._lkd_grad, self._cond_val, self._cond_grad
 
     def return_optz_val(self, hp_vec):
         return -self.calc_store_likelihood(np.atleast_1d(hp_vec).ravel())[0]
 
     def return_optz_grad(self, hp_vec):
         return -self.calc_store_likelihood(np.atleast_1d(hp_vec).ravel())[1]
+
+    # nonlinear condition-number constraint cond <= cond_max of the methods without the preconditioner (OptzLkd.py:102-114,
+    # GaussianProcess.py:210-212)
+    def return_cond_val(self, hp_vec):
+        return self.calc_store_likelihood(np.atleast_1d(hp_vec).ravel())[2]
+
+    def return_cond_grad(self, hp_vec):
+        return self.calc_store_likelihood(np.atleast_1d(hp_vec).ravel())[3]
 
     # ---- multi-start SLSQP (OptzLkd.py:185-333) ------------------------------------------------------------------
     def optz_hp_max_lkd(self, hp_x0_all, optz_bound):
@@ -252,28 +278,53 @@ class HparaOptz:
         except ImportError:                                   # pragma: no cover
             world, rank = 1, 0
         lo, hi = shard_rows(n_optz, world, rank)
+        all_con_good = np.full(n_optz, True, dtype=bool)
+        optz_cond_all = np.full(n_optz, np.nan)
+        n_cho_fail, n_cond2big, max_init_cond = 0, 0, np.nan
+        nlc = []
+        if self.b_use_cond_cstr:                                                 # OptzLkd.py:245, GaussianProcess.py:210-212
+            nlc = NonlinearConstraint(self.return_cond_val, -np.inf, self.cond_max, jac=self.return_cond_grad)
         for i in range(lo, hi):
             x0_i = hp_x0_all[i, :]
+            if self.b_use_cond_cstr:                                             # OptzLkd.py:255-259
+                self._last_hp_vec = np.full((1, x0_i.size), np.nan)
+                lkd_val, _, cond_val = self.calc_store_likelihood(x0_i)[:3]
+                max_init_cond = np.nanmax((max_init_cond, cond_val))
+                n_cho_fail += int(np.isnan(lkd_val))
+                n_cond2big += int(cond_val > self.cond_max)
             self._last_hp_vec = np.full((1, x0_i.size), np.nan)
             res = minimize(self.return_optz_val, x0_i, method=self.optz_mtd, jac=self.return_optz_grad,
-                           bounds=optz_bound, constraints=[], options=optz_opt)
+                           bounds=optz_bound, constraints=nlc, options=optz_opt)
             optz_sol_all[i, :] = res.x
             optz_obj_all[i] = res.fun
             all_optz_success[i] = res.success
             all_total_fun_iter[i] = res.nit
-            if not res.success:
-                print(f'Surr hpara optz: Con GOOD, Optimizer: {res.message}')
+            if self.b_use_cond_cstr:                                             # OptzLkd.py:276-279
+                optz_cond_all[i] = self.return_cond_val(res.x)
+                all_con_good[i] = optz_cond_all[i] < 1.01 * self.cond_max
+            if not (res.success and all_con_good[i]):
+                print(f"Surr hpara optz: Con {'GOOD' if all_con_good[i] else 'FAIL'}, Optimizer: {'GOOD' if res.success else res.message}")
         if world > 1:
-            table = gather_rows(np.column_stack((optz_obj_all, all_optz_success, all_total_fun_iter, optz_sol_all))[lo:hi], n_optz)
+            table = gather_rows(np.column_stack((optz_obj_all, all_optz_success, all_total_fun_iter, all_con_good, optz_cond_all,
+                                                 optz_sol_all))[lo:hi], n_optz)
             optz_obj_all, all_optz_success, all_total_fun_iter = table[:, 0], table[:, 1] > 0.5, table[:, 2]
-            optz_sol_all = table[:, 3:]
-        idx_min = np.nanargmin(optz_obj_all)
-        best_hp = optz_sol_all[idx_min, :]
+            all_con_good, optz_cond_all, optz_sol_all = table[:, 3] > 0.5, table[:, 4], table[:, 5:]
+        if np.any(all_con_good):                                                 # OptzLkd.py:294-305
+            obj_ok, sol_ok = optz_obj_all[all_con_good], optz_sol_all[all_con_good, :]
+        else:
+            print('*** No solutions satisfy the constraints for the GP hyperparameter optimization ***')
+            print(f'Cond = {optz_cond_all}')
+            obj_ok, sol_ok = optz_obj_all, optz_sol_all
+        idx_min = np.nanargmin(obj_ok)
+        best_hp = sol_ok[idx_min, :]
         surr_optz_info = {'hp_optz_success': np.mean(all_optz_success), 'hp_optz_iter_mean': np.mean(all_total_fun_iter),
-                          'hp_optz_iter_max': np.max(all_total_fun_iter), 'hp_optz_con_good': 1.0,
-                          'optz_n_cho_fail': 0, 'optz_n_cond2big': 0, 'optz_max_init_cond': np.nan}
+                          'hp_optz_iter_max': np.max(all_total_fun_iter), 'hp_optz_con_good': np.mean(all_con_good),
+                          'optz_n_cho_fail': n_cho_fail, 'optz_n_cond2big': n_cond2big, 'optz_max_init_cond': max_init_cond}
         self.optz_obj_all_last, self.optz_sol_all_last = optz_obj_all, optz_sol_all
-        return best_hp, np.nan, surr_optz_info
+        cond_val = np.nan
+        if self.b_use_cond_cstr:                                                 # final condition number, OptzLkd.py:324-331
+            cond_val = self.calc_lkd_all(self.hp_vec2dataclass(self.hp_info_optz_lkd, best_hp), calc_cond=True)[0].cond
+        return best_hp, cond_val, surr_optz_info
 
     # ---- driver (GpHparaOptz.py:140-218) -------------------------------------------------------------------------
     def get_init_hp_vals(self):

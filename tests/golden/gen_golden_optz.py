@@ -54,7 +54,7 @@ def _import_reference():
     return GaussianProcess
 
 
-def run_case(GaussianProcess, name, n, d, kernel, noise, seed, n_hist=2, start_mtd='hp_best', n_best=12):
+def run_case(GaussianProcess, name, n, d, kernel, noise, seed, n_hist=2, start_mtd='hp_best', n_best=12, wellcond='precon'):
     rng = np.random.default_rng(seed)
     x = rng.uniform(-2, 2, (n, d))
     f, g = rosenbrock(x)
@@ -64,7 +64,7 @@ def run_case(GaussianProcess, name, n, d, kernel, noise, seed, n_hist=2, start_m
         std_f, std_g = np.full(n, 1e-2), np.full((n, d), 1e-1)
     else:
         std_f = std_g = None
-    GP = GaussianProcess(d, True, kernel, 'precon')
+    GP = GaussianProcess(d, True, kernel, wellcond)
     GP.lkd_optz_start_mtd = start_mtd
     GP.lkd_hp_best_n_eval = n_best
     GP.optz_n_x0 = 3
@@ -99,6 +99,7 @@ def run_case(GaussianProcess, name, n, d, kernel, noise, seed, n_hist=2, start_m
         out[f'it{it}_iter_max'] = GP.hp_optz_iter_max[it]
         out[f'it{it}_success'] = GP.hp_optz_success[it]
         print(f"{name} it{it}: n={ni} theta={hv.theta} varK={hv.varK:.6e} ln_lkd={out[f'it{it}_ln_lkd']:.10e} nit={GP.hp_optz_iter_max[it]}")
+    out.update(wellcond=wellcond, cond_hist=GP.Kcov_cond_all[:n_hist + 1], con_good_hist=GP.hp_optz_con_good[:n_hist + 1])
     out.update(name=name, n=n, d=d, kernel=kernel, noise=noise, x=x, f=f, g=g, n_hist=n_hist, start_mtd=start_mtd, n_best=n_best,
                std_f=np.full(n, np.nan) if std_f is None else std_f, std_g=np.full((n, d), np.nan) if std_g is None else std_g,
                theta_hist0=GP.hp_theta_all[0], varK_hist0=GP.hp_varK_all[0], kernel_hist0=GP.hp_kernel_all[0])
@@ -107,6 +108,10 @@ def run_case(GaussianProcess, name, n, d, kernel, noise, seed, n_hist=2, start_m
 
 def main():
     GaussianProcess = _import_reference()
+    if len(sys.argv) > 1 and sys.argv[1] == 'base':       # 'base' well-conditioning: SLSQP with the condition-number constraint
+        run_case(GaussianProcess, 'optz_SqExp_none_n12_d2_base', 12, 2, 'SqExp', 'none', seed=37, wellcond='base')
+        run_case(GaussianProcess, 'optz_Ma5f2_known_n10_d2_base_lhs', 10, 2, 'Ma5f2', 'known', seed=38, wellcond='base', start_mtd='lhs')
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'ratqu':      # only the rational quadratic case (kernel with its own hyperparameter)
         run_case(GaussianProcess, 'optz_RatQu_none_n12_d2', 12, 2, 'RatQu', 'none', seed=36)
         return

@@ -29,7 +29,7 @@ def _noise_args(c, ni):
 
 def _new_gp(c):
     import gpgradpy_amd
-    GP = gpgradpy_amd.GaussianProcess(int(c["d"]), True, str(c["kernel"]), "precon")
+    GP = gpgradpy_amd.GaussianProcess(int(c["d"]), True, str(c["kernel"]), str(c.get("wellcond", "precon")))
     GP.lkd_optz_start_mtd = str(c["start_mtd"])
     GP.lkd_hp_best_n_eval = int(c["n_best"])
     GP.optz_n_x0 = 3
@@ -117,6 +117,9 @@ def test_optz_hp_flow_matches_reference(path):
         assert np.isclose(hv.varK, c[f"it{it}_varK"], rtol=5e-3)
         assert np.isclose(hv.beta[0], c[f"it{it}_beta"][0], rtol=1e-3, atol=1e-6 * max(1.0, abs(c[f"it{it}_beta"][0])))
         assert GP.hp_optz_success[it] == c[f"it{it}_success"]
+        if str(c.get("wellcond", "precon")) != "precon":       # SLSQP ran with the condition-number constraint
+            assert GP.hp_optz_con_good[it] == c["con_good_hist"][it]
+            assert np.isclose(GP.Kcov_cond_all[it], c["cond_hist"][it], rtol=1e-3) and GP.Kcov_cond_all[it] <= 1.01 * GP.cond_max
     GP.set_hpara('stored', 1)
     np.testing.assert_allclose(GP.hp_vals.theta, GP.hp_theta_all[1])
 
