@@ -471,8 +471,15 @@ class GaussianProcess(HparaOptz):
         if rc < 0:
             raise _lib.GpgError(f'gpg_lkd failed ({rc}): {self._err()}')
         if rc > 0:
-            # CalcLkd.py:308-311 / 330-333: the reference reports the SVD condition number here; not computed
-            return LkdInfo(cond=np.nan), False
+            # CalcLkd.py:308-311 / 330-333: the reference reports np.linalg.cond(Kcov, 2) of the matrix that could not be
+            # factorised.  No factor -> no Lanczos through it: the matrix is downloaded and the SVD done on the host, for
+            # moderate sizes only (this branch is the failure path, not the hot path); NaN above that.
+            cond_fail = np.nan
+            if self.n_data <= 4096:
+                Kc = np.empty((self.n_data, self.n_data))
+                if self._lib.gpg_get_matrix(self._ctx, C.byref(hp), 1, _lib.as_dp(Kc)) == 0:
+                    cond_fail = float(np.linalg.cond(Kc, p=2))
+            return LkdInfo(cond=cond_fail), False
         cond = cond_grad = None
         if calc_cond:
             if calc_grad and self.wellcond_mtd != 'precon':          # GpHparaCon.py:171-173: no gradient with 'precon'
