@@ -268,6 +268,18 @@ __device__ __forceinline__ void wave_tile_gemm(d4 (&acc)[4], const double* ga, i
       GPG_QS2_STEP(x0, x1, Ls, sdinv, q, 3)                                                  \
     }                                                                                       \
   }
+// one 16-column piece of GPG_QUAD_SUBST2 (see GPG_QUAD_SUBST_PIECE)
+#define GPG_QUAD_SUBST2_PIECE(x0, x1, Ls, sdinv, q, s)                                       \
+  {                                                                                         \
+    double lv[2][16];                                                                       \
+    _Pragma("unroll") for (int m = 0; m < 16; ++m) lv[0][m] = Ls[16 * (s)][q][m];            \
+    _Pragma("unroll") for (int mj = 4 * (s); mj < 4 * (s) + 4; ++mj) {                       \
+      GPG_QS2_STEP(x0, x1, Ls, sdinv, q, 0)                                                  \
+      GPG_QS2_STEP(x0, x1, Ls, sdinv, q, 1)                                                  \
+      GPG_QS2_STEP(x0, x1, Ls, sdinv, q, 2)                                                  \
+      GPG_QS2_STEP(x0, x1, Ls, sdinv, q, 3)                                                  \
+    }                                                                                       \
+  }
 #define GPG_QS2_STEP(x0, x1, Ls, sdinv, q, QJ)                                               \
   {                                                                                         \
     constexpr int cur = QJ & 1, nxt = cur ^ 1;                                               \

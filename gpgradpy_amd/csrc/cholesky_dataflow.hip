@@ -167,14 +167,14 @@ tile_chol_kernel(double* A, int ld, int c0, int Mt, const int* __restrict__ task
 // after its 64-row solve), L22 (flag_b = the tile's completion flag): column block 0 of this tile is solved and the
 // MFMA update of block 1 runs while the diagonal tile is still in its second potrf64.
 __device__ __forceinline__ int tile_solve_rows128(const double* L, int ldl, const double* dinv, double* X, int ldx, double* U,
-                                                  double (*Ls)[4][18], double* sdinv, int* flag_a, int* flag_c, int* flag_b,
+                                                  double (*Ls)[4][18], double* sdinv, int* pa, int* flag_c, int* pb,
                                                   int* abort_word, int* info, int* sh) {
   constexpr int SA = 80, BUF = 16 * SA;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
   const int q = tid & 3, rr = tid >> 2;
   const int sp = tid & 31, sk = tid >> 5;
-  double x0[16], x1[16], li[16];
+  double x0[16], x1[16];
   // ---- column block 0 ----------------------------------------------------------------------------------------
   {
     const double* Xr = X + rr + (size_t)q * ldx;     // own rows: in flight while the flag is polled
@@ -183,15 +183,24 @@ __device__ __forceinline__ int tile_solve_rows128(const double* L, int ldl, cons
       x0[m] = Xr[(size_t)(4 * m) * ldx];
       x1[m] = Xr[64 + (size_t)(4 * m) * ldx];
     }
-    if (!wg_wait_flag(flag_a, abort_word, info, sh)) return 0;
-    for (int t = tid; t < 64 * 64; t += 256) {
-      const int jj = t >> 6, k = t & 63;
-      Ls[jj][k & 3][k >> 2] = L[k + (size_t)jj * ldl];
-    }
-    if (tid < 64) sdinv[tid] = dinv[tid];
   }
-  __syncthreads();
-  GPG_QUAD_SUBST2(x0, x1, Ls, sdinv, q)
+  // L11 arrives in four 16-column pieces (pa[0..3]) while the diagonal tile is still in its first potrf64
+#define GPG_T128_PIECE(FL, LP, DOFF, S)                                                      \
+  {                                                                                         \
+    if (!wg_wait_flag((FL) + (S), abort_word, info, sh)) return 0;                           \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                          \
+      const int t = tid + 256 * u, jj = 16 * (S) + (t >> 6), k = t & 63;                     \
+      Ls[jj][k & 3][k >> 2] = (LP)[k + (size_t)jj * ldl];                                    \
+    }                                                                                       \
+    if (tid < 16) sdinv[16 * (S) + tid] = dinv[(DOFF) + 16 * (S) + tid];                     \
+    __syncthreads();                                                                        \
+    GPG_QUAD_SUBST2_PIECE(x0, x1, Ls, sdinv, q, S)                                           \
+    _Pragma("unroll") for (int m = 0; m < 16; ++m) { asm volatile("" : "+v"(x0[m])); asm volatile("" : "+v"(x1[m])); } \
+  }
+  GPG_T128_PIECE(pa, L, 0, 0)
+  GPG_T128_PIECE(pa, L, 0, 1)
+  GPG_T128_PIECE(pa, L, 0, 2)
+  GPG_T128_PIECE(pa, L, 0, 3)
   {
     double* Xr = X + rr + (size_t)q * ldx;
 #pragma unroll
@@ -228,23 +237,14 @@ __device__ __forceinline__ int tile_solve_rows128(const double* L, int ldl, cons
     }
     __syncthreads();   // tile consumed before the next pass stages into U again
   }
-  if (!wg_wait_flag(flag_b, abort_word, info, sh)) return 0;
-  {   // image of L22
+  {   // L22 in four pieces (pb[0..3]) while the diagonal tile is in its second potrf64
     const double* L22 = L + 64 + (size_t)64 * ldl;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int t = tid + 256 * i;
-      li[i] = L22[(t & 63) + (size_t)(t >> 6) * ldl];
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int t = tid + 256 * i, jj = t >> 6, k = t & 63;
-      Ls[jj][k & 3][k >> 2] = li[i];
-    }
-    if (tid < 64) sdinv[tid] = dinv[64 + tid];
+    GPG_T128_PIECE(pb, L22, 64, 0)
+    GPG_T128_PIECE(pb, L22, 64, 1)
+    GPG_T128_PIECE(pb, L22, 64, 2)
+    GPG_T128_PIECE(pb, L22, 64, 3)
   }
-  __syncthreads();
-  GPG_QUAD_SUBST2(x0, x1, Ls, sdinv, q)
+#undef GPG_T128_PIECE
   {
     double* Xr = X + rr + (size_t)(64 + q) * ldx;
 #pragma unroll
@@ -263,7 +263,7 @@ __shared__ __attribute__((aligned(16))) double t128_U[4 * 16 * 80];   // staging
 __shared__ __attribute__((aligned(16))) double t128_Ls[64][4][18];    // diagonal-block image / potrf scratch
 __shared__ double t128_sdinv[64];
 
-__device__ __noinline__ int tile128_finalize(double* A, int ld, size_t r0, size_t cj, int is_diag, int* flag_jj, int* flag_a,
+__device__ __noinline__ int tile128_finalize(double* A, int ld, size_t r0, size_t cj, int is_diag, int* pa, int* pb,
                                              int* flag_c, int* abort_word, double* dinv, int* info, int N) {
   constexpr int SA = 80;
   double* const U = t128_U;
@@ -283,10 +283,8 @@ __device__ __noinline__ int tile128_finalize(double* A, int ld, size_t r0, size_
     double* blk = A + cj + cj * (size_t)ld;
     double (*St)[64] = reinterpret_cast<double(*)[64]>(&Ls[0][0][0]);   // potrf scratch over the Ls region
     if (w == 0) {   // A11 was left in the LDS tile by this same wave (no barrier, no trip through memory)
-      const int bad = potrf64_wave(U, SA, St, blk, ld, dinv + cj);
+      const int bad = potrf64_wave(U, SA, St, blk, ld, dinv + cj, pa);   // L11 published in 16-column pieces pa[0..3]
       if (bad && lane == 0 && (int)cj + bad - 1 < N) atomicCAS(info, 0, (int)cj + bad);
-      GPG_RELEASE();   // L11 and its reciprocal pivots (all written by this wave) are published early
-      if (lane == 0) GPG_FLAG_UP(flag_a);
     }
     __syncthreads();   // also drains the other waves' stores of A21 / A22
     GPG_FS(1)
@@ -314,7 +312,7 @@ __device__ __noinline__ int tile128_finalize(double* A, int ld, size_t r0, size_
     __syncthreads();
     GPG_FS(3)
     if (w == 0) {
-      const int bad = potrf64_wave(U, SA, St, blk + 64 + (size_t)64 * ld, ld, dinv + cj + 64);
+      const int bad = potrf64_wave(U, SA, St, blk + 64 + (size_t)64 * ld, ld, dinv + cj + 64, pb);   // L22: pb[0..3]
       if (bad && lane == 0 && (int)cj + 64 + bad - 1 < N) atomicCAS(info, 0, (int)cj + 64 + bad);
     }
     GPG_FS(4)
@@ -323,7 +321,7 @@ __device__ __noinline__ int tile128_finalize(double* A, int ld, size_t r0, size_
   GPG_FS(1)
   const double* Ljj = A + cj + cj * (size_t)ld;
   double* X = A + r0 + cj * (size_t)ld;
-  if (!tile_solve_rows128(Ljj, ld, dinv + cj, X, ld, U, Ls, sdinv, flag_a, flag_c, flag_jj, abort_word, info, &sh_ok)) return 0;
+  if (!tile_solve_rows128(Ljj, ld, dinv + cj, X, ld, U, Ls, sdinv, pa, flag_c, pb, abort_word, info, &sh_ok)) return 0;
   GPG_FS(2)
   GPG_FS(3)
   return 1;
@@ -436,7 +434,8 @@ tile128_chol_kernel(double* A, int ld, int Mt, const int* __restrict__ tasks, in
         }
   }
   if (ti != tj) __syncthreads();
-  if (tile128_finalize(A, ld, r0, cj, ti == tj, frow_j + tj, flag_a + tj, flag_a + Mt + tj, abort_word, dinv, info, N) == 0) return;
+  if (tile128_finalize(A, ld, r0, cj, ti == tj, flag_a + 4 * tj, flag_a + 4 * Mt + 4 * tj, flag_a + 8 * Mt + tj, abort_word, dinv, info,
+                       N) == 0) return;
   // ---- (3) publish ----------------------------------------------------------------------------------------------
   GPG_RELEASE();
   __syncthreads();
@@ -828,7 +827,7 @@ static void launch_tile128_chol(gpg_ctx* c) {
   const int Mt = c->Npad / 128, Rt = c->ld / 128;
   const TileMap& tm = get_tile_tasks(c, Mt, Rt);
   if (!tm.dev) return;
-  const size_t nflag = (size_t)Mt * Rt + 1 + 2 * Mt;   // tile flags, abort word, two early flags per diagonal tile
+  const size_t nflag = (size_t)Mt * Rt + 1 + 9 * (size_t)Mt;   // tile flags, abort word, 4 + 4 piece flags and the L21 flag per diagonal tile
   if (!ensure_tile_flags(c, nflag)) return;
   (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
   const double m = (double)c->Npad;
@@ -859,7 +858,7 @@ static void launch_tile128_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a
     it = c->tilemaps.emplace(key, tm).first;
   }
   const TileMap& tm = it->second;
-  const size_t per = (size_t)Mt * Rt + 1 + 2 * (size_t)Mt, nflag = per * B;
+  const size_t per = (size_t)Mt * Rt + 1 + 9 * (size_t)Mt, nflag = per * B;
   if (!ensure_tile_flags(c, nflag)) return;
   (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
   const double m = (double)c->Npad;
