@@ -163,9 +163,10 @@ tile_chol_kernel(double* A, int ld, int c0, int Mt, const int* __restrict__ task
 //     publish: __threadfence, flag(i, j) = 1 (agent-scope release)
 // Progress argument and bounded waits as in tile_chol_kernel.
 // ------------------------------------------------------------------------------------------------
-// The diagonal tile publishes its pieces as they are final -- L11 (flag_a, after the first potrf64), L21 (flag_c,
-// after its 64-row solve), L22 (flag_b = the tile's completion flag): column block 0 of this tile is solved and the
-// MFMA update of block 1 runs while the diagonal tile is still in its second potrf64.
+// The diagonal tile publishes its pieces as they are final -- L11 in four 16-column pieces (pa[0..3], while its first
+// potrf64 is still running), L21 (flag_c, after its 64-row solve), L22 in four pieces (pb[0..3]): every column block of
+// this tile is substituted piece by piece, and the MFMA update of block 1 runs while the diagonal tile is still in its
+// second potrf64.
 __device__ __forceinline__ int tile_solve_rows128(const double* L, int ldl, const double* dinv, double* X, int ldx, double* U,
                                                   double (*Ls)[4][18], double* sdinv, int* pa, int* flag_c, int* pb,
                                                   int* abort_word, int* info, int* sh) {
@@ -328,7 +329,7 @@ __device__ __noinline__ int tile128_finalize(double* A, int ld, size_t r0, size_
 }
 
 __global__ void __launch_bounds__(256, 2)
-tile128_chol_kernel(double* A, int ld, int Mt, const int* __restrict__ tasks, int* flags, int* flag_a, int* abort_word,
+tile128_chol_kernel(double* A, int ld, int Mt, const int* __restrict__ tasks, int* flags, int* early /* pa | pb | flag_c */, int* abort_word,
                     double* __restrict__ dinv, int* __restrict__ info, int N, const int* __restrict__ batch_of, size_t a_stride,
                     int d_stride, int f_stride) {
   __shared__ int sh_kr;
@@ -343,7 +344,7 @@ tile128_chol_kernel(double* A, int ld, int Mt, const int* __restrict__ tasks, in
     dinv += (size_t)b * d_stride;
     info += b;
     flags += (size_t)b * f_stride;
-    flag_a += (size_t)b * f_stride;
+    early += (size_t)b * f_stride;
   }
   const size_t r0 = 128 * (size_t)ti, cj = 128 * (size_t)tj;
   int* const frow_i = flags + (size_t)ti * Mt;
@@ -434,7 +435,7 @@ tile128_chol_kernel(double* A, int ld, int Mt, const int* __restrict__ tasks, in
         }
   }
   if (ti != tj) __syncthreads();
-  if (tile128_finalize(A, ld, r0, cj, ti == tj, flag_a + 4 * tj, flag_a + 4 * Mt + 4 * tj, flag_a + 8 * Mt + tj, abort_word, dinv, info,
+  if (tile128_finalize(A, ld, r0, cj, ti == tj, early + 4 * tj, early + 4 * Mt + 4 * tj, early + 8 * Mt + tj, abort_word, dinv, info,
                        N) == 0) return;
   // ---- (3) publish ----------------------------------------------------------------------------------------------
   GPG_RELEASE();
