@@ -393,6 +393,39 @@ def test_ratqu_against_oracle_and_batched_rows():
         assert abs(g[k] - fd) <= 1e-4 * abs(fd) + 1e-6 * np.abs(g).max(), (k, g[k], fd)
 
 
+def test_ratqu_with_gradient_mask_against_oracle():
+    """bvec_use_grad with the rational quadratic kernel: the reference's own posterior fails there (KernelRatQuad.py:497-499,
+    no fixture), so the device is compared with the oracle, whose mask handling is pinned by the SqExp / Matern mask
+    fixtures and whose RatQu kernel by the RatQu fixtures."""
+    import gpgradpy_amd
+    from oracle import gp_oracle as orc
+    n, d = 90, 3
+    X, f, g = orc.synthetic_design(n, d, seed=8)
+    rng = np.random.default_rng(9)
+    mask = rng.random(n) > 0.4
+    mask[0], mask[-1] = True, False
+    GP = gpgradpy_amd.GaussianProcess(d, True, 'RatQu', 'precon')
+    GP.set_data(X, f, np.zeros(n), g[mask], np.zeros((int(mask.sum()), d)), mask)
+    theta, al = np.array([0.05, 0.3, 0.01]), 1.4
+    hp = GP.make_hp_class(theta=theta, kernel=al)
+    info, ok = GP.calc_lkd_all(hp)
+    y = orc.make_data_vec(f, g[mask])
+    nv = orc.calc_noise_vec(n, d, True, np.zeros(n), np.zeros((int(mask.sum()), d)), n_grad=int(mask.sum()))
+    r = orc.calc_lkd(X, y, theta, ("RatQu", al), True, "precon", GP._etaK, nv, False, grad_mask=mask)
+    assert ok and r.ok and y.size == GP.n_data
+    ref = dict(hp_beta=r.hp_beta, hp_varK=r.hp_varK, ln_det_Kmat=r.ln_det_Kmat, ln_lkd=r.ln_lkd)
+    tol.check_scalars(info.hp_beta[0], info.hp_varK, info.ln_det_Kmat, info.ln_lkd, ref, y.size, False)
+    hp2 = GP.optz_closed_form_hp(hp)
+    GP.set_hpara('set', 0, hp_vals=hp2)
+    m = orc.setup_eval_model(X, y, theta, ("RatQu", al), True, "precon", GP._etaK, nv, r.hp_beta, hp2.varK, mask)
+    xq = rng.uniform(-2, 2, (9, d))
+    mu, sig, dmu, dsig = GP.eval_model(xq, calc_grad=True)[:4]
+    mu_o, sig_o, dmu_o, dsig_o = orc.eval_model_grad(m, xq)
+    np.testing.assert_allclose(mu, mu_o, rtol=tol.MU_RTOL, atol=tol.MU_ATOL_SCALE * max(1.0, np.abs(mu_o).max()))
+    np.testing.assert_allclose(sig, sig_o, rtol=tol.SIG_RTOL, atol=tol.SIG_ATOL_SCALE * np.sqrt(hp2.varK))
+    tol.check_post_grad(dmu, dsig, dict(dmudx=dmu_o, dsigdx=dsig_o))
+
+
 def test_many_query_points_split_over_launches():
     """More query points than one dataflow solve launch takes (row tiles x column blocks > 4096): the backward sweep of
     the posterior gradients is split over several launches; the result must equal the same points evaluated in
