@@ -5,12 +5,14 @@ n=2000, d=8 (K is 18000 x 18000), fp64, on N MI355X of one node (BASELINE.json m
 A "step" is one likelihood evaluation (assembly + preconditioner + nugget + Cholesky + GLS mean +
 ln det + r'K^-1 r) of one restart row on each GPU; the data set is resident in HBM before the timed
 region (set_data excluded).  Multi-GPU is weak scaling over independent restart rows
-(SURVEY.md 8e): every rank evaluates `steps` rows of the shared restart table on its own device, then
-ONE all_gather (RCCL) of the ln_lkd values selects the best row -- no data-path collective.
+(SURVEY.md 8e): the global restart table has `steps` rows per rank, `select_best_restart` (the product's
+own sharding function) gives every rank its contiguous block, each rank evaluates it on its own device,
+then ONE all_gather (RCCL) of the ln_lkd values selects the best row -- no data-path collective.
 
     python bench.py --gpus 1 --steps 8 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus 1 --force-dist      # one rank, but through torch.distributed / RCCL like N > 1
 """
 import argparse
 import json
@@ -27,14 +29,12 @@ if ROOT not in sys.path:
 FP64_MFMA_PEAK_TFLOPS = 78.6   # v_mfma_f64_16x16x4_f64: 64 cycles / instr / SIMD measured (profiles/r01_fp64_pipe_probe.log)
                                # = 32 flop/clk/SIMD x 1024 SIMDs x 2.4 GHz; equals AMD's datasheet FP64 matrix figure
 HBM_PEAK_GBS = 8000.0
-# HBM bytes per launch of the dominant kernel at n=2000, d=8 (tile128_chol_kernel: ONE launch per evaluation) from
-# the PMC passes of profiles/r01_d_pmc_summary.txt (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes
-# over this same command, 2 evaluations = 2 launches): WRITE_SIZE 7.10 GB / 2; FETCH_SIZE 114.96 GB / 2 raw,
-# doubled per MI355X_MICROARCH.md (gfx950 counts wide streamed reads at half their bytes).  The left-looking
-# tile sweep reads 2 x 128 x K x 8 B of finished columns per 128 x 128 tile: 128 GB per factorisation, i.e. the
-# measured traffic is that operand stream with almost no L2 reuse between tiles (L2 hit 33 %); the matrix itself
-# (1.3 GB) is read and written once.
-PMC_TRAFFIC_BYTES_PER_LAUNCH_CFG3 = (2 * 114.96e9 + 7.10e9) / 2.0
+PARITY_RTOL = 1e-8             # ln_lkd of row 0 against the CPU oracle (tests/tolerances.py LN_LKD_RTOL)
+# HBM traffic of the dominant kernel: NOT a constant of this file.  tools/pmc_collect.sh runs this very command under
+# rocprofv3 --pmc (FETCH_SIZE and WRITE_SIZE in separate passes) and tools/pmc_summarize.py writes the per-launch
+# figures (FETCH_SIZE doubled per MI355X_MICROARCH.md: gfx950 counts wide streamed reads at half their bytes) into
+# this file, keyed by config and matrices per launch; `roofline.traffic` is read from it, or null when no entry matches.
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
 
 def make_workload(n, d, cfg="cfg3"):
@@ -59,47 +59,96 @@ def make_workload(n, d, cfg="cfg3"):
     return X, f, g, hp_table
 
 
-def cpu_baseline(n, d, X, f, g, theta, threads=16):
+def host_description():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.lower().startswith("model name"):
+                    model = ln.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"nproc": os.cpu_count(), "cpu_model": model}
+
+
+def cpu_baseline(cfg, n, d, kernel, X, f, g, hp_row, threads=16):
     """Oracle (NumPy/SciPy port of the reference's CPU path) timed on this box's host cores, rank 0, N=1.
-    (1) full-size evaluation with element-wise preconditioner scaling + LAPACK dpotrf/dpotrs -- the
-        best-practice CPU path, reported as `value` so the GPU/CPU ratio is not inflated by (2);
+    (1) evaluation with element-wise preconditioner scaling + LAPACK dpotrf/dpotrs -- the best-practice CPU
+        path, reported as `value` so the GPU/CPU ratio is not inflated by (2); at full size for cfg2 / cfg3, on a
+        bounded sample extrapolated with N^3 for cfg5 (N = 68000 does not finish in the budget of a bench run);
     (2) the reference as written (five dense diag-matrix GEMMs, Kernel.py:224-252) on a bounded sample,
-        extrapolated with N^3."""
+        extrapolated with N^3.
+    Returns (record, oracle result of the full-size evaluation or None)."""
     from oracle import gp_oracle as orc
     try:
         from threadpoolctl import threadpool_limits
         limiter = threadpool_limits(limits=threads)
     except Exception:  # pragma: no cover
         limiter = None
-    y = orc.make_data_vec(f, g)
-    N = y.size
-    eb, eta = orc.calc_nugget(n, d, "SqExp", True, "precon")
-    # warm BLAS threads
-    Xs, fs, gs = X[:64], f[:64], g[:64]
-    orc.calc_lkd(Xs, orc.make_data_vec(fs, gs), theta, "SqExp", True, "precon", eta, np.zeros(64 * (d + 1)), False)
-    t0 = time.perf_counter()
-    r = orc.calc_lkd(X, y, theta, "SqExp", True, "precon", eta, np.zeros(N), False)
-    t_best = time.perf_counter() - t0
-    ns = 500
-    Ns = ns * (d + 1)
-    Xs, fs, gs = X[:ns], f[:ns], g[:ns]
-    ys = orc.make_data_vec(fs, gs)
-    _, eta_s = orc.calc_nugget(ns, d, "SqExp", True, "precon")
-    t0 = time.perf_counter()
-    orc.calc_lkd(Xs, ys, theta, "SqExp", True, "precon", eta_s, np.zeros(Ns), False, as_written=True)
-    t_aw = time.perf_counter() - t0
-    scale = (N / Ns) ** 3
-    if limiter is not None:
-        limiter.unregister() if hasattr(limiter, "unregister") else None
-    return {
-        "value": 1.0 / t_best, "unit": "evals/s", "cores": threads, "kind": "port",
-        "sample": f"1 full-size evaluation (n={n}, d={d}, N={N}) of oracle/gp_oracle.py with element-wise "
-                  f"preconditioner scaling + LAPACK dpotrf/dpotrs: {t_best:.2f} s",
-        "as_written_value": 1.0 / (t_aw * scale),
-        "as_written_sample": f"reference-as-written path (dense diag GEMMs, Kernel.py:224-252) at n={ns} "
-                             f"(N={Ns}): {t_aw:.2f} s, extrapolated x(N/Ns)^3 = {scale:.0f}",
-        "ln_lkd_cpu": r.ln_lkd,
-    }, r
+    noisy = cfg == "cfg5"
+
+    def one(ns, as_written=False, reps=1):
+        Xs, fs, gs = X[:ns], f[:ns], g[:ns]
+        ys = orc.make_data_vec(fs, gs)
+        Ns = ys.size
+        _, eta = orc.calc_nugget(ns, d, kernel, True, "precon")
+        theta = 10.0 ** hp_row[:d]
+        if noisy:
+            nv = orc.calc_noise_vec(ns, d, True, np.full(ns, 1e-2), np.full((ns, d), 1e-1), None, None)
+            kw = dict(varK=10.0 ** hp_row[d])
+        else:
+            nv, kw = np.zeros(Ns), {}
+        best, r = np.inf, None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            r = orc.calc_lkd(Xs, ys, theta, kernel, True, "precon", eta, nv, noisy, as_written=as_written, **kw)
+            best = min(best, time.perf_counter() - t0)
+        return best, r, Ns
+
+    one(64)                                                     # warm the BLAS threads
+    N = n * (d + 1)
+    if cfg == "cfg5":
+        ns_full = 500                                           # N = 8500: ~2 s
+        t_best, r, Ns = one(ns_full)
+        scale = (N / Ns) ** 3
+        value = 1.0 / (t_best * scale)
+        sample = (f"bounded sample n={ns_full} (N={Ns}) of the {kernel} noisy workload with element-wise preconditioner "
+                  f"scaling + LAPACK dpotrf/dpotrs: {t_best:.2f} s, extrapolated x(N/Ns)^3 = {scale:.0f}")
+        r_full = None
+    else:
+        t_best, r_full, _ = one(n, reps=3 if cfg == "cfg2" else 1)
+        value = 1.0 / t_best
+        sample = (f"{'best of 3' if cfg == 'cfg2' else '1'} full-size evaluation(s) (n={n}, d={d}, N={N}) of oracle/gp_oracle.py with "
+                  f"element-wise preconditioner scaling + LAPACK dpotrf/dpotrs: {t_best:.3f} s")
+    ns_aw = min(n, 500)
+    t_aw, _, Ns_aw = one(ns_aw, as_written=True)
+    scale_aw = (N / Ns_aw) ** 3
+    if limiter is not None and hasattr(limiter, "unregister"):
+        limiter.unregister()
+    rec = {"value": value, "unit": "evals/s", "cores": threads, "kind": "port", "sample": sample,
+           "as_written_value": 1.0 / (t_aw * scale_aw),
+           "as_written_sample": f"reference-as-written path (dense diag GEMMs, Kernel.py:224-252) at n={ns_aw} "
+                                f"(N={Ns_aw}): {t_aw:.2f} s" + (f", extrapolated x(N/Ns)^3 = {scale_aw:.0f}" if scale_aw > 1.0 else ""),
+           "blas_threads": threads}
+    rec.update(host_description())
+    if r_full is not None:
+        rec["ln_lkd_cpu"] = r_full.ln_lkd
+    return rec, r_full
+
+
+def pmc_traffic(cfg, mats_per_launch, kernel_name):
+    """Per-launch HBM bytes of the dominant kernel from the tracked PMC summary (or None)."""
+    try:
+        with open(PMC_SUMMARY) as fh:
+            table = json.load(fh)
+    except (OSError, ValueError):
+        return None, None
+    for e in table.get("entries", []):
+        if e.get("config") == cfg and int(e.get("matrices_per_launch", -1)) == int(mats_per_launch) \
+                and e.get("kernel", "").split("(")[0].strip() == kernel_name.split("(")[0].strip():
+            return float(e["traffic_bytes_per_launch"]), e.get("source")
+    return None, None
 
 
 def main():
@@ -118,11 +167,17 @@ def main():
     ap.add_argument("--batch", type=int, default=-1, help="restart rows per batched launch on small matrices (gpg_set_batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--prof-all", action="store_true", help="time every kernel category (adds event overhead)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed even for one rank: the N > 1 code path (RCCL init, sharded selection, "
+                         "device-tensor all_gather) on a single GPU")
+    ap.add_argument("--backend", default="auto", choices=["auto", "nccl", "gloo"],
+                    help="auto: nccl (RCCL) with one rank per GPU, gloo when there are more ranks than GPUs (rehearsal)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     import gpgradpy_amd
+    from gpgradpy_amd import multistart
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -136,16 +191,24 @@ def main():
         print("[bench] no GPU visible: the product path has no CPU fallback", file=sys.stderr)
         sys.exit(3)
     ndev = torch.cuda.device_count()
+    # one rank per GPU -> RCCL ("nccl"); more ranks than GPUs (a rehearsal on a 1-GPU box) -> gloo on host tensors
+    backend = args.backend if args.backend != "auto" else ("nccl" if world <= ndev else "gloo")
+    if backend == "nccl" and local_rank >= ndev:
+        print(f"[bench] LOCAL_RANK={local_rank} but only {ndev} GPU(s) visible: RCCL needs one GPU per rank "
+              f"(use --backend gloo to rehearse more ranks than GPUs)", file=sys.stderr)
+        sys.exit(4)
     dev_index = local_rank % ndev
     torch.cuda.set_device(dev_index)
-    # one rank per GPU -> RCCL ("nccl"); more ranks than GPUs (a rehearsal on a 1-GPU box) -> gloo on host tensors
-    backend = "nccl" if world <= ndev else "gloo"
+    use_dist = world > 1 or args.force_dist
     coll_dev = torch.device("cuda", dev_index) if backend == "nccl" else torch.device("cpu")
-    if world > 1:
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+    group = dist.group.WORLD if use_dist else None
 
     n0, d0 = {"cfg2": (500, 4), "cfg3": (2000, 8), "cfg5": (4000, 16)}[args.config]
     n, d = args.n or n0, args.d or d0
@@ -170,50 +233,58 @@ def main():
         "tile64": "tile_chol_kernel (whole Cholesky as one dataflow launch, 64x64 tiles, left-looking)",
         "tile128": "tile128_chol_kernel (whole Cholesky as one dataflow launch, 128x128 tiles, left-looking)"}
 
-    # rank r owns rows [8r, 8r+8) of the 64-row table (BASELINE cfg4), cycled when steps > 8
-    def rows_for(k):
-        idx = [(8 * rank + i) % hp_table.shape[0] for i in range(k)]
+    # global restart table of the run: rank r's block is rows [8r, 8r+8) of the 64-row table (BASELINE cfg4: 8 per GPU),
+    # cycled when steps > 8; shard_rows(world * k, world, r) hands rank r exactly its block
+    def table_for(k):
+        idx = [(8 * r + i) % hp_table.shape[0] for r in range(world) for i in range(k)]
         return hp_table[idx]
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     GP.reserve_batch(args.steps)                                  # setup (like set_data): workspaces of the batched launches
     if args.warmup > 0:
-        GP.calc_lkd_batch(rows_for(args.warmup))
+        multistart.select_best_restart(table_for(args.warmup), GP.calc_lkd_batch, group=group, device=coll_dev if use_dist else None)
     cats = list(gpgradpy_amd._lib.PROF_CATS) if args.prof_all else ["gemm_trail", "assembly"]
     GP.prof_enable(cats)
     GP.prof_read()
+    local_s = [0.0]
+
+    def timed_eval(rows):                                         # this rank's share: K evaluations queued back-to-back, one sync
+        t = time.perf_counter()
+        out = GP.calc_lkd_batch(rows)
+        local_s[0] = time.perf_counter() - t
+        return out
+
     barrier()
     t0 = time.perf_counter()
-    ln_local = GP.calc_lkd_batch(rows_for(args.steps))           # K evaluations queued back-to-back, one sync
-    if world > 1:                                                # the single collective: gather ln_lkd, pick best
-        buf = torch.from_numpy(ln_local).to(coll_dev)
-        out = [torch.empty_like(buf) for _ in range(world)]
-        dist.all_gather(out, buf)
-        ln_all = torch.cat(out).cpu().numpy()
-    else:
-        ln_all = ln_local
+    # the product's own sharded selection: local block on this device, then the single collective + nanargmax
+    _, ln_all, best = multistart.select_best_restart(table_for(args.steps), timed_eval, group=group,
+                                                     device=coll_dev if use_dist else None)
     barrier()
     elapsed = time.perf_counter() - t0
-    best = int(np.nanargmax(ln_all))
+    collective_ms = multistart.last_collective_s * 1e3 if use_dist else 0.0
     dom_kernel = DOM_KERNELS[GP.last_factor()[0]]                # what the library actually launched
     prof = GP.prof_read()
     GP.prof_enable([])
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+    per_rank_ms = [local_s[0] * 1e3, local_s[0] * 1e3]
+    if use_dist:
+        t = torch.tensor([elapsed, local_s[0], -local_s[0], collective_ms], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, collective_ms = float(t[0].item()), float(t[3].item())
+        per_rank_ms = [-float(t[2].item()) * 1e3, float(t[1].item()) * 1e3]      # [min, max] over ranks of the local evaluation time
 
+    rc = 0
     if rank == 0:
         tr = prof["gemm_trail"]
         achieved = tr["work"] / (tr["ms"] * 1e-3) * 1e-12 if tr["ms"] > 0 else 0.0
-        # restart rows are batched into one factorisation launch (gpg_set_batch): flops per launch = B x Npad^3 / 3
-        mats_per_launch = int(round(tr["work"] / max(1, tr["count"]) / (Npad ** 3 / 3.0))) if tr["count"] else 1
+        # restart rows are batched into one factorisation launch (gpg_set_batch): flops per launch = B x N^3 / 3
+        mats_per_launch = int(round(tr["work"] / max(1, tr["count"]) / (N ** 3 / 3.0))) if tr["count"] else 1
         asm = prof["assembly"]
+        traffic, traffic_src = pmc_traffic(args.config, mats_per_launch, dom_kernel)
         result = {
             "metric": "marginal-likelihood evals/sec (grad-enh, n=2000 d=8)" if (n, d, args.config) == (2000, 8, "cfg3")
                       else f"marginal-likelihood evals/sec (grad-enh, n={n} d={d}, {args.config})",
@@ -224,34 +295,41 @@ def main():
                                    + ("known noise on f and grad f (varK a hyperparameter), " if args.config == "cfg5" else "noise-free, ")
                                    + "precon + nugget, value-only likelihood evaluation per restart row "
                                    "(rows of the BASELINE.md section 3 restart table, 8 per rank)",
-                       "n": n, "d": d, "N": N, "kernel": kernel, "wellcond": "precon",
-                       "evals_per_gpu": args.steps, "parallelism": f"restarts sharded over {world} rank(s), one all_gather ({backend if world > 1 else 'none'})"},
+                       "n": n, "d": d, "N": N, "Npad": Npad, "kernel": kernel, "wellcond": "precon",
+                       "evals_per_gpu": args.steps, "collective_backend": backend if use_dist else "none",
+                       "parallelism": f"restarts sharded over {world} rank(s), one all_gather ({backend if use_dist else 'none'})"},
+            "per_rank_ms": per_rank_ms, "collective_ms": collective_ms,
             "roofline": {"bound": "mfma", "kernel": dom_kernel,
                          "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
                          "matrices_per_launch": mats_per_launch,
-                         "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH_CFG3 * mats_per_launch
-                                    if (n, d, args.config, args.factor_mode) == (2000, 8, "cfg3", "auto") else None,
-                         "traffic_unit": "bytes/launch = matrices per launch x the single-matrix PMC figure (FETCH_SIZE x2 + "
-                                         "WRITE_SIZE, profiles/r01_d_pmc_summary.txt)",
+                         "traffic": traffic, "traffic_unit": "bytes/launch", "traffic_source": traffic_src,
                          "launches": tr["count"], "avg_launch_ms": tr["ms"] / max(1, tr["count"]),
-                         "algorithmic_flops": tr["work"],
+                         "algorithmic_flops": tr["work"], "algorithmic_flops_def": "matrices x N^3 / 3 (N, not the padded size)",
                          "share_of_step_time": tr["ms"] * 1e-3 / elapsed if elapsed > 0 else None},
             "assembly": {"bound": "hbm", "achieved": asm["work"] / (asm["ms"] * 1e-3) * 1e-9 if asm["ms"] > 0 else 0.0,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_ms": asm["ms"] / max(1, asm["count"])},
-            "best_row": best, "ln_lkd_best": float(ln_all[best]),
+            "best_row": int(best), "ln_lkd_best": float(ln_all[best]),
+            "factor_fallbacks": GP.factor_fallbacks(),
         }
         if args.prof_all:
             result["kernel_ms_per_eval"] = {c: prof[c]["ms"] / args.steps for c in prof}
-        if world == 1 and not args.no_cpu_baseline and args.config == "cfg3":
-            theta0 = 10.0 ** hp_table[0]
-            cb, r = cpu_baseline(n, d, X, f, g, theta0)
+        if world == 1 and not args.no_cpu_baseline:
+            cb, r = cpu_baseline(args.config, n, d, kernel, X, f, g, hp_table[0])
             result["cpu_baseline"] = cb
-            result["parity_ln_lkd_rel_err_row0"] = abs(ln_local[0] - r.ln_lkd) / abs(r.ln_lkd) if args.steps >= 1 else None
+            if r is not None and args.steps >= 1:
+                err = abs(ln_all[0] - r.ln_lkd) / abs(r.ln_lkd)
+                result["parity_ln_lkd_rel_err_row0"] = err
+                result["parity_rtol"] = PARITY_RTOL
+                if not (err <= PARITY_RTOL):
+                    print(f"[bench] PARITY FAILURE: ln_lkd of row 0 is {ln_all[0]!r} on the device, {r.ln_lkd!r} on the CPU oracle "
+                          f"(rel {err:.3e} > {PARITY_RTOL:g})", file=sys.stderr)
+                    rc = 5
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    sys.exit(rc)
 
 
 if __name__ == "__main__":

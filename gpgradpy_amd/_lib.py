@@ -18,7 +18,7 @@ PROF_NCAT = len(PROF_CATS)
 # every symbol include/gpgrad.h declares
 ABI_SYMBOLS = (
     "gpg_create", "gpg_destroy", "gpg_last_error", "gpg_set_grad_mask", "gpg_set_data", "gpg_lkd", "gpg_lkd_grad", "gpg_lkd_batch",
-    "gpg_setup_eval", "gpg_predict", "gpg_predict_grad", "gpg_predict_hess", "gpg_get_matrix", "gpg_factor_apply", "gpg_dcov_quadform", "gpg_prof_enable", "gpg_prof_read", "gpg_set_panel", "gpg_set_lookahead", "gpg_set_factor_mode", "gpg_factor_fallbacks", "gpg_last_factor", "gpg_set_batch", "gpg_reserve_batch",
+    "gpg_setup_eval", "gpg_predict", "gpg_predict_grad", "gpg_predict_var", "gpg_predict_hess", "gpg_get_matrix", "gpg_factor_apply", "gpg_dcov_quadform", "gpg_prof_enable", "gpg_prof_read", "gpg_set_panel", "gpg_set_lookahead", "gpg_set_factor_mode", "gpg_factor_fallbacks", "gpg_last_factor", "gpg_set_batch", "gpg_reserve_batch",
     "gpg_device_info",
 )
 
@@ -74,6 +74,8 @@ def load():
     lib.gpg_predict.restype = C.c_int
     lib.gpg_predict_grad.argtypes = [vp, C.c_int, dp, C.c_double, dp, dp, dp, dp, dp]
     lib.gpg_predict_grad.restype = C.c_int
+    lib.gpg_predict_var.argtypes = [vp, C.c_int, dp, C.c_double, dp, dp]
+    lib.gpg_predict_var.restype = C.c_int
     lib.gpg_predict_hess.argtypes = [vp, dp, C.c_double, dp, dp, dp, dp, dp, dp]
     lib.gpg_predict_hess.restype = C.c_int
     lib.gpg_get_matrix.argtypes = [vp, C.POINTER(GpgHp), C.c_int, dp]

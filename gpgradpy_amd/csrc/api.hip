@@ -48,6 +48,39 @@ static AsmParams make_params(const gpg_ctx* c, const gpg_hp* hp, int mode) {
   return p;
 }
 
+// ---- workspace sets ---------------------------------------------------------------------------------
+static void ws_park(gpg_ctx* c) {
+  gpg_ws& w = c->ws[c->ws_cur];
+  w.A = c->A; w.dvec = c->dvec; w.invp = c->invp; w.dinv = c->dinv; w.zvec = c->zvec; w.tmpv = c->tmpv;
+  w.factor_valid = c->factor_valid; w.prep_valid = c->prep_valid; w.precon = c->last_precon;
+}
+
+int gpg_ws_activate(gpg_ctx* c, int which) {
+  if (which == c->ws_cur) return 0;
+  ws_park(c);
+  gpg_ws& w = c->ws[which];
+  if (!w.A) {   // first gpg_setup_eval: a second workspace of the context's (full-gradient) shape
+    const size_t nv = sizeof(double) * (size_t)c->vec_rows_cols;
+    double** ptrs[] = {&w.dvec, &w.invp, &w.dinv, &w.zvec, &w.tmpv};
+    bool ok = hipMalloc(&w.A, sizeof(double) * c->A_elems) == hipSuccess;
+    for (double** q : ptrs) ok = ok && hipMalloc(q, nv) == hipSuccess;
+    ok = ok && hipMemsetAsync(w.A, 0, sizeof(double) * c->A_elems, c->stream) == hipSuccess;
+    if (!ok) {
+      (void)hipGetLastError();
+      if (w.A) (void)hipFree(w.A);
+      for (double** q : ptrs) if (*q) { (void)hipFree(*q); *q = nullptr; }
+      w = gpg_ws();
+      c->err = "out of device memory for the posterior's own factor workspace";
+      return -2;
+    }
+  }
+  c->A = w.A; c->dvec = w.dvec; c->invp = w.invp; c->dinv = w.dinv; c->zvec = w.zvec; c->tmpv = w.tmpv;
+  c->factor_valid = w.factor_valid; c->prep_valid = w.prep_valid; c->last_precon = w.precon;
+  c->ws_cur = which;
+  return 0;
+}
+#define GPG_WS(c, which) do { if (gpg_ws_activate((c), (which)) != 0) return -2; } while (0)
+
 static int check_hp(gpg_ctx* c, const gpg_hp* hp) {
   if (!c) return -1;
   if (!hp || !hp->theta) { c->err = "hp / hp->theta is NULL"; return -1; }
@@ -82,6 +115,8 @@ static int ensure_scal(gpg_ctx* c, int slots) {
 static void enqueue_lkd(gpg_ctx* c, const gpg_hp* hp, int slot) {
   AsmParams p = make_params(c, hp, 0);
   c->last_precon = p.precon;
+  c->prep_valid = true;
+  c->last_factor_ws = c->ws_cur;
   int* info_save = c->info;
   c->info = info_save + slot;   // potrf writes through c->info
   gpg_launch_prep(c, p, hp->var_fval, hp->var_fgrad, 1.0, 0.0, 0.0, 1.0);
@@ -169,7 +204,8 @@ int gpg_create(gpg_ctx** out, int device, int n_eval, int dim, int use_grad, int
   CREATE_OK(hipMalloc(&c->zvec, sizeof(double) * c->Npad));
   CREATE_OK(hipMalloc(&c->tmpv, sizeof(double) * c->Npad));
   CREATE_OK(hipMalloc(&c->dinv, sizeof(double) * c->Npad));
-  CREATE_OK(hipMemset(c->A, 0, sizeof(double) * (size_t)c->ld * c->Npad));
+  CREATE_OK(hipMemsetAsync(c->A, 0, sizeof(double) * (size_t)c->ld * c->Npad, c->stream));   // ordered on the context's own
+  CREATE_OK(hipStreamSynchronize(c->stream));                                                  // (non-blocking) stream
 #undef CREATE_OK
   if (ensure_scal(c, 64) != 0) { g_create_err = c->err; gpg_destroy(c); return -2; }
   *out = c;
@@ -183,7 +219,10 @@ void gpg_destroy(gpg_ctx* c) {
   if (c->stream_upd) (void)hipStreamSynchronize(c->stream_upd);
   for (auto& pe : c->prof_pending) { (void)hipEventDestroy(pe.e0); (void)hipEventDestroy(pe.e1); }
   for (auto& ev : c->prof_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-  double* bufs[] = {c->A, c->Xt, c->y, c->noise, c->dvec, c->invp, c->zvec, c->tmpv, c->dinv, c->scal, c->Wt, c->xq_dev,
+  ws_park(c);
+  double* bufs[] = {c->ws[0].A, c->ws[0].dvec, c->ws[0].invp, c->ws[0].zvec, c->ws[0].tmpv, c->ws[0].dinv,
+                    c->ws[1].A, c->ws[1].dvec, c->ws[1].invp, c->ws[1].zvec, c->ws[1].tmpv, c->ws[1].dinv,
+                    c->Xt, c->y, c->noise, c->scal, c->Wt, c->xq_dev,
                     c->musig, c->gradbuf, c->dense_tmp, c->Wfull, c->Minv, c->gpartial, c->batchA, c->batchV, c->vec_rows, c->vec_x, c->apply_buf};
   for (double* b : bufs) if (b) (void)hipFree(b);
   if (c->info) (void)hipFree(c->info);
@@ -216,7 +255,8 @@ int gpg_set_grad_mask(gpg_ctx* c, const unsigned char* use_grad_pt) {
   c->Npad = ((c->N + GPG_TILE - 1) / GPG_TILE) * GPG_TILE;
   c->ld = c->Npad + c->R;                                        // never exceeds the allocation made for all gradients
   c->have_data = false;
-  c->factor_valid = c->eval_ready = false;
+  c->factor_valid = c->eval_ready = c->prep_valid = false;
+  c->ws[0].factor_valid = c->ws[1].factor_valid = c->ws[0].prep_valid = c->ws[1].prep_valid = false;
   if (c->dense_tmp) { (void)hipFree(c->dense_tmp); c->dense_tmp = nullptr; }
   if (c->batchA) { (void)hipFree(c->batchA); (void)hipFree(c->batchV); c->batchA = c->batchV = nullptr; c->batch_cap = 0; }
   if (c->Wfull) { (void)hipFree(c->Wfull); (void)hipFree(c->Minv); c->Wfull = c->Minv = nullptr; }
@@ -235,9 +275,13 @@ int gpg_set_data(gpg_ctx* c, const double* x, const double* data_vec, const doub
   GPG_HIP_OK(c, hipMemcpy(c->Xt, xt.data(), sizeof(double) * xt.size(), hipMemcpyHostToDevice));
   GPG_HIP_OK(c, hipMemcpy(c->y, data_vec, sizeof(double) * c->N, hipMemcpyHostToDevice));
   if (noise_var) GPG_HIP_OK(c, hipMemcpy(c->noise, noise_var, sizeof(double) * c->N, hipMemcpyHostToDevice));
-  else GPG_HIP_OK(c, hipMemset(c->noise, 0, sizeof(double) * c->N));
+  else {   // on the context's stream (created non-blocking: the null stream is not ordered against it), then waited for
+    GPG_HIP_OK(c, hipMemsetAsync(c->noise, 0, sizeof(double) * c->N, c->stream));
+    GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
+  }
   c->have_data = true;
-  c->factor_valid = c->eval_ready = false;
+  c->factor_valid = c->eval_ready = c->prep_valid = false;
+  c->ws[0].factor_valid = c->ws[1].factor_valid = c->ws[0].prep_valid = c->ws[1].prep_valid = false;
   return 0;
 }
 
@@ -247,10 +291,19 @@ static int internal_failure(gpg_ctx* c, const int* infos, int m) {
   for (int i = 0; i < m; ++i)
     if (infos[i] == GPG_INFO_INTERNAL) {
       c->err = "dataflow Cholesky: a dependency wait timed out (another dataflow launch on this device?)";
-      c->factor_valid = c->eval_ready = false;
+      c->factor_valid = false;
+      if (c->ws_cur == 1) c->eval_ready = false;
       return -4;
     }
   return 0;
+}
+
+// The dataflow triangular solves of the posterior have the same bounded waits as the factorisation; the factor in A
+// is untouched by them, so the evaluation is simply repeated with the blocked sweeps.
+static int solve_failure(gpg_ctx* c) {
+  if (*c->h_info != GPG_INFO_INTERNAL) return 0;
+  c->err = "dataflow triangular solve: a dependency wait timed out (another dataflow launch on this device?)";
+  return -4;
 }
 
 static int gpg_lkd_once(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out) {
@@ -258,6 +311,7 @@ static int gpg_lkd_once(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out) {
   if (rc) return rc;
   if (!out) { c->err = "out is NULL"; return -1; }
   GPG_HIP_OK(c, hipSetDevice(c->device));
+  GPG_WS(c, 0);
   GPG_HIP_OK(c, hipMemsetAsync(c->info, 0, sizeof(int), c->stream));
   enqueue_lkd(c, hp, 0);
   GPG_HIP_OK(c, hipMemcpyAsync(c->h_scal, c->scal, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
@@ -267,7 +321,6 @@ static int gpg_lkd_once(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out) {
   GPG_LAUNCH_OK(c);
   if (internal_failure(c, c->h_info, 1)) return -4;
   c->factor_valid = (c->h_info[0] == 0);
-  c->eval_ready = false;
   finish_lkd(c, hp, c->h_scal, c->h_info[0], out);
   return out->info;
 }
@@ -277,6 +330,7 @@ static int gpg_lkd_grad_once(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out, dou
   if (rc) return rc;
   if (!out || !g_aa || !g_inv) { c->err = "out / g_aa / g_inv is NULL"; return -1; }
   GPG_HIP_OK(c, hipSetDevice(c->device));
+  GPG_WS(c, 0);
   const size_t nn = (size_t)c->Npad * c->Npad;
   if (!c->Wfull) {
     GPG_HIP_OK(c, hipMalloc(&c->Wfull, sizeof(double) * nn));
@@ -293,7 +347,6 @@ static int gpg_lkd_grad_once(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out, dou
   GPG_HIP_OK(c, hipGetLastError());
   GPG_LAUNCH_OK(c);
   if (internal_failure(c, c->h_info, 1)) return -4;
-  c->eval_ready = false;
   c->factor_valid = (c->h_info[0] == 0);
   finish_lkd(c, hp, c->h_scal, c->h_info[0], out);
   if (out->info != 0) return out->info;
@@ -307,9 +360,11 @@ static int gpg_lkd_grad_once(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out, dou
   std::vector<double> h(nval);
   const int ns = c->d + 3 + (c->kernel == GPG_KERNEL_RATQU ? 1 : 0);
   GPG_HIP_OK(c, hipMemcpyAsync(h.data(), res, sizeof(double) * 2 * ns, hipMemcpyDeviceToHost, c->stream));
-  GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
+  GPG_HIP_OK(c, hipMemcpyAsync(c->h_info, c->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));   // the dataflow solve
+  GPG_HIP_OK(c, hipStreamSynchronize(c->stream));                                                      // reports through info
   GPG_HIP_OK(c, hipGetLastError());
   GPG_LAUNCH_OK(c);
+  if (solve_failure(c)) return -4;
   g_aa[c->d + 3] = g_inv[c->d + 3] = 0.0;                  // hp_kernel slot: RatQu only
   for (int k = 0; k < ns; ++k) { g_aa[k] = h[k]; g_inv[k] = h[ns + k]; }
   return 0;
@@ -365,6 +420,7 @@ static int gpg_lkd_batch_once(gpg_ctx* c, int m, const double* hp_rows, int row_
   if (!c) return -1;
   if (m < 1 || !hp_rows || !out || row_len < c->d + 3) { c->err = "bad batch arguments (row_len >= d + 3)"; return -1; }
   GPG_HIP_OK(c, hipSetDevice(c->device));
+  GPG_WS(c, 0);
   int rc = ensure_scal(c, m);
   if (rc) return rc;
   if (m > c->items_cap) {
@@ -396,8 +452,15 @@ static int gpg_lkd_batch_once(gpg_ctx* c, int m, const double* hp_rows, int row_
     B = (m + ngroups - 1) / ngroups;
   }
   if (B > 1) {
-    double *A0 = c->A, *dvec0 = c->dvec, *invp0 = c->invp, *dinv0 = c->dinv;
+    // the launch helpers read the context's pointers: they are redirected to the batch workspaces for the loop and put
+    // back by the guard on EVERY way out of this scope (an early error return must not leave them redirected)
+    struct Restore {
+      gpg_ctx* c; double *A, *dvec, *invp, *dinv; int* info;
+      ~Restore() { c->A = A; c->dvec = dvec; c->invp = invp; c->dinv = dinv; c->info = info; }
+    } restore{c, c->A, c->dvec, c->invp, c->dinv, c->info};
     int* info0 = c->info;
+    c->prep_valid = false;                                        // dvec / invp no longer belong to one hyperparameter row
+    c->last_factor_ws = 0;
     for (int r0 = 0; r0 < m; r0 += B) {
       const int Bg = (m - r0) < B ? (m - r0) : B;
       // matrix b of the group: workspace batchA + b A_elems, vectors dvec | invp | dinv at batchV + 3 b Npad
@@ -428,7 +491,6 @@ static int gpg_lkd_batch_once(gpg_ctx* c, int m, const double* hp_rows, int row_
         gpg_launch_lkd_reduce(c, r0);
       }
     }
-    c->A = A0; c->dvec = dvec0; c->invp = invp0; c->dinv = dinv0; c->info = info0;
   } else {
     for (int i = 0; i < m; ++i) enqueue_lkd(c, &hps[i], i);
   }
@@ -439,7 +501,7 @@ static int gpg_lkd_batch_once(gpg_ctx* c, int m, const double* hp_rows, int row_
   GPG_LAUNCH_OK(c);
   if (internal_failure(c, c->h_info, m)) return -4;
   for (int i = 0; i < m; ++i) finish_lkd(c, &hps[i], c->h_scal + (size_t)8 * i, c->h_info[i], &out[i]);
-  c->factor_valid = c->eval_ready = false;
+  c->factor_valid = false;
   return 0;
 }
 
@@ -447,9 +509,12 @@ static int gpg_setup_eval_once(gpg_ctx* c, const gpg_hp* hp, double beta, double
   int rc = check_hp(c, hp);
   if (rc) return rc;
   GPG_HIP_OK(c, hipSetDevice(c->device));
+  GPG_WS(c, 1);                                   // the posterior's own factor storage (GpEvalModel.py:17-57)
   c->eval_ready = false;
   AsmParams p = make_params(c, hp, 0);
   c->last_precon = p.precon;
+  c->prep_valid = true;
+  c->last_factor_ws = 1;
   GPG_HIP_OK(c, hipMemsetAsync(c->info, 0, sizeof(int), c->stream));
   gpg_launch_prep(c, p, hp->var_fval, hp->var_fgrad, -beta, 1.0, 0.0, 0.0);   // RHS row 0 = (y - V beta) P^-1
   gpg_launch_assembly(c, p);
@@ -466,9 +531,11 @@ static int gpg_setup_eval_once(gpg_ctx* c, const gpg_hp* hp, double beta, double
     gpg_launch_alpha(c, c->tmpv);
     GPG_HIP_OK(c, hipMemcpyAsync(alpha_out, c->tmpv, sizeof(double) * c->N, hipMemcpyDeviceToHost, c->stream));
   }
-  GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
+  GPG_HIP_OK(c, hipMemcpyAsync(c->h_info, c->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));   // the dataflow backward solve
+  GPG_HIP_OK(c, hipStreamSynchronize(c->stream));                                                      // reports a timed-out wait here
   GPG_HIP_OK(c, hipGetLastError());
   GPG_LAUNCH_OK(c);
+  if (solve_failure(c)) return -4;
   c->eval_ready = true;
   c->eval_beta = beta;
   c->eval_params = p;   // theta etc. for the cross kernel
@@ -513,15 +580,8 @@ int gpg_last_factor(gpg_ctx* c, int* kernel, int* matrices) {
 }
 
 static int predict_impl(gpg_ctx* c, int nx, const double* xq, double varK, double* mu, double* sig, double* sig2_raw,
-                        double* dmudx, double* dsigdx);
+                        double* dmudx, double* dsigdx, double* dsig2dx = nullptr);
 
-// The dataflow triangular solves of the posterior have the same bounded waits as the factorisation; the factor in A
-// is untouched by them, so the evaluation is simply repeated with the blocked sweeps.
-static int solve_failure(gpg_ctx* c) {
-  if (*c->h_info != GPG_INFO_INTERNAL) return 0;
-  c->err = "dataflow triangular solve: a dependency wait timed out (another dataflow launch on this device?)";
-  return -4;
-}
 
 int gpg_predict(gpg_ctx* c, int nx, const double* xq, double varK, double* mu, double* sig, double* sig2_raw) {
   return with_fallback(c, [&] { return predict_impl(c, nx, xq, varK, mu, sig, sig2_raw, nullptr, nullptr); });
@@ -533,12 +593,26 @@ int gpg_predict_grad(gpg_ctx* c, int nx, const double* xq, double varK, double* 
   return with_fallback(c, [&] { return predict_impl(c, nx, xq, varK, mu, sig, sig2_raw, dmudx, dsigdx); });
 }
 
+int gpg_predict_var(gpg_ctx* c, int nx, const double* xq, double varK, double* sig2, double* dsig2dx) {
+  if (c && !sig2) { c->err = "sig2 is NULL"; return -1; }
+  if (!c || nx < 1) { if (c) c->err = "bad predict arguments"; return -1; }
+  std::vector<double> mu(nx), sg(nx), dmu(dsig2dx ? (size_t)nx * c->d : 0), dsg(dmu.size());
+  int rc = with_fallback(c, [&] {
+    return predict_impl(c, nx, xq, varK, mu.data(), sg.data(), sig2, dsig2dx ? dmu.data() : nullptr,
+                        dsig2dx ? dsg.data() : nullptr, dsig2dx);
+  });
+  if (rc) return rc;
+  for (int j = 0; j < nx; ++j) sig2[j] *= varK;            // GpEvalModel.py:297: varK (1 - diag(Kxy K^-1 Kyx)), not clipped
+  return 0;
+}
+
 static int predict_impl(gpg_ctx* c, int nx, const double* xq, double varK, double* mu, double* sig, double* sig2_raw,
-                        double* dmudx, double* dsigdx) {
+                        double* dmudx, double* dsigdx, double* dsig2dx) {
   if (!c) return -1;
   if (!c->eval_ready) { c->err = "gpg_setup_eval must succeed before gpg_predict"; return -1; }
   if (nx < 1 || !xq || !mu || !sig) { c->err = "bad predict arguments"; return -1; }
   GPG_HIP_OK(c, hipSetDevice(c->device));
+  GPG_WS(c, 1);
   const int nxp = ((nx + 63) / 64) * 64;
   if (nxp > c->xq_cap) {
     if (c->Wt) (void)hipFree(c->Wt);
@@ -593,6 +667,7 @@ static int predict_impl(gpg_ctx* c, int nx, const double* xq, double varK, doubl
       for (int k = 0; k < c->d; ++k) {
         dmudx[(size_t)j * c->d + k] = hgrad[(size_t)j * c->d + k];                                        // :319-325
         dsigdx[(size_t)j * c->d + k] = -inv_sig * (hgrad[(size_t)nxp * GPG_MAX_DIM + (size_t)j * c->d + k] * varK);   // :339-354
+        if (dsig2dx) dsig2dx[(size_t)j * c->d + k] = -2.0 * hgrad[(size_t)nxp * GPG_MAX_DIM + (size_t)j * c->d + k] * varK;   // :327-337
       }
     }
   }
@@ -646,23 +721,29 @@ static int predict_hess_once(gpg_ctx* c, const double* xq, double varK, double* 
 
 int gpg_get_matrix(gpg_ctx* c, const gpg_hp* hp, int which, double* out) {
   if (!c) return -1;
-  if (!out || which < 0 || which > 3) { c->err = "bad get_matrix arguments"; return -1; }
+  if (!out || which < 0 || which > 4) { c->err = "bad get_matrix arguments"; return -1; }
   GPG_HIP_OK(c, hipSetDevice(c->device));
   if (!c->dense_tmp) GPG_HIP_OK(c, hipMalloc(&c->dense_tmp, sizeof(double) * (size_t)c->N * c->N));
-  if (which == 3) {
+  if (which == 4) {
+    if (!c->eval_ready) { c->err = "no factor kept by gpg_setup_eval on the device"; return -1; }
+    GPG_WS(c, 1);
+  } else if (which == 3) {
+    GPG_WS(c, c->last_factor_ws);
     if (!c->factor_valid) { c->err = "no valid factor on the device"; return -1; }
   } else {
     int rc = check_hp(c, hp);
     if (rc) return rc;
+    GPG_WS(c, 0);
+    c->prep_valid = true;
     AsmParams p = make_params(c, hp, which == 0 ? 1 : (which == 1 ? 2 : 0));
     c->last_precon = p.precon;
     gpg_launch_prep(c, p, hp->var_fval, hp->var_fgrad, 0.0, 0.0, 0.0, 0.0);
     unsigned save = c->prof_mask; c->prof_mask = 0;
     gpg_launch_assembly(c, p);
     c->prof_mask = save;
-    c->factor_valid = c->eval_ready = false;
+    c->factor_valid = false;
   }
-  gpg_launch_extract(c, which);
+  gpg_launch_extract(c, which == 4 ? 3 : which);
   GPG_HIP_OK(c, hipMemcpyAsync(out, c->dense_tmp, sizeof(double) * (size_t)c->N * c->N, hipMemcpyDeviceToHost,
                                c->stream));
   GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
@@ -675,8 +756,9 @@ int gpg_dcov_quadform(gpg_ctx* c, const gpg_hp* hp, const double* v, double* out
   int rc = check_hp(c, hp);
   if (rc) return rc;
   if (!v || !out) { c->err = "v / out is NULL"; return -1; }
-  if (!c->factor_valid) { c->err = "gpg_dcov_quadform follows a successful gpg_lkd / gpg_setup_eval with the same hp"; return -1; }
   GPG_HIP_OK(c, hipSetDevice(c->device));
+  GPG_WS(c, c->last_factor_ws);
+  if (!c->prep_valid) { c->err = "gpg_dcov_quadform follows a gpg_lkd / gpg_setup_eval call with the same hp"; return -1; }
   const int nblk = gpg_grad_partial_blocks(c);
   const int nval = 2 * GPG_GRAD_SLOTS_MAX;
   if (!c->gpartial) GPG_HIP_OK(c, hipMalloc(&c->gpartial, sizeof(double) * (size_t)nval * (nblk + 1)));
@@ -702,8 +784,9 @@ int gpg_dcov_quadform(gpg_ctx* c, const gpg_hp* hp, const double* v, double* out
 int gpg_factor_apply(gpg_ctx* c, int op, const double* v, double* out) {
   if (!c) return -1;
   if (!v || !out || (op != 0 && op != 1)) { c->err = "bad factor_apply arguments"; return -1; }
-  if (!c->factor_valid) { c->err = "no valid factor on the device (gpg_lkd / gpg_setup_eval first)"; return -1; }
   GPG_HIP_OK(c, hipSetDevice(c->device));
+  GPG_WS(c, c->last_factor_ws);
+  if (!c->factor_valid) { c->err = "no valid factor on the device (gpg_lkd / gpg_setup_eval first)"; return -1; }
   if (!c->apply_buf) GPG_HIP_OK(c, hipMalloc(&c->apply_buf, sizeof(double) * 2 * (size_t)c->vec_rows_cols));
   double* dv = c->apply_buf;
   double* dout = c->apply_buf + c->vec_rows_cols;

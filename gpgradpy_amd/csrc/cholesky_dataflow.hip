@@ -781,8 +781,8 @@ static void launch_tile_chol(gpg_ctx* c, int c0) {
   const size_t nflag = (size_t)Mt * Rt + 1 + 4 * (size_t)Mt;   // tile flags, abort word, four piece flags per diagonal tile
   if (!ensure_tile_flags(c, nflag)) return;
   (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
-  const double m = (double)(c->Npad - c0);
-  gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, m * m * m / 3.0);
+  const double m = (double)(c->N - c0);                    // algorithmic flops: N^3 / 3 of the real matrix, not of the padded one
+  gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, m > 0 ? m * m * m / 3.0 : 0.0);
   int* abort_word = c->tile_flags + (size_t)Mt * Rt;
   hipLaunchKernelGGL(tile_chol_kernel, dim3(tm.n), dim3(256), 0, c->stream, c->A, c->ld, c0, Mt, (const int*)tm.dev,
                      c->tile_flags, abort_word + 1, abort_word, c->dinv, c->info, c->N, (const int*)nullptr, (size_t)0, 0, 0);
@@ -814,7 +814,7 @@ static void launch_tile_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a_st
   const size_t per = (size_t)Mt * Rt + 1 + 4 * (size_t)Mt, nflag = per * B;
   if (!ensure_tile_flags(c, nflag)) return;
   (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
-  const double m = (double)c->Npad;
+  const double m = (double)c->N;
   gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, B * m * m * m / 3.0);
   int* abort_word = c->tile_flags + (size_t)Mt * Rt;      // the abort word of matrix 0 serves the whole launch
   hipLaunchKernelGGL(tile_chol_kernel, dim3(tm.n), dim3(256), 0, c->stream, Abase, c->ld, 0, Mt, (const int*)tm.dev,
@@ -831,7 +831,7 @@ static void launch_tile128_chol(gpg_ctx* c) {
   const size_t nflag = (size_t)Mt * Rt + 1 + 9 * (size_t)Mt;   // tile flags, abort word, 4 + 4 piece flags and the L21 flag per diagonal tile
   if (!ensure_tile_flags(c, nflag)) return;
   (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
-  const double m = (double)c->Npad;
+  const double m = (double)c->N;
   gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, m * m * m / 3.0);
   int* abort_word = c->tile_flags + (size_t)Mt * Rt;
   hipLaunchKernelGGL(tile128_chol_kernel, dim3(tm.n), dim3(256), 0, c->stream, c->A, c->ld, Mt, (const int*)tm.dev,
@@ -862,7 +862,7 @@ static void launch_tile128_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a
   const size_t per = (size_t)Mt * Rt + 1 + 9 * (size_t)Mt, nflag = per * B;
   if (!ensure_tile_flags(c, nflag)) return;
   (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
-  const double m = (double)c->Npad;
+  const double m = (double)c->N;
   gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, B * m * m * m / 3.0);
   int* abort_word = c->tile_flags + (size_t)Mt * Rt;
   hipLaunchKernelGGL(tile128_chol_kernel, dim3(tm.n), dim3(256), 0, c->stream, Abase, c->ld, Mt, (const int*)tm.dev,

@@ -33,6 +33,17 @@ struct TileMap { int* dev; int n; };
 
 struct ProfEvent { hipEvent_t e0, e1; int cat; };
 
+// One factorisation workspace with the vectors that belong to the matrix in it.  The context keeps two: set 0 serves the
+// likelihood evaluations (gpg_lkd / gpg_lkd_grad / gpg_lkd_batch / gpg_get_matrix 0..2), set 1 holds the factor kept by
+// gpg_setup_eval for gpg_predict* -- the reference keeps KernEta_chofac untouched by later likelihood calls
+// (GpEvalModel.py:17-57), so the posterior must not share storage with them.  Set 1 is allocated by the first
+// gpg_setup_eval.  The "active" set is mirrored in gpg_ctx::A, dvec, ... (what every launch helper reads).
+struct gpg_ws {
+  double *A = nullptr, *dvec = nullptr, *invp = nullptr, *dinv = nullptr, *zvec = nullptr, *tmpv = nullptr;
+  bool factor_valid = false, prep_valid = false;
+  int precon = 0;
+};
+
 struct gpg_ctx {
   int device = 0;
   hipStream_t stream = nullptr;      // main stream
@@ -97,8 +108,12 @@ struct gpg_ctx {
   int* h_info = nullptr;
   // state
   bool have_data = false;
-  bool factor_valid = false;   // A holds L of the last setup_eval
-  bool eval_ready = false;
+  bool factor_valid = false;   // the active workspace holds a finished factor
+  bool prep_valid = false;     // dvec / invp of the active workspace belong to the hyperparameters of the last single-matrix call
+  gpg_ws ws[2];                // parked copies of the workspace sets (the active one is stale here until it is parked)
+  int ws_cur = 0;              // which set is active
+  int last_factor_ws = 0;      // set of the most recent factorisation (gpg_factor_apply, gpg_get_matrix 3, gpg_dcov_quadform)
+  bool eval_ready = false;     // set 1 holds factor + alpha of a successful gpg_setup_eval
   double eval_beta = 0.0;
   int last_precon = 0;         // wellcond of the matrix currently in A
   int scal_slots = 0;
@@ -148,6 +163,7 @@ void gpg_launch_unscale(gpg_ctx* c, const double* v, double* z);          // z =
 int gpg_grad_partial_blocks(const gpg_ctx* c);
 int gpg_factor_apply_dev(gpg_ctx* c, int op, double* v, double* out);       // (L L^T) v or (L L^T)^-1 v, device vectors [Npad]
 void gpg_launch_extract(gpg_ctx* c, int which);                          // dense_tmp <- sym / P L
+int gpg_ws_activate(gpg_ctx* c, int which);                              // make workspace set `which` the active one (allocates set 1 on first use)
 
 // Device allocation inside a launch helper (task lists, flags, carrier tiles): on failure the pointer stays null, the
 // context is marked and the helper returns WITHOUT launching; the API call reports it (GPG_LAUNCH_OK) instead of a

@@ -17,6 +17,38 @@ from .hpara import HparaOptzInfo, HparaOptzVal, LkdInfo
 from .hpara_optz import HparaOptz
 
 
+class DeviceChoFactor:
+    """`KernEta_chofac` of a model whose factor lives in HBM: behaves like SciPy's `(c, lower)` pair --
+    `scipy.linalg.cho_solve(GP.KernEta_chofac, b)` unpacks it -- and downloads the lower-triangular `P L`
+    (Kernel.py:252) from the posterior's own device workspace on first use (gpg_get_matrix which = 4); the hot path
+    (`eval_model`, `eval_model_var`) never triggers the download."""
+
+    def __init__(self, gp):
+        self._gp = gp
+        self._fac = None
+
+    def _array(self):
+        if self._fac is None:
+            gp = self._gp
+            if gp.KernEta_chofac is not self:
+                raise RuntimeError('this KernEta_chofac belongs to an earlier setup_eval_model(): its device factor has been replaced')
+            fac = np.empty((gp.n_data, gp.n_data))
+            rc = gp._lib.gpg_get_matrix(gp._ctx, None, 4, _lib.as_dp(fac))
+            if rc != 0:
+                raise _lib.GpgError(f'gpg_get_matrix failed ({rc}): {gp._err()}')
+            self._fac = fac
+        return self._fac
+
+    def __iter__(self):
+        return iter((self._array(), True))
+
+    def __len__(self):
+        return 2
+
+    def __getitem__(self, i):
+        return (self._array(), True)[i]
+
+
 class GaussianProcess(HparaOptz):
     # ---- options read by the hot path (reference GaussianProcess.py:27-113) -------------------------
     optz_log_hp_theta = True
@@ -435,9 +467,10 @@ class GaussianProcess(HparaOptz):
             else:
                 print(f'Failure of the Cholesky decomposition, first non-positive pivot = {rc}')   # Kernel.py:255
         self._time_chofac += time.time() - t0
-        self._eval_ready = False
         condK = None
         if calc_cond:                                         # Kernel.py:239-245 / 279-285 (needs the factor here)
+            if self.cond_norm != 2:
+                raise NotImplementedError("only the 2-norm condition number is on the accelerated path (cond_norm = 'fro' is not)")
             condK = self.calc_cond_device() if chofac is not None else np.nan
         return Kern, None, Kcov, chofac, condK, self._etaK, None
 
@@ -449,7 +482,7 @@ class GaussianProcess(HparaOptz):
             raise NotImplementedError('likelihood gradient with a bvec_use_grad mask is not supported')
         if calc_grad and not (lkd_use_adj_mtd is None or lkd_use_adj_mtd) and not self.lkd_use_adj_mtd:
             raise NotImplementedError('only the adjoint gradient method is on the accelerated path')
-        if calc_cond and calc_grad and self.cond_norm != 2:
+        if calc_cond and self.cond_norm != 2:
             raise NotImplementedError("only the 2-norm condition number is on the accelerated path (cond_norm = 'fro' is not)")
         noisy = self.b_has_noisy_data
         if noisy:
@@ -467,19 +500,23 @@ class GaussianProcess(HparaOptz):
         else:
             rc = self._lib.gpg_lkd(self._ctx, C.byref(hp), C.byref(out))
         self._time_chofac += time.time() - t0
-        self._eval_ready = False
         if rc < 0:
             raise _lib.GpgError(f'gpg_lkd failed ({rc}): {self._err()}')
         if rc > 0:
             # CalcLkd.py:308-311 / 330-333: the reference reports np.linalg.cond(Kcov, 2) of the matrix that could not be
             # factorised.  No factor -> no Lanczos through it: the matrix is downloaded and the SVD done on the host, for
             # moderate sizes only (this branch is the failure path, not the hot path); NaN above that.
-            cond_fail = np.nan
+            cond_fail, cond_grad_fail = np.nan, None
             if self.n_data <= 4096:
                 Kc = np.empty((self.n_data, self.n_data))
                 if self._lib.gpg_get_matrix(self._ctx, C.byref(hp), 1, _lib.as_dp(Kc)) == 0:
                     cond_fail = float(np.linalg.cond(Kc, p=2))
-            return LkdInfo(cond=cond_fail), False
+                    if calc_grad and self.wellcond_mtd != 'precon':
+                        # calc_cond_L2_w_grad of the failed matrix (GpHparaCon.py:163-197): extreme eigenpairs on the host
+                        # (the matrix is already here), the quadratic forms v' (d Kcov / d hp_k) v on the device
+                        ev, evec = np.linalg.eigh(Kc)
+                        cond_grad_fail = self._cond_grad_from_vectors(hp, cond_fail, ev[0], evec[:, -1], evec[:, 0])
+            return LkdInfo(cond=cond_fail, cond_grad=cond_grad_fail), False
         cond = cond_grad = None
         if calc_cond:
             if calc_grad and self.wellcond_mtd != 'precon':          # GpHparaCon.py:171-173: no gradient with 'precon'
@@ -557,7 +594,6 @@ class GaussianProcess(HparaOptz):
         rc = self._lib.gpg_lkd_batch(self._ctx, m, _lib.as_dp(rows), rows.shape[1], float(self._etaK),
                                      _lib.GPG_WELLCOND[self.wellcond_mtd], int(not self.b_has_noisy_data), outs)
         self._time_chofac += time.time() - t0
-        self._eval_ready = False
         if rc != 0:
             raise _lib.GpgError(f'gpg_lkd_batch failed ({rc}): {self._err()}')
         ln = np.array([o.ln_lkd if o.info == 0 else np.nan for o in outs])
@@ -602,8 +638,8 @@ class GaussianProcess(HparaOptz):
 
     def setup_eval_model(self, calc_cond=False):
         """GpEvalModel.py:17-57: factor kept on the device, alpha = K^-1 (y - V beta) returned to the host."""
-        if calc_cond:
-            raise NotImplementedError('calc_cond=True is outside the accelerated path')
+        if calc_cond and self.cond_norm != 2:
+            raise NotImplementedError("only the 2-norm condition number is on the accelerated path (cond_norm = 'fro' is not)")
         self._hp_vals_model_setup = copy.copy(self.hp_vals)
         hp, keep = self._make_hp(self.hp_vals, 1.0, closed_form=not self.b_has_noisy_data)   # b_normlz_w_varK=True
         beta = float(np.ravel(self.hp_vals.beta)[0])
@@ -622,9 +658,11 @@ class GaussianProcess(HparaOptz):
             self.invKernEta_fdiff = None
             self._eval_ready = False
         else:
-            self.KernEta_chofac = 'device'      # the factor lives in HBM; gpg_get_matrix(which=3) downloads it
+            self.KernEta_chofac = DeviceChoFactor(self)   # the factor stays in HBM; downloaded if somebody unpacks it
             self.invKernEta_fdiff = alpha
             self._eval_ready = True
+            if calc_cond:                                 # GpEvalModel.py:39-41 -> Kernel.py:239-245 / 279-285
+                self.condK = self.calc_cond_device()
 
     def eval_model(self, x2model_in, calc_grad=False, calc_hess=False, squeeze_nx=False):
         """GpEvalModel.py:59-198: returns (mu, sig, dmudx, dsigdx, d2mudx2, d2sigdx2); the Hessians are
@@ -647,7 +685,7 @@ class GaussianProcess(HparaOptz):
         if (self.hp_vals == self._hp_vals_model_setup) is False:
             raise Exception('Cannot change hp_vals between calling setup_eval_model() and eval_model()')
         if not self._eval_ready:
-            raise Exception('setup_eval_model() must be called again: the device factor was overwritten by a likelihood evaluation')
+            raise Exception('setup_eval_model() must be called (again): set_data() replaced the data of the device model')
         xq = np.ascontiguousarray(x2model, dtype=np.float64)
         mu, sig, s2 = np.empty(nx), np.empty(nx), np.empty(nx)
         dmudx = dsigdx = d2mudx2 = d2sigdx2 = None
@@ -677,6 +715,70 @@ class GaussianProcess(HparaOptz):
                 return mu[0], sig[0], dmudx[0, :], dsigdx[0, :], None, None
             return mu[0], sig[0], None, None, None, None
         return mu, sig, dmudx, dsigdx, d2mudx2, d2sigdx2
+
+    def eval_model_var(self, x2model_in, calc_grad=False, calc_hess=False, squeeze_nx=False):
+        """GpEvalModel.py:200-317: variance form of the posterior, returns (sig2, dsig2dx, d2sig2dx2) with
+        sig2 = varK (1 - diag(Kxy K^-1 Kyx)) and dsig2dx of calc_dsig2dx (:327-337)."""
+        assert self.KernEta_chofac is not None, 'To evaluate the surr the Cholesky decomposition is required'
+        if x2model_in.ndim == 1:
+            x2model = x2model_in[None, :]
+        elif x2model_in.ndim == 2:
+            x2model = x2model_in
+        else:
+            raise Exception(f'x2model_in should be a 2d array but it has shape {x2model_in.shape}')
+        nx = x2model.shape[0]
+        if squeeze_nx:
+            assert nx == 1, 'If squeeze_nx is True, then x_acq must only have one point'
+        if (self.hp_vals == self._hp_vals_model_setup) is False:
+            raise Exception('Cannot change hp_vals between calling setup_eval_model() and eval_model()')
+        if calc_hess:
+            assert calc_grad, 'To return the hessian calc_grad must also be set to True'
+        if not self._eval_ready:
+            raise Exception('setup_eval_model() must be called (again): set_data() replaced the data of the device model')
+        xq = np.ascontiguousarray(x2model, dtype=np.float64)
+        sig2 = np.empty(nx)
+        dsig2dx = np.empty((nx, self.dim)) if calc_grad else None
+        rc = self._lib.gpg_predict_var(self._ctx, nx, _lib.as_dp(xq), float(self.hp_vals.varK), _lib.as_dp(sig2),
+                                       None if dsig2dx is None else _lib.as_dp(dsig2dx))
+        if rc != 0:
+            raise _lib.GpgError(f'gpg_predict_var failed ({rc}): {self._err()}')
+        assert np.min(sig2) >= 0, f'The variance of the surr should be non-negative but min(sig2) = {np.min(sig2)}'   # :298
+        if calc_hess:
+            raise Exception('Must add method to calculate d2sig2dx2')                                            # :306
+        if squeeze_nx:
+            return sig2[0], (dsig2dx[0, :] if calc_grad else None), None
+        return sig2, dsig2dx, None
+
+    def shard_restarts(self, group):
+        """Opt in to sharding the restart rows of `set_hpara('optz')` (the hp_best pre-selection and the SLSQP
+        multi-start) over the ranks of a torch.distributed process group, one process per GPU (SURVEY.md 8e);
+        None switches it off.  Every rank of the group must then make the same calls with the same data."""
+        self.restart_group = group
+
+    def _cond_grad_from_vectors(self, hp_struct, cond, lam_min, v_max, v_min):
+        """d cond / d hp_k = (v_max' G_k v_max - cond v_min' G_k v_min) / max(lam_min, 1e-16), G_k = d Kmat / d hp_k
+        (GpHparaCon.py:175-197), the quadratic forms on the device, laid out in hp_info_optz_lkd order."""
+        q = []
+        for v in (v_max, v_min):
+            out = np.zeros(self.dim + 4)
+            v = np.ascontiguousarray(v, dtype=np.float64)
+            rc = self._lib.gpg_dcov_quadform(self._ctx, C.byref(hp_struct), _lib.as_dp(v), _lib.as_dp(out))
+            if rc != 0:
+                raise _lib.GpgError(f'gpg_dcov_quadform failed ({rc}): {self._err()}')
+            q.append(out)
+        g_all = (q[0] - cond * q[1]) / max(lam_min, 1e-16)                      # eig_min_mod, GpHparaCon.py:192
+        hi, d = self.hp_info_optz_lkd, self.dim
+        cond_grad = np.zeros(hi.n_hp)
+        cond_grad[hi.idx_theta] = g_all[:d]
+        if hi.has_kernel:
+            cond_grad[hi.idx_kernel] = g_all[d + 3]
+        if hi.has_varK:
+            cond_grad[hi.idx_varK] = g_all[d]
+        if hi.has_var_fval:
+            cond_grad[hi.idx_var_fval] = g_all[d + 1]
+        if hi.has_var_fgrad:
+            cond_grad[hi.idx_var_fgrad] = g_all[d + 2]
+        return cond_grad
 
     # ---- instrumentation -------------------------------------------------------------------------------
     def prof_enable(self, cats):
@@ -783,27 +885,7 @@ class GaussianProcess(HparaOptz):
         #   d cond / d hp_k = (v_max^T G_k v_max - cond v_min^T G_k v_min) / lambda_min,   G_k = d Kmat / d hp_k,
         # the quadratic forms on the device (gpg_dcov_quadform), the hyperparameter values in hp_info_optz_lkd order
         cond, lam_min, v_max, v_min = cond_from_factor(op(0), op(1), N, want_vectors=True)
-        q = []
-        for v in (v_max, v_min):
-            out = np.zeros(self.dim + 4)
-            v = np.ascontiguousarray(v, dtype=np.float64)
-            rc = self._lib.gpg_dcov_quadform(self._ctx, C.byref(hp_struct), _lib.as_dp(v), _lib.as_dp(out))
-            if rc != 0:
-                raise _lib.GpgError(f'gpg_dcov_quadform failed ({rc}): {self._err()}')
-            q.append(out)
-        g_all = (q[0] - cond * q[1]) / max(lam_min, 1e-16)                      # eig_min_mod, GpHparaCon.py:192
-        hi, d = self.hp_info_optz_lkd, self.dim
-        cond_grad = np.zeros(hi.n_hp)
-        cond_grad[hi.idx_theta] = g_all[:d]
-        if hi.has_kernel:
-            cond_grad[hi.idx_kernel] = g_all[d + 3]
-        if hi.has_varK:
-            cond_grad[hi.idx_varK] = g_all[d]
-        if hi.has_var_fval:
-            cond_grad[hi.idx_var_fval] = g_all[d + 1]
-        if hi.has_var_fgrad:
-            cond_grad[hi.idx_var_fgrad] = g_all[d + 2]
-        return cond, cond_grad
+        return cond, self._cond_grad_from_vectors(hp_struct, cond, lam_min, v_max, v_min)
 
     def last_factor(self):
         """(schedule, matrices) of the most recent factorisation launch: 'blocked' | 'tile64' | 'tile128'."""

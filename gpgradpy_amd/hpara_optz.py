@@ -60,6 +60,8 @@ class HparaOptz:
     hp_var_fval_range = [1e-8, 1e8]
     hp_var_fgrad_range = [1e-8, 1e8]
     b_use_cond_cstr = False
+    restart_group = None          # torch.distributed process group the restarts are sharded over (None: no sharding)
+    _last_chofac_good = True
     _save_data = False
     _lkd_val = _lkd_grad = None
 
@@ -206,7 +208,7 @@ class HparaOptz:
             # the reference's loop over calc_lkd_all (GpHparaX0.py:39-45) = one batched device call, sharded
             # over ranks when torch.distributed is up; failed factorisations are NaN and drop out of nanargmax
             from .multistart import select_best_restart
-            hp_x0 = select_best_restart(hp_x0, self.calc_lkd_batch)[0]
+            hp_x0 = select_best_restart(hp_x0, self.calc_lkd_batch, group=self.restart_group)[0]
         return hp_x0, optz_bound, time.time() - start_time
 
     # ---- objective (OptzLkd.py:15-100) ------------------------------------------------------------------------
@@ -227,13 +229,19 @@ class HparaOptz:
                     if self.b_use_cond_cstr and cond_grad is not None:
                         cond_grad[bvec] *= transformation
             else:
-                # the reference falls back on minus the SVD condition number here (OptzLkd.py:74-77), which it
-                # computes from the matrix; here the factor is needed for it: NaN, zero slope
-                ln_lkd_val = np.nan
-                ln_lkd_grad = np.zeros(self.hp_info_optz_lkd.n_hp)
-                cond_val = np.nan if cond_val is None else cond_val
-                cond_grad = np.zeros(self.hp_info_optz_lkd.n_hp) if cond_grad is None else cond_grad
+                # OptzLkd.py:74-77: a failed Cholesky makes minus the condition number the objective (and minus its
+                # gradient, WITHOUT the log10 chain rule, the slope), so that SLSQP walks back into the region where
+                # the matrix can be factorised.  calc_lkd_all computes both for the failed matrix up to N = 4096
+                # (host SVD / eigenvectors of the downloaded matrix); above that, and for 'precon' (where the
+                # reference has no cond_grad and stops with a TypeError), a large finite penalty / zero slope.
+                n_hp = self.hp_info_optz_lkd.n_hp
+                if cond_val is None or not np.isfinite(cond_val):
+                    cond_val = self.cond_max_abs
+                cond_grad = np.zeros(n_hp) if cond_grad is None else cond_grad
+                ln_lkd_val = -cond_val
+                ln_lkd_grad = -cond_grad
             self._last_hp_vec = hp_vec.copy()
+            self._last_chofac_good = bool(b_chofac_good)
             self._lkd_val, self._lkd_grad = ln_lkd_val, ln_lkd_grad
             self._cond_val = np.nan if cond_val is None else cond_val
             self._cond_grad = cond_grad
@@ -271,50 +279,61 @@ class HparaOptz:
         # the starts are independent: with torch.distributed up, rank r runs its contiguous block of them on its own
         # GPU and one all_gather shares (objective, success, iterations, solution) -- SURVEY.md 8e applied to the
         # optimiser's multi-start (the reference runs them one after the other, OptzLkd.py:252-290)
-        from .multistart import gather_rows, shard_rows
-        try:
-            import torch.distributed as dist
-            world, rank = (dist.get_world_size(), dist.get_rank()) if dist.is_available() and dist.is_initialized() else (1, 0)
-        except ImportError:                                   # pragma: no cover
-            world, rank = 1, 0
+        from .multistart import _group_info, gather_rows, shard_rows
+        group = self.restart_group                                # None: all starts on this process
+        world, rank, _ = _group_info(group)
         lo, hi = shard_rows(n_optz, world, rank)
         all_con_good = np.full(n_optz, True, dtype=bool)
         optz_cond_all = np.full(n_optz, np.nan)
-        n_cho_fail, n_cond2big, max_init_cond = 0, 0, np.nan
+        # per-start counters of OptzLkd.py:255-259 (kept per start so that they travel with the gathered table)
+        cho_fail_all, cond2big_all, init_cond_all = np.zeros(n_optz), np.zeros(n_optz), np.full(n_optz, np.nan)
         nlc = []
         if self.b_use_cond_cstr:                                                 # OptzLkd.py:245, GaussianProcess.py:210-212
             nlc = NonlinearConstraint(self.return_cond_val, -np.inf, self.cond_max, jac=self.return_cond_grad)
-        for i in range(lo, hi):
-            x0_i = hp_x0_all[i, :]
-            if self.b_use_cond_cstr:                                             # OptzLkd.py:255-259
+        err = None
+        try:
+            for i in range(lo, hi):
+                x0_i = hp_x0_all[i, :]
+                if self.b_use_cond_cstr:                                         # OptzLkd.py:255-259
+                    self._last_hp_vec = np.full((1, x0_i.size), np.nan)
+                    self.calc_store_likelihood(x0_i)
+                    init_cond_all[i] = self._cond_val
+                    cho_fail_all[i] = float(not self._last_chofac_good)
+                    cond2big_all[i] = float(self._cond_val > self.cond_max)
                 self._last_hp_vec = np.full((1, x0_i.size), np.nan)
-                lkd_val, _, cond_val = self.calc_store_likelihood(x0_i)[:3]
-                max_init_cond = np.nanmax((max_init_cond, cond_val))
-                n_cho_fail += int(np.isnan(lkd_val))
-                n_cond2big += int(cond_val > self.cond_max)
-            self._last_hp_vec = np.full((1, x0_i.size), np.nan)
-            res = minimize(self.return_optz_val, x0_i, method=self.optz_mtd, jac=self.return_optz_grad,
-                           bounds=optz_bound, constraints=nlc, options=optz_opt)
-            optz_sol_all[i, :] = res.x
-            optz_obj_all[i] = res.fun
-            all_optz_success[i] = res.success
-            all_total_fun_iter[i] = res.nit
-            if self.b_use_cond_cstr:                                             # OptzLkd.py:276-279
-                optz_cond_all[i] = self.return_cond_val(res.x)
-                all_con_good[i] = optz_cond_all[i] < 1.01 * self.cond_max
-            if not (res.success and all_con_good[i]):
-                print(f"Surr hpara optz: Con {'GOOD' if all_con_good[i] else 'FAIL'}, Optimizer: {'GOOD' if res.success else res.message}")
-        if world > 1:
+                res = minimize(self.return_optz_val, x0_i, method=self.optz_mtd, jac=self.return_optz_grad,
+                               bounds=optz_bound, constraints=nlc, options=optz_opt)
+                optz_sol_all[i, :] = res.x
+                optz_obj_all[i] = res.fun
+                all_optz_success[i] = res.success
+                all_total_fun_iter[i] = res.nit
+                if self.b_use_cond_cstr:                                         # OptzLkd.py:276-279
+                    optz_cond_all[i] = self.return_cond_val(res.x)
+                    all_con_good[i] = optz_cond_all[i] < 1.01 * self.cond_max
+                if not (res.success and all_con_good[i]):
+                    print(f"Surr hpara optz: Con {'GOOD' if all_con_good[i] else 'FAIL'}, Optimizer: {'GOOD' if res.success else res.message}")
+        except Exception as e:          # noqa: BLE001 -- a failing rank still joins the collective below, then re-raises
+            err = e
+        if group is not None:
             table = gather_rows(np.column_stack((optz_obj_all, all_optz_success, all_total_fun_iter, all_con_good, optz_cond_all,
-                                                 optz_sol_all))[lo:hi], n_optz)
+                                                 cho_fail_all, cond2big_all, init_cond_all, optz_sol_all))[lo:hi], n_optz,
+                                group=group, error=err)
             optz_obj_all, all_optz_success, all_total_fun_iter = table[:, 0], table[:, 1] > 0.5, table[:, 2]
-            all_con_good, optz_cond_all, optz_sol_all = table[:, 3] > 0.5, table[:, 4], table[:, 5:]
+            all_con_good, optz_cond_all = table[:, 3] > 0.5, table[:, 4]
+            cho_fail_all, cond2big_all, init_cond_all, optz_sol_all = table[:, 5], table[:, 6], table[:, 7], table[:, 8:]
+        elif err is not None:
+            raise err
+        n_cho_fail, n_cond2big = int(np.nansum(cho_fail_all)), int(np.nansum(cond2big_all))
+        max_init_cond = np.nan if np.all(np.isnan(init_cond_all)) else float(np.nanmax(init_cond_all))
         if np.any(all_con_good):                                                 # OptzLkd.py:294-305
             obj_ok, sol_ok = optz_obj_all[all_con_good], optz_sol_all[all_con_good, :]
         else:
             print('*** No solutions satisfy the constraints for the GP hyperparameter optimization ***')
             print(f'Cond = {optz_cond_all}')
             obj_ok, sol_ok = optz_obj_all, optz_sol_all
+        if np.all(np.isnan(obj_ok)):
+            raise RuntimeError('hyperparameter optimisation: every start ended with a NaN objective '
+                               f'(objectives {optz_obj_all}); no solution can be selected')
         idx_min = np.nanargmin(obj_ok)
         best_hp = sol_ok[idx_min, :]
         surr_optz_info = {'hp_optz_success': np.mean(all_optz_success), 'hp_optz_iter_mean': np.mean(all_total_fun_iter),

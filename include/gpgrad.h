@@ -113,7 +113,11 @@ int gpg_lkd_batch(gpg_ctx* ctx, int m, const double* hp_rows, int row_len, doubl
 
 /* Replaces GpEvalModel.setup_eval_model (GpEvalModel.py:17-57): factorises the matrix for hp (the
  * caller passes varK_mat = 1, noise undivided: the b_normlz_w_varK quirk of Kernel.py:196-197,218)
- * and keeps the factor plus alpha = Kcov^-1 (y - V beta) on the device.  alpha_out [N] may be NULL. */
+ * and keeps the factor plus alpha = Kcov^-1 (y - V beta) on the device.  alpha_out [N] may be NULL.
+ * The factor lives in a workspace of its own (allocated by the first call: one more (N_pad + 128) x N_pad fp64
+ * array): gpg_lkd / gpg_lkd_grad / gpg_lkd_batch / gpg_get_matrix calls that follow do NOT disturb it, and
+ * gpg_predict* keep answering from it until the next gpg_setup_eval / gpg_set_data -- as KernEta_chofac of the
+ * reference survives later calc_lkd_all calls. */
 int gpg_setup_eval(gpg_ctx* ctx, const gpg_hp* hp, double beta, double* alpha_out);
 
 /* Replaces GpEvalModel.eval_model(x, calc_grad=False) (GpEvalModel.py:59-198): cross-kernel
@@ -130,6 +134,12 @@ int gpg_predict(gpg_ctx* ctx, int nx, const double* xq, double varK, double* mu,
 int gpg_predict_grad(gpg_ctx* ctx, int nx, const double* xq, double varK, double* mu, double* sig,
                      double* sig2_raw, double* dmudx, double* dsigdx);
 
+/* Replaces GpEvalModel.eval_model_var(x, calc_grad) (GpEvalModel.py:200-317): the variance form of the posterior,
+ * sig2 [nx] = varK (1 - diag(Kxy K^-1 Kyx)) (:297, NOT clipped at zero: the reference asserts min >= 0 on it) and, when
+ * dsig2dx != NULL, its gradient [nx, dim] row-major = -2 varK sum_r dKxy_dx[., r] (K^-1 Kyx)[r] (calc_dsig2dx :327-337;
+ * defined where sig = 0, unlike dsigdx). */
+int gpg_predict_var(gpg_ctx* ctx, int nx, const double* xq, double varK, double* sig2, double* dsig2dx);
+
 /* Posterior Hessians at ONE query point xq[d] (the reference evaluates them one point per call):
  * d2mudx2[d*d], d2sigdx2[d*d] row-major, plus everything gpg_predict_grad returns for that point.
  * Replaces eval_model(calc_grad=True, calc_hess=True) -- GpEvalModel.py:170-181, calc_d2mudx2 :355-363,
@@ -142,9 +152,11 @@ int gpg_predict_hess(gpg_ctx* ctx, const double* xq, double varK, double* mu, do
  * copies them).  out is [N, N] column-major == row-major (symmetric) for which = 0..2:
  *   0 Kern (Kernel.py:213-216), 1 Kcov (Kernel.py:237 / 277), 2 the matrix that is factorised
  *   (Kcov_precon, Kernel.py:236; equals Kcov for wellcond = base);
- *   3 the Cholesky factor kept by the last gpg_setup_eval / gpg_lkd call, as the lower-triangular
- *     P L of Kernel.py:252 (row-major [N, N], zeros above the diagonal) usable with
- *     scipy.linalg.cho_solve((out, True), b). */
+ *   3 the Cholesky factor of the most recent factorisation (gpg_lkd / gpg_lkd_grad / gpg_setup_eval), as the
+ *     lower-triangular P L of Kernel.py:252 (row-major [N, N], zeros above the diagonal) usable with
+ *     scipy.linalg.cho_solve((out, True), b);
+ *   4 the same for the factor KEPT by the last successful gpg_setup_eval, whatever likelihood calls came after it
+ *     (hp ignored for 3 and 4). */
 int gpg_get_matrix(gpg_ctx* ctx, const gpg_hp* hp, int which, double* out);
 
 /* Products with the matrix that was factorised last (gpg_lkd / gpg_setup_eval), through its factor in HBM:

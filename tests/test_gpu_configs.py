@@ -1,0 +1,230 @@
+"""GPU (MI355X): BASELINE.json configurations pinned exactly, and the drop-in state semantics of the posterior.
+
+cfg1 / cfg2 (SURVEY.md 8(d) inputs, reference-generated fixtures cfg1_full / cfg2_full) also run through the generic
+golden test of test_gpu_parity.py; here: cfg3 at FULL size asserted against one evaluation of the CPU oracle, the
+interleaving of likelihood and posterior calls the reference allows (GpEvalModel.py:17-57 keeps KernEta_chofac),
+eval_model_var (GpEvalModel.py:200-317), setup_eval_model(calc_cond=True), and the failed-Cholesky objective of the
+optimiser (OptzLkd.py:74-77)."""
+import os
+
+import numpy as np
+import pytest
+from scipy.linalg import cho_solve
+
+from conftest import GOLDEN_DIR, load_case
+import tolerances as tol
+
+pytestmark = pytest.mark.gpu
+
+
+def _design(n, d):
+    """SURVEY.md 8(d) / BASELINE.md section 3 inputs (same generator as bench.py)."""
+    import bench
+    return bench.make_workload(n, d, "cfg3")
+
+
+def test_cfg2_exact_configuration():
+    """BASELINE configs[1] exactly as SURVEY.md 8(d) defines it: n = 500, d = 4, noise-free, theta = 0.5, seed 0 --
+    the reference's own evaluation (probe value of SURVEY.md 8c: ln_lkd = -3.765538651174e+03)."""
+    import gpgradpy_amd
+    c = load_case(os.path.join(GOLDEN_DIR, "cfg2_full.npz"))
+    X, f, g, _ = _design(500, 4)
+    np.testing.assert_array_equal(X, c["x"])                       # bench.py's generator IS the fixture's input
+    np.testing.assert_allclose(f, c["f"], rtol=1e-14)
+    assert abs(c["ln_lkd"] - (-3.765538651174e+03)) < 1e-6
+    GP = gpgradpy_amd.GaussianProcess(4, True, "SqExp", "precon")
+    GP.set_data(X, f, np.zeros(500), g, np.zeros((500, 4)))
+    for mode in ("auto", "tile128", "blocked"):
+        GP.set_factor_mode(mode)
+        info, ok = GP.calc_lkd_all(GP.make_hp_class(theta=0.5 * np.ones(4)))
+        assert ok
+        tol.check_scalars(info.hp_beta[0], info.hp_varK, info.ln_det_Kmat, info.ln_lkd, c, GP.n_data, False)
+    ln = GP.calc_lkd_batch(np.log10(0.5) * np.ones((3, 4)))          # the batched path at the exact configuration
+    np.testing.assert_allclose(ln, c["ln_lkd"], rtol=tol.LN_LKD_RTOL)
+
+
+def test_cfg1_exact_configuration():
+    """BASELINE configs[0]: gradient-free SqExp, n = 200, d = 2 (reference probe: ln_lkd = 2.992208556656e+02)."""
+    import gpgradpy_amd
+    c = load_case(os.path.join(GOLDEN_DIR, "cfg1_full.npz"))
+    assert abs(c["ln_lkd"] - 2.992208556656e+02) < 1e-7 and c["wellcond"] == "base"
+    GP = gpgradpy_amd.GaussianProcess(2, False, "SqExp", "precon")   # 'precon' is coerced to 'base' (GaussianProcess.py:202-203)
+    GP.set_data(c["x"], c["f"], np.zeros(200))
+    info, ok = GP.calc_lkd_all(GP.make_hp_class(theta=0.5 * np.ones(2)))
+    assert ok and GP.wellcond_mtd == "base"
+    tol.check_scalars(info.hp_beta[0], info.hp_varK, info.ln_det_Kmat, info.ln_lkd, c, 200, False)
+
+
+@pytest.mark.timeout(900)
+def test_cfg3_full_size_against_oracle():
+    """BASELINE configs[2] at full size (n = 2000, d = 8, N = 18000): every scalar of the likelihood, alpha and the
+    posterior at 8 points asserted against ONE evaluation of the CPU oracle (about 10 s of LAPACK on the box's host
+    cores), under the tolerances of tests/tolerances.py; value + gradient against central differences."""
+    import gpgradpy_amd
+    from oracle import gp_oracle as orc
+    n, d = 2000, 8
+    X, f, g, hp_table = _design(n, d)
+    theta = 10.0 ** hp_table[0]
+    GP = gpgradpy_amd.GaussianProcess(d, True, "SqExp", "precon")
+    GP.set_data(X, f, np.zeros(n), g, np.zeros((n, d)))
+    hp = GP.make_hp_class(theta=theta)
+    info, ok = GP.calc_lkd_all(hp)
+    y = orc.make_data_vec(f, g)
+    N = y.size
+    r = orc.calc_lkd(X, y, theta, "SqExp", True, "precon", GP._etaK, np.zeros(N), False)
+    assert ok and r.ok and N == 18000
+    ref = dict(hp_beta=r.hp_beta, hp_varK=r.hp_varK, ln_det_Kmat=r.ln_det_Kmat, ln_lkd=r.ln_lkd)
+    tol.check_scalars(info.hp_beta[0], info.hp_varK, info.ln_det_Kmat, info.ln_lkd, ref, N, False)
+    # the batched launch (what bench.py times) gives the same number for this row
+    ln = GP.calc_lkd_batch(hp_table[:8])
+    assert abs(ln[0] - r.ln_lkd) <= tol.LN_LKD_RTOL * abs(r.ln_lkd)
+    # posterior: alpha residual against the oracle's covariance matrix, mu / sig at 8 points
+    hp2 = GP.optz_closed_form_hp(hp)
+    GP.set_hpara("set", 0, hp_vals=hp2)
+    alpha = GP.invKernEta_fdiff
+    Kcov = r.factor.Kcov
+    res = y.copy()
+    res[:n] -= hp2.beta[0]
+    rel = np.linalg.norm(Kcov @ alpha - res) / (np.linalg.norm(Kcov, "fro") * np.linalg.norm(alpha))
+    assert rel <= tol.ALPHA_RESIDUAL, rel
+    assert np.linalg.norm(alpha - r.alpha) <= tol.ALPHA_NORMWISE * np.linalg.norm(r.alpha)
+    xq = np.random.default_rng(5).uniform(-2, 2, (8, d))
+    m = orc.setup_eval_model(X, y, theta, "SqExp", True, "precon", GP._etaK, np.zeros(N), r.hp_beta, hp2.varK)
+    mu_o, sig_o = orc.eval_model(m, xq)
+    mu, sig, dmudx, dsigdx = GP.eval_model(xq, calc_grad=True)[:4]
+    np.testing.assert_allclose(mu, mu_o, rtol=tol.MU_RTOL, atol=tol.MU_ATOL_SCALE * max(1.0, np.abs(mu_o).max()))
+    np.testing.assert_allclose(sig, sig_o, rtol=tol.SIG_RTOL, atol=tol.SIG_ATOL_SCALE * np.sqrt(hp2.varK))
+    _, _, dmu_o, dsig_o = orc.eval_model_grad(m, xq[:2])
+    tol.check_post_grad(dmudx[:2], dsigdx[:2], dict(dmudx=dmu_o, dsigdx=dsig_o))
+    # likelihood gradient at full size: adjoint on the device against central differences of the device likelihood
+    info_g, ok_g = GP.calc_lkd_all(hp, calc_grad=True)
+    assert ok_g and abs(info_g.ln_lkd - info.ln_lkd) <= 1e-12 * abs(info.ln_lkd)
+    k = int(np.argmax(np.abs(info_g.ln_lkd_grad)))
+    h = 1e-4 * theta[k]
+    tp, tm = theta.copy(), theta.copy()
+    tp[k] += h
+    tm[k] -= h
+    fd = (GP.calc_lkd_all(GP.make_hp_class(theta=tp))[0].ln_lkd - GP.calc_lkd_all(GP.make_hp_class(theta=tm))[0].ln_lkd) / (2 * h)
+    assert abs(fd - info_g.ln_lkd_grad[k]) <= 2e-3 * abs(fd), (fd, info_g.ln_lkd_grad[k])
+
+
+def test_likelihood_calls_do_not_disturb_the_posterior():
+    """The reference keeps KernEta_chofac / invKernEta_fdiff across later calc_lkd_all calls (GpEvalModel.py:17-57; BO
+    loops interleave them).  Every kind of likelihood call between setup_eval_model and eval_model must leave the
+    posterior answering from ITS factor."""
+    import gpgradpy_amd
+    c = load_case(os.path.join(GOLDEN_DIR, "SqExp_none_n64_d8.npz"))
+    GP = gpgradpy_amd.GaussianProcess(c["d"], True, "SqExp", "precon")
+    GP.set_data(c["x"], c["f"], c["std_f"], c["g"], c["std_g"])
+    hp = GP.optz_closed_form_hp(GP.make_hp_class(theta=c["theta"]))
+    GP.set_hpara("set", 0, hp_vals=hp)
+    other = GP.make_hp_class(theta=c["theta"] * 3.0)
+    rows = np.log10(c["theta"])[None, :] + np.linspace(-0.5, 0.5, 9)[:, None]
+    GP.calc_lkd_all(other)                                            # single evaluation
+    GP.calc_lkd_all(other, calc_grad=True)                            # value + gradient
+    GP.calc_lkd_batch(rows)                                           # batched launch
+    GP.calc_Kern_w_chofac(None, other, materialize=True)              # 7-tuple with downloads
+    mu, sig, dmudx, dsigdx = GP.eval_model(c["xq"], calc_grad=True)[:4]
+    np.testing.assert_allclose(mu, c["mu"], rtol=tol.MU_RTOL, atol=tol.MU_ATOL_SCALE * max(1.0, np.abs(c["mu"]).max()))
+    np.testing.assert_allclose(sig, c["sig"], rtol=tol.SIG_RTOL, atol=tol.SIG_ATOL_SCALE * np.sqrt(hp.varK))
+    tol.check_post_grad(dmudx, dsigdx, c)
+    # KernEta_chofac is SciPy's (c, lower) pair, downloaded on first use from the posterior's own workspace --
+    # after all those likelihood calls it still is the factor of the model's matrix
+    y = GP.make_data_vec(c["f"], c["g"])
+    r = y.copy()
+    r[:c["n"]] -= hp.beta[0]
+    a = cho_solve(GP.KernEta_chofac, r)
+    assert np.linalg.norm(a - GP.invKernEta_fdiff) <= 1e-6 * np.linalg.norm(a)
+    L, lower = GP.KernEta_chofac
+    assert lower is True and L.shape == (GP.n_data, GP.n_data) and np.allclose(np.triu(L, 1), 0.0)
+    # and the likelihood side still answers for ITS hyperparameters
+    info, ok = GP.calc_lkd_all(GP.make_hp_class(theta=c["theta"]))
+    assert ok and abs(info.ln_lkd - c["ln_lkd"]) <= tol.LN_LKD_RTOL * abs(c["ln_lkd"])
+    # a new data set invalidates the model, as in the reference (eval_model asserts on the factor)
+    GP.set_data(c["x"][:10], c["f"][:10], c["std_f"][:10], c["g"][:10], c["std_g"][:10])
+    with pytest.raises((AssertionError, Exception)):
+        GP.eval_model(c["xq"])
+
+
+def test_setup_eval_model_with_cond():
+    """setup_eval_model(calc_cond=True) / set_hpara(..., calc_cond=True) (GpEvalModel.py:39-41, GaussianProcess.py:365,395):
+    condK = 2-norm condition number of the matrix the model factorised."""
+    import gpgradpy_amd
+    from oracle import gp_oracle as orc
+    c = load_case(os.path.join(GOLDEN_DIR, "Ma5f2_known_n17_d4.npz"))
+    GP = gpgradpy_amd.GaussianProcess(c["d"], True, "Ma5f2", "precon")
+    GP.set_data(c["x"], c["f"], c["std_f"], c["g"], c["std_g"])
+    hp = GP.optz_closed_form_hp(GP.make_hp_class(theta=c["theta"], varK=c["varK_in"]))
+    GP.set_hpara("set", 0, hp_vals=hp, calc_cond=True)
+    nv = orc.calc_noise_vec(c["n"], c["d"], True, c["std_f"], c["std_g"])
+    fac = orc.calc_all_K_w_chofac(c["x"], c["theta"], "Ma5f2", True, "precon", c["etaK"], nv, varK=1.0)   # b_normlz_w_varK: varK := 1
+    want = np.linalg.cond(fac.Kcov / np.outer(fac.pvec, fac.pvec))     # Kcov_precon = P^-1 Kcov P^-1 (Kernel.py:236,240)
+    np.testing.assert_allclose(GP.condK, want, rtol=1e-6)
+    GP.cond_norm = "fro"
+    with pytest.raises(NotImplementedError):
+        GP.setup_eval_model(calc_cond=True)
+    with pytest.raises(NotImplementedError):
+        GP.calc_lkd_all(hp, calc_cond=True)                          # silently returning the 2-norm would be wrong
+
+
+EVAR = ["evar_SqExp_none_n20_d3", "evar_Ma5f2_known_n25_d2", "evar_RatQu_none_n30_d2_nograd"]
+
+
+@pytest.mark.parametrize("name", EVAR)
+def test_eval_model_var_against_reference(name):
+    import gpgradpy_amd
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    d, use_grad, kernel = int(z["d"]), bool(z["use_grad"]), str(z["kernel"])
+    GP = gpgradpy_amd.GaussianProcess(d, use_grad, kernel, str(z["wellcond"]) if use_grad else "base")
+    if use_grad:
+        GP.set_data(z["x"], z["f"], z["std_f"], z["g"], z["std_g"])
+    else:
+        GP.set_data(z["x"], z["f"], z["std_f"])
+    hp = GP.make_hp_class(beta=z["beta"], theta=z["theta"], kernel=None if np.isnan(z["hp_kernel"]) else float(z["hp_kernel"]),
+                          varK=float(z["varK"]))
+    GP.set_hpara("set", 0, hp_vals=hp)
+    sig2, dsig2dx, h = GP.eval_model_var(z["xq"], calc_grad=True)
+    varK = float(z["varK"])
+    assert h is None and dsig2dx.shape == z["dsig2dx"].shape
+    np.testing.assert_allclose(sig2, z["sig2"], rtol=1e-5, atol=(tol.SIG_ATOL_SCALE ** 2) * varK + 1e-7 * varK)
+    scale = np.abs(z["dsig2dx"]).max()
+    np.testing.assert_allclose(dsig2dx, z["dsig2dx"], rtol=1e-5, atol=1e-6 * scale)
+    s0, g0, _ = GP.eval_model_var(z["xq"][1], calc_grad=True, squeeze_nx=True)
+    assert np.isclose(s0, sig2[1], rtol=1e-10, atol=1e-300) and g0.shape == (d,)
+    s_only, none_g, _ = GP.eval_model_var(z["xq"])
+    assert none_g is None and np.allclose(s_only, sig2, rtol=1e-10, atol=1e-300)
+    # consistency with eval_model: sig = sqrt(sig2), dsig2dx = 2 sig dsigdx where sig > 0
+    mu, sig, _, dsigdx = GP.eval_model(z["xq"], calc_grad=True)[:4]
+    np.testing.assert_allclose(sig ** 2, sig2, rtol=1e-9, atol=1e-300)
+    np.testing.assert_allclose(2 * sig[:, None] * dsigdx, dsig2dx, rtol=1e-9, atol=1e-12 * scale)
+    with pytest.raises(Exception, match="d2sig2dx2"):
+        GP.eval_model_var(z["xq"][0], calc_grad=True, calc_hess=True)
+
+
+def test_failed_cholesky_objective():
+    """OptzLkd.py:74-77: when the Cholesky fails the optimiser's objective is minus the condition number, its slope
+    minus the condition number's gradient.  At a failure the matrix is numerically singular (cond ~ 1e21 here), so the
+    reference's own numbers are rounding noise in the last digits: orders of magnitude and finiteness are pinned."""
+    import gpgradpy_amd
+    z = np.load(os.path.join(GOLDEN_DIR, "failobj_SqExp_n20_d2.npz"))
+    n, d = z["x"].shape
+    GP = gpgradpy_amd.GaussianProcess(d, True, "SqExp", "base")
+    GP.set_data(z["x"], z["f"], np.zeros(n), z["g"], np.zeros((n, d)))
+    GP._etaK = GP._eta_Kgrad = float(z["etaK"])
+    GP._last_hp_vec = np.full((1, d), np.nan)
+    val, grad, cond, cond_grad = GP.calc_store_likelihood(z["hp_vec"])
+    assert not GP._last_chofac_good
+    assert np.isfinite(val) and val == -cond and cond > 1e15
+    assert abs(np.log10(cond) - np.log10(float(z["cond"]))) < 3.0
+    assert grad.shape == (d,) and np.all(np.isfinite(grad)) and np.array_equal(grad, -cond_grad)
+    # the same through 'precon' (the reference has no cond_grad there and stops with a TypeError): finite, zero slope
+    GP2 = gpgradpy_amd.GaussianProcess(d, True, "SqExp", "precon")
+    GP2.set_data(z["x"], z["f"], np.zeros(n), z["g"], np.zeros((n, d)))
+    GP2._etaK = GP2._eta_Kgrad = -0.9                                   # makes the preconditioned matrix indefinite
+    GP2._last_hp_vec = np.full((1, d), np.nan)
+    v2, g2 = GP2.calc_store_likelihood(z["hp_vec"])[:2]
+    assert np.isfinite(v2) and v2 < 0 and np.all(g2 == 0.0)
+    # SLSQP over a start row that fails does not stall on NaN and does not raise
+    from scipy.optimize import Bounds
+    best, _, info = GP.optz_hp_max_lkd(np.array([z["hp_vec"]]), Bounds(z["hp_vec"] - 1.0, z["hp_vec"] + 3.0, keep_feasible=True))
+    assert np.all(np.isfinite(best))

@@ -43,9 +43,13 @@ def _worker(rank, world, port, fixture, out_dir):
             ln[0] = np.nan
         return ln
 
-    hp_best, ln_all, idx = select_best_restart(z["hp_x0"], eval_with_failure)
+    hp_best, ln_all, idx = select_best_restart(z["hp_x0"], eval_with_failure, group=dist.group.WORLD)
     lo, hi = shard_rows(len(z["hp_x0"]), world, rank)
     assert calls == [hi - lo]
+    # sharding is opt-in: without a group every rank evaluates all rows itself, whatever torch.distributed is used for
+    calls.clear()
+    _, ln_solo, idx_solo = select_best_restart(z["hp_x0"][:6], eval_fn)
+    assert calls == [6] and idx_solo == int(np.nanargmax(ln_solo))
     np.save(os.path.join(out_dir, f"ln_{rank}.npy"), ln_all)
     np.save(os.path.join(out_dir, f"idx_{rank}.npy"), np.array([idx]))
     dist.destroy_process_group()
@@ -95,6 +99,8 @@ def _optz_worker(rank, world, port, out_dir):
             return np.array([2 * (x[0] + 2), 2 * (x[1] - 1)]) if a < b else np.array([4 * (x[0] - 1), 2 * (x[1] + 1)])
 
     gp = Fake()
+    gp.shard_restarts = lambda g: setattr(gp, "restart_group", g)
+    gp.shard_restarts(dist.group.WORLD)
     x0 = np.array([[-2.5, 1.5], [-1.5, 0.5], [0.5, -0.5], [2.0, -2.0], [0.9, -1.2]])
     best, cond, info = gp.optz_hp_max_lkd(x0, Bounds([-5, -5], [5, 5], keep_feasible=True))
     np.save(os.path.join(out_dir, f"best_{rank}.npy"), best)
@@ -113,3 +119,62 @@ def test_optimiser_multistart_sharded_two_ranks_gloo(tmp_path):
     np.testing.assert_allclose(b0, [1.0, -1.0], atol=1e-5)     # the deeper basin, found by a start of rank 1's block
     assert np.all(np.isfinite(o0)) and o0.shape == (5,)
     assert np.isclose(o0[:2], 1.0, atol=1e-8).all() and np.isclose(o0[2:], 0.0, atol=1e-8).all()
+
+
+def _failing_worker(rank, world, port, out_dir):
+    """Rank 1's local evaluation raises: it must still join the all_gather (no hang on rank 0), then re-raise; rank 0
+    gets RankFailure naming the failed rank."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import datetime
+    import torch.distributed as dist
+    from gpgradpy_amd.multistart import RankFailure, gather_rows, select_best_restart
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+
+    def eval_fn(rows):
+        if rank == 1:
+            raise ValueError("device evaluation failed on this rank")
+        return -np.sum(rows ** 2, axis=1)
+
+    x0 = np.arange(12.0).reshape(6, 2)
+    outcome = []
+    try:
+        select_best_restart(x0, eval_fn, group=dist.group.WORLD)
+        outcome.append("returned")
+    except ValueError:
+        outcome.append("own-error")
+    except RankFailure as e:
+        outcome.append("rank-failure:" + str(e))
+    # tolerant form: the caller asks for the table and the list of failed ranks
+    if rank == 0:
+        hp_best, ln_all, idx, bad = select_best_restart(x0, eval_fn, group=dist.group.WORLD, return_failed=True)
+        assert bad == [1] and np.isnan(ln_all[3:]).all() and idx == 0
+    else:
+        try:
+            select_best_restart(x0, eval_fn, group=dist.group.WORLD, return_failed=True)
+        except ValueError:
+            pass
+    try:
+        gather_rows(np.ones((3, 2)) * rank, 6, group=dist.group.WORLD, error=RuntimeError("boom") if rank == 1 else None)
+        outcome.append("returned")
+    except RuntimeError as e:
+        outcome.append(type(e).__name__)
+    with open(os.path.join(out_dir, f"outcome_{rank}.txt"), "w") as fh:
+        fh.write("|".join(outcome))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_failing_rank_still_joins_the_collective(tmp_path):
+    world = 2
+    mp.spawn(_failing_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    o0 = open(tmp_path / "outcome_0.txt").read().split("|")
+    o1 = open(tmp_path / "outcome_1.txt").read().split("|")
+    assert o0[0].startswith("rank-failure:") and "[1]" in o0[0] and o0[1] == "RankFailure"
+    assert o1 == ["own-error", "RuntimeError"]
+
+
+def test_all_rows_failed_is_a_clear_error():
+    from gpgradpy_amd.multistart import select_best_restart
+    with pytest.raises(RuntimeError, match="every restart row failed"):
+        select_best_restart(np.zeros((3, 2)), lambda rows: np.full(len(rows), np.nan))
