@@ -17,8 +17,8 @@ PROF_NCAT = len(PROF_CATS)
 
 # every symbol include/gpgrad.h declares
 ABI_SYMBOLS = (
-    "gpg_create", "gpg_destroy", "gpg_last_error", "gpg_set_grad_mask", "gpg_set_data", "gpg_lkd", "gpg_lkd_grad", "gpg_lkd_batch",
-    "gpg_setup_eval", "gpg_predict", "gpg_predict_grad", "gpg_predict_var", "gpg_predict_hess", "gpg_get_matrix", "gpg_factor_apply", "gpg_dcov_quadform", "gpg_prof_enable", "gpg_prof_read", "gpg_set_panel", "gpg_set_lookahead", "gpg_set_factor_mode", "gpg_factor_fallbacks", "gpg_last_factor", "gpg_set_batch", "gpg_reserve_batch",
+    "gpg_create", "gpg_destroy", "gpg_last_error", "gpg_set_grad_mask", "gpg_set_data", "gpg_lkd", "gpg_lkd_grad", "gpg_lkd_batch", "gpg_lkd_grad_batch",
+    "gpg_setup_eval", "gpg_predict", "gpg_predict_grad", "gpg_predict_var", "gpg_predict_hess", "gpg_get_matrix", "gpg_kern_rtensor", "gpg_factor_apply", "gpg_dcov_quadform", "gpg_prof_enable", "gpg_prof_read", "gpg_set_panel", "gpg_set_lookahead", "gpg_set_factor_mode", "gpg_factor_fallbacks", "gpg_last_factor", "gpg_set_batch", "gpg_reserve_batch",
     "gpg_device_info",
 )
 
@@ -68,6 +68,8 @@ def load():
     lib.gpg_lkd_grad.restype = C.c_int
     lib.gpg_lkd_batch.argtypes = [vp, C.c_int, dp, C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(GpgLkdOut)]
     lib.gpg_lkd_batch.restype = C.c_int
+    lib.gpg_lkd_grad_batch.argtypes = [vp, C.c_int, dp, C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(GpgLkdOut), dp, dp]
+    lib.gpg_lkd_grad_batch.restype = C.c_int
     lib.gpg_setup_eval.argtypes = [vp, C.POINTER(GpgHp), C.c_double, dp]
     lib.gpg_setup_eval.restype = C.c_int
     lib.gpg_predict.argtypes = [vp, C.c_int, dp, C.c_double, dp, dp, dp]
@@ -80,6 +82,9 @@ def load():
     lib.gpg_predict_hess.restype = C.c_int
     lib.gpg_get_matrix.argtypes = [vp, C.POINTER(GpgHp), C.c_int, dp]
     lib.gpg_get_matrix.restype = C.c_int
+    lib.gpg_kern_rtensor.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, C.c_double, C.c_int,
+                                     C.POINTER(C.c_ubyte), C.POINTER(C.c_ubyte), dp]
+    lib.gpg_kern_rtensor.restype = C.c_int
     lib.gpg_prof_enable.argtypes = [vp, C.c_uint]
     lib.gpg_prof_enable.restype = C.c_int
     lib.gpg_prof_read.argtypes = [vp, dp, C.POINTER(C.c_longlong), dp]

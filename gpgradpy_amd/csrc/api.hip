@@ -180,6 +180,7 @@ int gpg_create(gpg_ctx** out, int device, int n_eval, int dim, int use_grad, int
     }                                                                                \
   } while (0)
   CREATE_OK(hipSetDevice(device));
+  CREATE_OK(hipDeviceGetAttribute(&c->num_cus, hipDeviceAttributeMultiprocessorCount, device));
   {
     int prio_lo = 0, prio_hi = 0;
     CREATE_OK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));   // numerically lowest = highest priority
@@ -223,7 +224,8 @@ void gpg_destroy(gpg_ctx* c) {
   double* bufs[] = {c->ws[0].A, c->ws[0].dvec, c->ws[0].invp, c->ws[0].zvec, c->ws[0].tmpv, c->ws[0].dinv,
                     c->ws[1].A, c->ws[1].dvec, c->ws[1].invp, c->ws[1].zvec, c->ws[1].tmpv, c->ws[1].dinv,
                     c->Xt, c->y, c->noise, c->scal, c->Wt, c->xq_dev,
-                    c->musig, c->gradbuf, c->dense_tmp, c->Wfull, c->Minv, c->gpartial, c->batchA, c->batchV, c->vec_rows, c->vec_x, c->apply_buf};
+                    c->musig, c->gradbuf, c->dense_tmp, c->Wfull, c->Minv, c->gpartial, c->batchA, c->batchV, c->vec_rows, c->vec_x, c->apply_buf,
+                    c->batchW, c->batchM, c->batchZ, c->gres};
   for (double* b : bufs) if (b) (void)hipFree(b);
   if (c->info) (void)hipFree(c->info);
   if (c->gpos) (void)hipFree(c->gpos);
@@ -260,6 +262,7 @@ int gpg_set_grad_mask(gpg_ctx* c, const unsigned char* use_grad_pt) {
   if (c->dense_tmp) { (void)hipFree(c->dense_tmp); c->dense_tmp = nullptr; }
   if (c->batchA) { (void)hipFree(c->batchA); (void)hipFree(c->batchV); c->batchA = c->batchV = nullptr; c->batch_cap = 0; }
   if (c->Wfull) { (void)hipFree(c->Wfull); (void)hipFree(c->Minv); c->Wfull = c->Minv = nullptr; }
+  if (c->batchW) { (void)hipFree(c->batchW); (void)hipFree(c->batchM); (void)hipFree(c->batchZ); c->batchW = c->batchM = c->batchZ = nullptr; c->gbatch_cap = 0; }
   if (c->Wt) { (void)hipFree(c->Wt); (void)hipFree(c->xq_dev); (void)hipFree(c->musig); (void)hipFree(c->gradbuf); c->Wt = c->xq_dev = c->musig = c->gradbuf = nullptr; c->xq_cap = 0; }
   return 0;
 }
@@ -505,6 +508,155 @@ static int gpg_lkd_batch_once(gpg_ctx* c, int m, const double* hp_rows, int row_
   return 0;
 }
 
+// Value + adjoint gradient of m restart rows (gpg_lkd_grad_batch).  Groups of up to B rows: ONE launch each of
+// prep / assembly / factorisation / reduction for the group (as gpg_lkd_batch), the short per-matrix steps (alpha by the
+// vector solve) one after the other, then ONE launch each of W = L^-T and -(W W^T) for the whole group, then the fused
+// contraction per matrix.  One synchronisation at the end.  Same arithmetic per row as gpg_lkd_grad (bit-identical).
+static int gpg_lkd_grad_batch_once(gpg_ctx* c, int m, const double* hp_rows, int row_len, double eta, int wellcond,
+                                   int closed_form_varK, gpg_lkd_out* out, double* g_aa, double* g_inv) {
+  if (!c) return -1;
+  if (m < 1 || !hp_rows || !out || !g_aa || !g_inv || row_len < c->d + 3) { c->err = "bad batch arguments (row_len >= d + 3)"; return -1; }
+  GPG_HIP_OK(c, hipSetDevice(c->device));
+  GPG_WS(c, 0);
+  int rc = ensure_scal(c, m);
+  if (rc) return rc;
+  if (m > c->items_cap) {
+    if (c->items_dev) (void)hipFree(c->items_dev);
+    if (c->items_host) (void)hipHostFree(c->items_host);
+    c->items_dev = c->items_host = nullptr; c->items_cap = 0;
+    GPG_HIP_OK(c, hipMalloc(&c->items_dev, sizeof(gpg_batch_item) * m));
+    GPG_HIP_OK(c, hipHostMalloc(&c->items_host, sizeof(gpg_batch_item) * m));
+    c->items_cap = m;
+  }
+  std::vector<gpg_hp> hps(m);
+  for (int i = 0; i < m; ++i) {
+    const double* row = hp_rows + (size_t)i * row_len;
+    hps[i].theta = row;
+    hps[i].varK_mat = row[c->d];
+    hps[i].var_fval = row[c->d + 1];
+    hps[i].var_fgrad = row[c->d + 2];
+    hps[i].eta = eta;
+    hps[i].wellcond = wellcond;
+    hps[i].closed_form_varK = closed_form_varK;
+    hps[i].hp_kernel = row_len >= c->d + 4 ? row[c->d + 3] : 0.0;
+    rc = check_hp(c, &hps[i]);
+    if (rc) return rc;
+  }
+  const int slots = GPG_GRAD_SLOTS_MAX, nval = 2 * slots;
+  const int ns = c->d + 3 + (c->kernel == GPG_KERNEL_RATQU ? 1 : 0);
+  // rows per group: what the value path batches (batch_plan also allocates batchA / batchV), at most 8, and within
+  // 96 GB for the two Npad^2 arrays (W, Minv) per matrix
+  int B = batch_plan(c, m);
+  const size_t nn = (size_t)c->Npad * c->Npad;
+  if (B > 8) B = 8;
+  while (B > 1 && 2 * nn * sizeof(double) * B > ((size_t)96 << 30)) --B;
+  const bool dataflow = c->chol_impl != 0 || c->tail_cols != 0;
+  if (!dataflow || c->Npad < 512) B = 1;           // blocked mode / tiny matrices: one row at a time through gpg_lkd_grad's steps
+  if (B > c->gbatch_cap) {
+    if (c->batchW) (void)hipFree(c->batchW);
+    if (c->batchM) (void)hipFree(c->batchM);
+    if (c->batchZ) (void)hipFree(c->batchZ);
+    c->batchW = c->batchM = c->batchZ = nullptr; c->gbatch_cap = 0;
+    GPG_HIP_OK(c, hipMalloc(&c->batchW, sizeof(double) * nn * B));
+    GPG_HIP_OK(c, hipMalloc(&c->batchM, sizeof(double) * nn * B));
+    GPG_HIP_OK(c, hipMalloc(&c->batchZ, sizeof(double) * (size_t)c->vec_rows_cols * B));
+    c->gbatch_cap = B;
+  }
+  const int nblk = gpg_grad_partial_blocks(c);
+  if (!c->gpartial) GPG_HIP_OK(c, hipMalloc(&c->gpartial, sizeof(double) * (size_t)nval * (nblk + 1)));
+  if (m > c->gres_cap) {
+    if (c->gres) (void)hipFree(c->gres);
+    c->gres = nullptr; c->gres_cap = 0;
+    GPG_HIP_OK(c, hipMalloc(&c->gres, sizeof(double) * (size_t)nval * m));
+    c->gres_cap = m;
+  }
+  GPG_HIP_OK(c, hipMemsetAsync(c->info, 0, sizeof(int) * m, c->stream));
+  GPG_HIP_OK(c, hipMemsetAsync(c->gres, 0, sizeof(double) * (size_t)nval * m, c->stream));
+  if (B <= 1) {   // one row at a time, still queued back-to-back with one synchronisation
+    if (!c->Wfull) {
+      GPG_HIP_OK(c, hipMalloc(&c->Wfull, sizeof(double) * nn));
+      GPG_HIP_OK(c, hipMalloc(&c->Minv, sizeof(double) * nn));
+    }
+    for (int i = 0; i < m; ++i) {
+      enqueue_lkd(c, &hps[i], i);
+      AsmParams p = make_params(c, &hps[i], 0);
+      gpg_launch_combine_rows(c, i);
+      gpg_backward_solve(c);
+      gpg_inverse_from_factor(c, c->Wfull, c->Minv);
+      gpg_launch_grad_contract(c, p, c->gpartial, c->gres + (size_t)nval * i, c->zvec, c->Minv);
+    }
+  } else {
+    struct Restore {
+      gpg_ctx* c; double *A, *dvec, *invp, *dinv, *zvec; int* info;
+      ~Restore() { c->A = A; c->dvec = dvec; c->invp = invp; c->dinv = dinv; c->zvec = zvec; c->info = info; }
+    } restore{c, c->A, c->dvec, c->invp, c->dinv, c->zvec, c->info};
+    int* info0 = c->info;
+    c->prep_valid = false;
+    c->last_factor_ws = 0;
+    const size_t vs = 3 * (size_t)c->Npad;
+    const int ngroups = (m + B - 1) / B;
+    const int Bq = (m + ngroups - 1) / ngroups;                   // equal groups
+    for (int r0 = 0; r0 < m; r0 += Bq) {
+      const int Bg = (m - r0) < Bq ? (m - r0) : Bq;
+      c->A = c->batchA;
+      c->dvec = c->batchV;
+      c->invp = c->dvec + c->Npad;
+      c->dinv = c->invp + c->Npad;
+      c->info = info0;
+      for (int b = 0; b < Bg; ++b) {
+        gpg_batch_item& it = c->items_host[r0 + b];
+        it.p = make_params(c, &hps[r0 + b], 0);
+        it.var_fval = hps[r0 + b].var_fval;
+        it.var_fgrad = hps[r0 + b].var_fgrad;
+      }
+      c->last_precon = c->items_host[r0].p.precon;
+      GPG_HIP_OK(c, hipMemcpyAsync(c->items_dev + r0, c->items_host + r0, sizeof(gpg_batch_item) * Bg, hipMemcpyHostToDevice, c->stream));
+      gpg_launch_prep_assembly_batch(c, c->items_host[r0].p, Bg, c->items_dev + r0, vs, c->A_elems);
+      if (Bg > 1) gpg_launch_tile_chol_batch(c, Bg, c->batchA, c->A_elems, c->batchV + 2 * (size_t)c->Npad, 3 * c->Npad, info0 + r0);
+      else { c->info = info0 + r0; gpg_cholesky(c); c->info = info0; }
+      gpg_launch_lkd_reduce_batch(c, r0, Bg, vs, c->A_elems);
+      for (int b = 0; b < Bg; ++b) {     // alpha of matrix b: RHS row 0 <- w2 - beta w1, then z = L^-T (.) by the vector solve
+        c->A = c->batchA + (size_t)b * c->A_elems;
+        c->dinv = c->batchV + (size_t)b * vs + 2 * (size_t)c->Npad;
+        c->zvec = c->batchZ + (size_t)b * c->vec_rows_cols;
+        c->info = info0 + r0 + b;
+        gpg_launch_combine_rows(c, r0 + b);
+        gpg_backward_solve(c);
+      }
+      c->info = info0;
+      if (!gpg_launch_tile128_inverse_batch(c, Bg, c->batchA, c->A_elems, c->batchV + 2 * (size_t)c->Npad, 3 * c->Npad, c->batchW,
+                                            c->batchM, info0 + r0)) {
+        c->err = "batched inverse could not be launched";
+        return -2;
+      }
+      for (int b = 0; b < Bg; ++b) {
+        c->invp = c->batchV + (size_t)b * vs + c->Npad;
+        gpg_launch_grad_contract(c, c->items_host[r0 + b].p, c->gpartial, c->gres + (size_t)nval * (r0 + b),
+                                 c->batchZ + (size_t)b * c->vec_rows_cols, c->batchM + (size_t)b * nn);
+      }
+    }
+  }
+  std::vector<double> hres((size_t)nval * m);
+  GPG_HIP_OK(c, hipMemcpyAsync(hres.data(), c->gres, sizeof(double) * hres.size(), hipMemcpyDeviceToHost, c->stream));
+  GPG_HIP_OK(c, hipMemcpyAsync(c->h_scal, c->scal, sizeof(double) * 8 * m, hipMemcpyDeviceToHost, c->stream));
+  GPG_HIP_OK(c, hipMemcpyAsync(c->h_info, c->info, sizeof(int) * m, hipMemcpyDeviceToHost, c->stream));
+  GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
+  GPG_HIP_OK(c, hipGetLastError());
+  GPG_LAUNCH_OK(c);
+  if (internal_failure(c, c->h_info, m)) return -4;
+  for (int i = 0; i < m; ++i) {
+    finish_lkd(c, &hps[i], c->h_scal + (size_t)8 * i, c->h_info[i], &out[i]);
+    double* ga = g_aa + (size_t)i * (c->d + 4);
+    double* gi = g_inv + (size_t)i * (c->d + 4);
+    for (int k = 0; k < c->d + 4; ++k) ga[k] = gi[k] = 0.0;
+    if (c->h_info[i] != 0) { for (int k = 0; k < c->d + 4; ++k) ga[k] = gi[k] = std::numeric_limits<double>::quiet_NaN(); continue; }
+    for (int k = 0; k < ns; ++k) { ga[k] = hres[(size_t)nval * i + k]; gi[k] = hres[(size_t)nval * i + ns + k]; }
+    if (c->kernel == GPG_KERNEL_RATQU) { ga[c->d + 3] = hres[(size_t)nval * i + ns - 1]; gi[c->d + 3] = hres[(size_t)nval * i + 2 * ns - 1]; }
+  }
+  c->factor_valid = false;
+  return 0;
+}
+
 static int gpg_setup_eval_once(gpg_ctx* c, const gpg_hp* hp, double beta, double* alpha_out) {
   int rc = check_hp(c, hp);
   if (rc) return rc;
@@ -567,6 +719,10 @@ int gpg_lkd_grad(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out, double* g_aa, d
 int gpg_lkd_batch(gpg_ctx* c, int m, const double* hp_rows, int row_len, double eta, int wellcond, int closed_form_varK,
                   gpg_lkd_out* out) {
   return with_fallback(c, [&] { return gpg_lkd_batch_once(c, m, hp_rows, row_len, eta, wellcond, closed_form_varK, out); });
+}
+int gpg_lkd_grad_batch(gpg_ctx* c, int m, const double* hp_rows, int row_len, double eta, int wellcond, int closed_form_varK,
+                       gpg_lkd_out* out, double* g_aa, double* g_inv) {
+  return with_fallback(c, [&] { return gpg_lkd_grad_batch_once(c, m, hp_rows, row_len, eta, wellcond, closed_form_varK, out, g_aa, g_inv); });
 }
 int gpg_setup_eval(gpg_ctx* c, const gpg_hp* hp, double beta, double* alpha_out) {
   return with_fallback(c, [&] { return gpg_setup_eval_once(c, hp, beta, alpha_out); });
@@ -750,6 +906,51 @@ int gpg_get_matrix(gpg_ctx* c, const gpg_hp* hp, int which, double* out) {
   GPG_HIP_OK(c, hipGetLastError());
   GPG_LAUNCH_OK(c);
   return 0;
+}
+
+int gpg_kern_rtensor(int device, int kernel, int dim, int n1, int n2, const double* rtensor, const double* theta, double hp_kernel,
+                     int use_grad, const unsigned char* use_grad1, const unsigned char* use_grad2, double* out) {
+  if (!rtensor || !theta || !out || dim < 1 || dim > GPG_MAX_DIM || n1 < 1 || n2 < 1) { g_create_err = "bad gpg_kern_rtensor arguments (1 <= dim <= 16)"; return -1; }
+  if (kernel != GPG_KERNEL_SQEXP && kernel != GPG_KERNEL_MA5F2 && kernel != GPG_KERNEL_RATQU) { g_create_err = "unknown kernel id"; return -1; }
+  if (kernel == GPG_KERNEL_RATQU && !(hp_kernel > 0.0)) { g_create_err = "hp_kernel (alpha of RatQu) must be positive"; return -1; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_create_err = "no HIP device visible"; return -2; }
+  if (device < 0 || device >= ndev) { g_create_err = "device index out of range"; return -1; }
+  std::vector<int> gp1(n1, -1), gp2(n2, -1);
+  int n1g = 0, n2g = 0;
+  if (use_grad) {
+    for (int a = 0; a < n1; ++a) if (!use_grad1 || use_grad1[a]) gp1[a] = n1g++;
+    for (int b = 0; b < n2; ++b) if (!use_grad2 || use_grad2[b]) gp2[b] = n2g++;
+  }
+  const size_t R1 = (size_t)n1 + (size_t)n1g * dim, C2 = (size_t)n2 + (size_t)n2g * dim;
+  const size_t nrt = (size_t)dim * n1 * n2;
+  double *d_rt = nullptr, *d_out = nullptr;
+  int *d_g1 = nullptr, *d_g2 = nullptr;
+  hipStream_t st = nullptr;
+  int rc = 0;
+  auto fail = [&](const char* what, hipError_t e) { g_create_err = std::string(what) + ": " + hipGetErrorString(e); rc = -2; };
+  hipError_t e;
+  if ((e = hipSetDevice(device)) != hipSuccess) fail("hipSetDevice", e);
+  if (!rc && (e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) fail("hipStreamCreate", e);
+  if (!rc && (e = hipMalloc(&d_rt, sizeof(double) * nrt)) != hipSuccess) fail("hipMalloc(rtensor)", e);
+  if (!rc && (e = hipMalloc(&d_out, sizeof(double) * R1 * C2)) != hipSuccess) fail("hipMalloc(out)", e);
+  if (!rc && (e = hipMalloc(&d_g1, sizeof(int) * n1)) != hipSuccess) fail("hipMalloc(gpos1)", e);
+  if (!rc && (e = hipMalloc(&d_g2, sizeof(int) * n2)) != hipSuccess) fail("hipMalloc(gpos2)", e);
+  if (!rc && (e = hipMemcpyAsync(d_rt, rtensor, sizeof(double) * nrt, hipMemcpyHostToDevice, st)) != hipSuccess) fail("copy rtensor", e);
+  if (!rc && (e = hipMemcpyAsync(d_g1, gp1.data(), sizeof(int) * n1, hipMemcpyHostToDevice, st)) != hipSuccess) fail("copy gpos1", e);
+  if (!rc && (e = hipMemcpyAsync(d_g2, gp2.data(), sizeof(int) * n2, hipMemcpyHostToDevice, st)) != hipSuccess) fail("copy gpos2", e);
+  if (!rc && (e = hipMemsetAsync(d_out, 0, sizeof(double) * R1 * C2, st)) != hipSuccess) fail("memset out", e);
+  if (!rc && gpg_kern_rtensor_run(kernel, dim, n1, n2, n1g, n2g, use_grad ? 1 : 0, theta, hp_kernel, d_rt, d_g1, d_g2, d_out, st) != 0) {
+    g_create_err = "rtensor kernel launch failed"; rc = -2;
+  }
+  if (!rc && (e = hipMemcpyAsync(out, d_out, sizeof(double) * R1 * C2, hipMemcpyDeviceToHost, st)) != hipSuccess) fail("copy out", e);
+  if (!rc && (e = hipStreamSynchronize(st)) != hipSuccess) fail("hipStreamSynchronize", e);
+  if (d_rt) (void)hipFree(d_rt);
+  if (d_out) (void)hipFree(d_out);
+  if (d_g1) (void)hipFree(d_g1);
+  if (d_g2) (void)hipFree(d_g2);
+  if (st) (void)hipStreamDestroy(st);
+  return rc;
 }
 
 int gpg_dcov_quadform(gpg_ctx* c, const gpg_hp* hp, const double* v, double* out) {

@@ -12,6 +12,7 @@
 // Mapping: lane <-> data point a (rows r = I*n + a are contiguous in a, so every store instruction of
 // a wave writes 512 contiguous bytes of one matrix column); each thread walks TB columns b and emits
 // the (d+1)(d+2)/2 block entries of the ordered pair (a, b) that fall in the lower triangle.
+#include <cstring>
 #include "gpg_internal.h"
 
 namespace {
@@ -269,6 +270,80 @@ __global__ void __launch_bounds__(256) cross_kernel(AsmParams P, const double* _
   }
 }
 
+// Kernel table entry points of the reference (Kernel.py:27-126: calc_KernBase / calc_KernGrad take the [d, n1, n2]
+// difference tensor, NOT point sets): one thread per pair (a, b) reads R[:, a, b] and emits the (d+1)^2 block entries of
+// KernelSqExp.py:381-408 / KernelMatern5f2.py:421-447 / KernelRatQuad.py:523-552 in those lines' operation order
+// (this file is compiled with -ffp-contract=off).  out is row-major [n1 + n1g d, n2 + n2g d] (NumPy C order); gradient
+// rows / columns exist for the points selected by bvec_use_grad1 / 2 (gpos = position among them, -1 = not used).
+struct RtParams { int d, n1, n2, n1g, n2g, use_grad; double hp_kernel; double theta[GPG_MAX_DIM]; };
+
+template <int KERN>
+__global__ void __launch_bounds__(256) rtensor_kern_kernel(RtParams P, const double* __restrict__ Rt, const int* __restrict__ gpos1,
+                                                           const int* __restrict__ gpos2, double* __restrict__ out) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long np = (long long)P.n1 * P.n2;
+  if (t >= np) return;
+  const int a = (int)(t / P.n2), b = (int)(t - (long long)a * P.n2);
+  const int d = P.d;
+  double R[GPG_MAX_DIM];
+  double s = 0.0;
+  for (int k = 0; k < d; ++k) {
+    R[k] = Rt[(size_t)k * np + t];
+    if (KERN == GPG_KERNEL_SQEXP) s -= P.theta[k] * (R[k] * R[k]);
+    else s += P.theta[k] * (R[k] * R[k]);
+  }
+  double E, M1 = 0.0, K00, c2;                      // c2: factor of the mixed second derivatives
+  if (KERN == GPG_KERNEL_SQEXP) {
+    E = exp(s); K00 = E; c2 = -4.0;
+  } else if (KERN == GPG_KERNEL_RATQU) {
+    const double Bq = 1.0 + s / P.hp_kernel;
+    K00 = pow(Bq, -P.hp_kernel);
+    M1 = pow(Bq, -P.hp_kernel - 1.0);
+    E = pow(Bq, -P.hp_kernel - 2.0);
+    c2 = -(4.0 * (1.0 + 1.0 / P.hp_kernel));
+  } else {
+    const double sqrt5 = sqrt(5.0), nu = sqrt(s);
+    E = exp(-sqrt5 * nu);
+    M1 = ((5.0 / 3.0) * (1.0 + sqrt5 * nu)) * E;
+    K00 = (1.0 + sqrt5 * nu + (5.0 / 3.0) * (nu * nu)) * E;
+    c2 = -(25.0 / 3.0);
+  }
+  const size_t C2 = (size_t)P.n2 + (P.use_grad ? (size_t)P.n2g * d : 0);
+  out[(size_t)a * C2 + b] = K00;
+  if (!P.use_grad) return;
+  const int g1 = gpos1[a], g2 = gpos2[b];
+  for (int i = 0; i < d; ++i) {
+    const double th = P.theta[i];
+    double v10, v01, vii;
+    if (KERN == GPG_KERNEL_SQEXP) {
+      v10 = ((-2.0 * th) * R[i]) * E;
+      v01 = ((2.0 * th) * R[i]) * E;
+      vii = (2.0 * th - (4.0 * (th * th)) * (R[i] * R[i])) * E;
+    } else if (KERN == GPG_KERNEL_RATQU) {
+      v10 = ((-2.0 * th) * R[i]) * M1;
+      v01 = ((2.0 * th) * R[i]) * M1;
+      vii = (2.0 * th) * M1 - (((-c2) * (th * th)) * (R[i] * R[i])) * E;
+    } else {
+      v10 = ((-th) * R[i]) * M1;
+      v01 = (th * R[i]) * M1;
+      vii = th * M1 - (((25.0 / 3.0) * (th * th)) * (R[i] * R[i])) * E;
+    }
+    const size_t ri = (size_t)P.n1 + (size_t)i * P.n1g + g1, ci = (size_t)P.n2 + (size_t)i * P.n2g + g2;
+    if (g1 >= 0) out[ri * C2 + b] = v10;
+    if (g2 >= 0) out[(size_t)a * C2 + ci] = v01;
+    if (g1 >= 0 && g2 >= 0) {
+      out[ri * C2 + ci] = vii;
+      for (int j = i + 1; j < d; ++j) {
+        const double term = KERN == GPG_KERNEL_SQEXP ? ((-4.0 * th) * P.theta[j]) * ((R[i] * R[j]) * E)
+                                                     : (((c2 * th) * P.theta[j]) * R[i]) * R[j] * E;
+        const size_t rj = (size_t)P.n1 + (size_t)j * P.n1g + g1, cj = (size_t)P.n2 + (size_t)j * P.n2g + g2;
+        out[ri * C2 + cj] = term;
+        out[rj * C2 + ci] = term;
+      }
+    }
+  }
+}
+
 template <int KERN>
 void launch_assemble_d(gpg_ctx* c, const AsmParams& p, int B, const gpg_batch_item* items, size_t v_stride, size_t a_stride) {
   dim3 grid((p.n + 255) / 256, (p.n + kTB - 1) / kTB, B);
@@ -340,4 +415,19 @@ void gpg_launch_cross(gpg_ctx* c, const AsmParams& p, int nx, int nxp) {
   if (p.kernel == GPG_KERNEL_SQEXP) launch_cross_d<GPG_KERNEL_SQEXP>(c, p, nx, nxp);
   else if (p.kernel == GPG_KERNEL_RATQU) launch_cross_d<GPG_KERNEL_RATQU>(c, p, nx, nxp);
   else launch_cross_d<GPG_KERNEL_MA5F2>(c, p, nx, nxp);
+}
+
+// Host side of gpg_kern_rtensor (api.hip): device buffers are temporaries of the call.
+int gpg_kern_rtensor_run(int kernel, int d, int n1, int n2, int n1g, int n2g, int use_grad, const double* theta, double hp_kernel,
+                         const double* rt_dev, const int* gpos1_dev, const int* gpos2_dev, double* out_dev, hipStream_t stream) {
+  RtParams P;
+  memset(&P, 0, sizeof(P));
+  P.d = d; P.n1 = n1; P.n2 = n2; P.n1g = n1g; P.n2g = n2g; P.use_grad = use_grad; P.hp_kernel = hp_kernel;
+  for (int k = 0; k < d; ++k) P.theta[k] = theta[k];
+  const long long np = (long long)n1 * n2;
+  const dim3 grid((unsigned)((np + 255) / 256));
+  if (kernel == GPG_KERNEL_SQEXP) hipLaunchKernelGGL(rtensor_kern_kernel<GPG_KERNEL_SQEXP>, grid, dim3(256), 0, stream, P, rt_dev, gpos1_dev, gpos2_dev, out_dev);
+  else if (kernel == GPG_KERNEL_RATQU) hipLaunchKernelGGL(rtensor_kern_kernel<GPG_KERNEL_RATQU>, grid, dim3(256), 0, stream, P, rt_dev, gpos1_dev, gpos2_dev, out_dev);
+  else hipLaunchKernelGGL(rtensor_kern_kernel<GPG_KERNEL_MA5F2>, grid, dim3(256), 0, stream, P, rt_dev, gpos1_dev, gpos2_dev, out_dev);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -732,6 +732,11 @@ void gpg_forward_rows(gpg_ctx* c, double* W, int ldw, int rows, int valid) {
 //       (lower tiles only): another N^3/3.
 // Replaces adj_ln_detK = cho_solve(chofac, eye(N)) of the reference (CalcLkd.py:174,234).
 void gpg_inverse_from_factor(gpg_ctx* c, double* W, double* Minv) {
+  // dataflow schedule: W = L^-T and Minv = -W W^T as one launch each (128 x 128 tiles); the blocked sweeps below remain
+  // for the blocked factor mode (A/B runs, fallback after a timed-out wait)
+  if (c->chol_impl != 0 || c->tail_cols != 0) {
+    if (gpg_launch_tile128_inverse(c, W, Minv)) return;
+  }
   const int ld = c->ld, Npad = c->Npad, NB = c->nb_outer, ldw = c->Npad;
   const double* A = c->A;
   gpg_launch_identity(c, W, ldw);

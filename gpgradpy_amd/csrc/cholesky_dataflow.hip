@@ -5,6 +5,66 @@
 
 namespace {
 
+// Next task of a persistent workgroup: one relaxed agent-scope fetch-add by thread 0, shared through LDS.  The two
+// barriers also separate the LDS use of consecutive tasks.
+__device__ __forceinline__ int next_ticket(int* ticket, int* sh, int round) {
+#ifdef GPG_NO_PERSIST   // A/B builds of tools/tile_probe.hip only: one task per workgroup, taken in dispatch order (the round-1 schedule)
+  (void)ticket; (void)sh;
+  return round == 0 ? (int)blockIdx.x : 0x7fffffff;
+#else
+#ifdef GPG_TICKET_ONESHOT   // A/B: ticket order, but one task per workgroup (grid = number of tasks; the hardware refills the slots)
+  if (round > 0) return 0x7fffffff;
+#endif
+  (void)round;
+  __syncthreads();
+  if (threadIdx.x == 0) *sh = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  return *sh;
+#endif
+}
+
+// Ticket of the NEXT task, fetched by the publish step of the current one (GPG_PUBLISH_AND_NEXT): the fetch-add travels
+// with the drain of the tile's write-through stores, so a workgroup that finishes a task knows its next one without a
+// further round trip.  That matters on the critical path of a factorisation: the diagonal tile of the next column
+// usually gets its workgroup only when some task ends (all slots are busy), and whatever that workgroup spends finding
+// out what to do next is added to every one of the Mt hops of the dependency chain (measured: 141 tile columns x ~6 us).
+// The ticket is held without being worked on only for the duration of that drain.
+__shared__ int g_next_ticket;
+#if defined(GPG_NO_PERSIST) || defined(GPG_TICKET_ONESHOT)
+#define GPG_PUBLISH_AND_NEXT(ticket, flag_ptr)                                             \
+  GPG_RELEASE();                                                                            \
+  __syncthreads();                                                                          \
+  if (threadIdx.x == 0) { GPG_FLAG_UP(flag_ptr); g_next_ticket = 0x7fffffff; }
+#else
+#define GPG_PUBLISH_AND_NEXT(ticket, flag_ptr)                                             \
+  {                                                                                         \
+    int nxt_ = 0;                                                                           \
+    if (threadIdx.x == 0) nxt_ = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+    GPG_RELEASE();                                                                          \
+    if (threadIdx.x == 0) g_next_ticket = nxt_;                                             \
+    __syncthreads();                                                                        \
+    if (threadIdx.x == 0) GPG_FLAG_UP(flag_ptr);                                            \
+  }
+#endif
+
+// The task body of a persistent kernel is compiled as a function of its own (noinline) that fetches the kernel's
+// arguments from the kernarg segment by scalar loads: inlined into the task loop, the arguments stay live in ~25 SGPRs
+// across the back edge and the compiler spills the broadcast operands of the pivot chain (potrf64_wave) through
+// v_writelane / v_readlane instead -- 400 extra pairs in tile_chol_kernel, 8 % on a chain-bound factorisation.  The
+// kernel's formal parameter is only there to give the segment its layout.
+#define GPG_KERNARGS(T, ap)                                                                                   \
+  const __attribute__((address_space(4))) T* ap =                                                             \
+      (const __attribute__((address_space(4))) T*)__builtin_amdgcn_kernarg_segment_ptr();                      \
+  asm volatile("" : "+s"(ap))
+// In a (noinline) device function the kernarg segment pointer is NOT available through the builtin (it reads as null
+// there): the kernel passes it as an ordinary argument, which arrives in VGPRs; readfirstlane makes it scalar again so
+// that the loads through it are s_load.
+#define GPG_KERNARGS_FROM(T, ap, bits)                                                                        \
+  const unsigned long long ap##_u =                                                                           \
+      ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((bits) >> 32)) << 32) |             \
+      (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)((bits) & 0xffffffffull));            \
+  const __attribute__((address_space(4))) T* ap = (const __attribute__((address_space(4))) T*)ap##_u
+
 // ------------------------------------------------------------------------------------------------
 // tile_chol_kernel: dataflow (left-looking) Cholesky of the trailing block A[c0:, c0:] in 64 x 64 tiles,
 // ONE launch.  Used where the blocked algorithm is latency-bound: the last few thousand columns of a large
@@ -14,18 +74,22 @@ namespace {
 //     i==j : L_jj = chol(acc) by wave 0 (potrf64_wave), reciprocal pivots to dinv
 //     i> j : L_ij = acc L_jj^-T by the quad-row substitution, once flag(j, j) is up
 //     publish: __threadfence, then flag(i, j) = 1 (agent-scope release)
-// A task only ever waits for tasks with a smaller index, and workgroups are dispatched in index order, so
-// the oldest unfinished workgroup can always run to completion (no deadlock whatever the residency).  As
-// a backstop every wait is bounded in time: on timeout the kernel raises the abort word, all workgroups drain, and
-// the host falls back on the blocked schedule.  (That does happen when two such launches share the GPU, e.g.
-// two processes on one device: each launch's waiting workgroups can hold the slots the other one's oldest
-// pending workgroup needs.)  The serial chain per 64 columns is potrf -> substitution ->
-// one 64-deep MFMA block (~20 us) instead of three dependent launches per step plus B_p and U_p.
+// Scheduling: PERSISTENT workgroups.  The launch has at most as many workgroups as the device holds at once; each
+// takes its next task from an atomic ticket counter, in list order, until the list is exhausted.  A task only ever
+// waits for tasks with a smaller ticket.  Progress: let T be the smallest unfinished ticket.  If T has been taken,
+// its workgroup is resident (it took the ticket while running) and everything T waits for has a smaller ticket, i.e.
+// is finished -- T completes.  If T has not been taken, every resident workgroup holds a smaller ticket, all of those
+// are finished, so one of them asks for its next ticket and gets T.  Nothing here depends on the order in which the
+// hardware dispatches workgroups, on how many of them are resident, or on having the device alone: another process's
+// launch on the same GPU can only delay this one, never block it.  Every wait still is bounded in time as a backstop:
+// on timeout the kernel raises the abort word, all workgroups drain, and the host falls back on the blocked schedule.
+// The serial chain per 64 columns is potrf -> substitution -> one 64-deep MFMA block (~20 us) instead of three
+// dependent launches per step plus B_p and U_p.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 2)
-tile_chol_kernel(double* A, int ld, int c0, int Mt, const int* __restrict__ tasks, int* flags, int* pieces, int* abort_word,
-                 double* __restrict__ dinv, int* __restrict__ info, int N, const int* __restrict__ batch_of, size_t a_stride,
-                 int d_stride, int f_stride) {
+__device__ __forceinline__ bool
+tile_chol_task(int tix, double* A, int ld, int c0, int Mt, const int* __restrict__ tasks, int* flags, int* pieces, int* abort_word,
+               int* ticket, double* __restrict__ dinv, int* __restrict__ info, int N, const int* __restrict__ batch_of, size_t a_stride,
+               int d_stride, int f_stride) {
   constexpr int KB = 16, SA = 80, BUF = KB * SA;
   __shared__ __attribute__((aligned(16))) double U[4 * BUF];      // staging sA[2] | sB[2]; later the tile Ts[64][SA]
   __shared__ __attribute__((aligned(16))) double Ls[64][4][18];   // L_jj image (i > j) / potrf scratch St[64][64] (i == j)
@@ -36,10 +100,10 @@ tile_chol_kernel(double* A, int ld, int c0, int Mt, const int* __restrict__ task
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
-  const int task = tasks[blockIdx.x];
+  const int task = tasks[tix];
   const int ti = task & 0xffff, tj = task >> 16;
   if (batch_of) {   // batched launch: several independent matrices (restart rows) share the grid
-    const int b = batch_of[blockIdx.x];
+    const int b = batch_of[tix];
     A += (size_t)b * a_stride;
     dinv += (size_t)b * d_stride;
     info += b;
@@ -86,7 +150,7 @@ tile_chol_kernel(double* A, int ld, int c0, int Mt, const int* __restrict__ task
     }
     __syncthreads();
     const int kr = sh_kr;
-    if (kr < 0) return;                                  // abort: drain
+    if (kr < 0) return false;                            // abort: drain
     GPG_ACQUIRE();   // the producers' tiles are visible from here on
     const size_t ck = (size_t)c0 + 64 * (size_t)kdone;
     wave_tile_gemm(acc, A + r0 + 2 * sp + (ck + sk) * (size_t)ld, ld, A + cj + 2 * sp + (ck + sk) * (size_t)ld, ld,
@@ -122,7 +186,7 @@ tile_chol_kernel(double* A, int ld, int c0, int Mt, const int* __restrict__ task
     const double* Ljj = A + cj + cj * (size_t)ld;
 #define GPG_TC_PIECE(S)                                                                      \
     {                                                                                       \
-      if (!wg_wait_flag(pieces + 4 * tj + (S), abort_word, info, &sh_kr)) return;            \
+      if (!wg_wait_flag(pieces + 4 * tj + (S), abort_word, info, &sh_kr)) return false;      \
       _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                        \
         const int t = tid + 256 * u, jj = 16 * (S) + (t >> 6), k = t & 63;                   \
         Ls[jj][k & 3][k >> 2] = Ljj[k + (size_t)jj * ld];                                    \
@@ -142,10 +206,35 @@ tile_chol_kernel(double* A, int ld, int c0, int Mt, const int* __restrict__ task
 #pragma unroll
     for (int m = 0; m < 16; ++m) GPG_ST(&Xr[(size_t)(4 * m) * ld], x[m]);
   }
-  // ---- (3) publish ----------------------------------------------------------------------------------------------
-  GPG_RELEASE();
-  __syncthreads();
-  if (tid == 0) GPG_FLAG_UP(frow_i + tj);
+  // ---- (3) publish (and fetch the next ticket) --------------------------------------------------------------------
+  GPG_PUBLISH_AND_NEXT(ticket, frow_i + tj)
+  return true;
+}
+
+struct TileCholArgs {
+  double* A; int ld, c0, Mt; const int* tasks; int ntask; int* flags; int* pieces; int* abort_word; int* ticket; double* dinv;
+  int* info; int N; const int* batch_of; size_t a_stride; int d_stride, f_stride;
+};
+
+__device__ __noinline__ int tile_chol_task_call(int tix_v, unsigned long long kernarg_bits) {
+  GPG_KERNARGS_FROM(TileCholArgs, ap, kernarg_bits);
+  const int tix = __builtin_amdgcn_readfirstlane(tix_v);
+  return tile_chol_task(tix, ap->A, ap->ld, ap->c0, ap->Mt, ap->tasks, ap->flags, ap->pieces, ap->abort_word, ap->ticket, ap->dinv,
+                        ap->info, ap->N, ap->batch_of, ap->a_stride, ap->d_stride, ap->f_stride) ? 1 : 0;
+}
+
+__global__ void __launch_bounds__(256, 2) tile_chol_kernel(TileCholArgs) {
+  int tix;
+  {
+    GPG_KERNARGS(TileCholArgs, ap);
+    tix = next_ticket(ap->ticket, &g_next_ticket, 0);       // the first ticket; every later one comes with a task's publish step
+  }
+  for (;;) {
+    GPG_KERNARGS(TileCholArgs, ap);
+    if (tix >= ap->ntask) return;
+    if (!__builtin_amdgcn_readfirstlane(tile_chol_task_call(tix, (unsigned long long)ap))) return;   // aborted: every workgroup drains
+    tix = g_next_ticket;                                    // written before the barrier of the publish step
+  }
 }
 
 
@@ -161,7 +250,7 @@ tile_chol_kernel(double* A, int ld, int c0, int Mt, const int* __restrict__ task
 //            update, potrf64)
 //     i> j : L_ij = acc L_jj^-T, two 64-row passes of panel_solve_rows64 against the 128-wide diagonal tile
 //     publish: __threadfence, flag(i, j) = 1 (agent-scope release)
-// Progress argument and bounded waits as in tile_chol_kernel.
+// Persistent workgroups, ticket order, progress argument and bounded waits as in tile_chol_kernel.
 // ------------------------------------------------------------------------------------------------
 // The diagonal tile publishes its pieces as they are final -- L11 in four 16-column pieces (pa[0..3], while its first
 // potrf64 is still running), L21 (flag_c, after its 64-row solve), L22 in four pieces (pb[0..3]): every column block of
@@ -265,7 +354,7 @@ __shared__ __attribute__((aligned(16))) double t128_Ls[64][4][18];    // diagona
 __shared__ double t128_sdinv[64];
 
 __device__ __noinline__ int tile128_finalize(double* A, int ld, size_t r0, size_t cj, int is_diag, int* pa, int* pb,
-                                             int* flag_c, int* abort_word, double* dinv, int* info, int N) {
+                                             int* flag_c, int* abort_word, double* dinv, int* info, int N, int tix) {
   constexpr int SA = 80;
   double* const U = t128_U;
   double (*const Ls)[4][18] = t128_Ls;
@@ -274,7 +363,7 @@ __device__ __noinline__ int tile128_finalize(double* A, int ld, size_t r0, size_
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
 #ifdef GPG_STAMP
-  unsigned long long* fo = (g_stamp_buf != nullptr && blockIdx.x < GPG_STAMP_MAX) ? g_stamp_buf + (size_t)GPG_STAMP_MAX * 8 + (size_t)blockIdx.x * 8 : nullptr;
+  unsigned long long* fo = (g_stamp_buf != nullptr && tix < GPG_STAMP_MAX) ? g_stamp_buf + (size_t)GPG_STAMP_MAX * 8 + (size_t)tix * 8 : nullptr;
 #define GPG_FS(k) if (tid == 0 && fo) fo[k] = __builtin_amdgcn_s_memrealtime();
 #else
 #define GPG_FS(k)
@@ -328,18 +417,18 @@ __device__ __noinline__ int tile128_finalize(double* A, int ld, size_t r0, size_
   return 1;
 }
 
-__global__ void __launch_bounds__(256, 2)
-tile128_chol_kernel(double* A, int ld, int Mt, const int* __restrict__ tasks, int* flags, int* early /* pa | pb | flag_c */, int* abort_word,
-                    double* __restrict__ dinv, int* __restrict__ info, int N, const int* __restrict__ batch_of, size_t a_stride,
-                    int d_stride, int f_stride) {
+__device__ __forceinline__ bool
+tile128_chol_task(int tix, double* A, int ld, int Mt, const int* __restrict__ tasks, int* flags, int* early /* pa | pb | flag_c */, int* abort_word,
+                  int* ticket, double* __restrict__ dinv, int* __restrict__ info, int N, const int* __restrict__ batch_of, size_t a_stride,
+                  int d_stride, int f_stride) {
   __shared__ int sh_kr;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w & 1, wn = w >> 1;
   const int l15 = lane & 15, l4 = lane >> 4;
-  const int task = tasks[blockIdx.x];
+  const int task = tasks[tix];
   const int ti = task & 0xffff, tj = task >> 16;
   if (batch_of) {   // batched launch: several independent matrices (restart rows) share the grid
-    const int b = batch_of[blockIdx.x];
+    const int b = batch_of[tix];
     A += (size_t)b * a_stride;
     dinv += (size_t)b * d_stride;
     info += b;
@@ -392,7 +481,7 @@ tile128_chol_kernel(double* A, int ld, int Mt, const int* __restrict__ tasks, in
     }
     __syncthreads();
     const int kr = sh_kr;
-    if (kr < 0) return;
+    if (kr < 0) return false;
     GPG_ACQUIRE();
     GPG_TR(q1)
     const size_t ck = 128 * (size_t)kdone;
@@ -436,20 +525,202 @@ tile128_chol_kernel(double* A, int ld, int Mt, const int* __restrict__ tasks, in
   }
   if (ti != tj) __syncthreads();
   if (tile128_finalize(A, ld, r0, cj, ti == tj, early + 4 * tj, early + 4 * Mt + 4 * tj, early + 8 * Mt + tj, abort_word, dinv, info,
-                       N) == 0) return;
-  // ---- (3) publish ----------------------------------------------------------------------------------------------
-  GPG_RELEASE();
-  __syncthreads();
-  if (tid == 0) GPG_FLAG_UP(frow_i + tj);
+                       N, tix) == 0) return false;
+  // ---- (3) publish (and fetch the next ticket) --------------------------------------------------------------------
+  GPG_PUBLISH_AND_NEXT(ticket, frow_i + tj)
 #ifdef GPG_STAMP
-  if (tid == 0 && g_stamp_buf != nullptr && blockIdx.x < GPG_STAMP_MAX) {
-    unsigned long long* o = g_stamp_buf + (size_t)blockIdx.x * 8;
+  if (tid == 0 && g_stamp_buf != nullptr && tix < GPG_STAMP_MAX) {
+    unsigned long long* o = g_stamp_buf + (size_t)tix * 8;
     o[0] = tk_start; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = tk_spin; o[3] = tk_gemm; o[4] = tk_runs;
-    o[5] = tk_fin0; o[6] = (unsigned long long)task;
+    o[5] = tk_fin0; o[6] = (unsigned long long)task; o[7] = (unsigned long long)blockIdx.x;
   }
 #endif
+  return true;
 }
 
+__global__ void __launch_bounds__(256, 2) tile128_chol_kernel(TileCholArgs) {   // c0 unused, pieces = early flags
+  int tix;
+  {
+    GPG_KERNARGS(TileCholArgs, ap);
+    tix = next_ticket(ap->ticket, &g_next_ticket, 0);
+  }
+  for (;;) {
+    GPG_KERNARGS(TileCholArgs, ap);
+    if (tix >= ap->ntask) return;
+    // inlined here (its MFMA loop wants every VGPR: a separate function would save / restore ~100 callee-saved registers
+    // through scratch per task); re-reading the arguments per iteration keeps them out of the loop-carried SGPRs
+    if (!tile128_chol_task(tix, ap->A, ap->ld, ap->Mt, ap->tasks, ap->flags, ap->pieces, ap->abort_word, ap->ticket, ap->dinv, ap->info,
+                           ap->N, ap->batch_of, ap->a_stride, ap->d_stride, ap->f_stride))
+      return;                                             // aborted: every workgroup drains
+    tix = g_next_ticket;
+  }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// tile128_trinv_kernel: W = L^-T (upper triangular, Npad x Npad, leading dimension ldw) from the finished factor L in A,
+// as ONE dataflow launch over 128 x 128 tiles -- the first N^3/3 sweep of the explicit inverse that the adjoint
+// likelihood gradient contracts with (reference: adj_ln_detK = cho_solve(chofac, eye(N)), CalcLkd.py:174,234).
+// W starts as the identity.  Workgroup task (j, i), j <= i (row tile j, column tile i of W; list order: tile column by
+// tile column, longest accumulation first):
+//     acc  = W_ji - sum_{k=j}^{i-1} W_jk L_ik^T    the MFMA loop of the factorisation (A operand: W row tile j, B operand:
+//                                                  L row tile i, both read in fragment layout straight from memory),
+//                                                  consumed in runs as the flags of W's row tile j come up
+//     W_ji = acc L_ii^-T                           the 128-row substitution of the factorisation's off-diagonal tiles
+//                                                  against the (final) diagonal tile of L
+//     publish flag(j, i)
+// Persistent workgroups and ticket order as in tile_chol_kernel: (j, i) waits only for (j, k), k < i -- earlier tile
+// columns, i.e. smaller tickets.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool
+tile128_trinv_task(int tix, const double* __restrict__ A, int ld, const double* __restrict__ dinv, double* W, int ldw, int Mt,
+                   const int* __restrict__ tasks, int* flags, int* ones, int* abort_word, int* ticket, int* info,
+                   const int* __restrict__ batch_of, size_t a_stride, size_t w_stride, int d_stride, int f_stride) {
+  __shared__ int sh_kr;
+  __shared__ int sh_ok;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w & 1, wn = w >> 1;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int task = tasks[tix];
+  const int tj = task & 0xffff, ti = task >> 16;          // row tile j of W, column tile i
+  if (batch_of) {   // batched launch: the factors of several matrices (restart rows) are inverted by one launch
+    const int b = batch_of[tix];
+    A += (size_t)b * a_stride;
+    dinv += (size_t)b * d_stride;
+    W += (size_t)b * w_stride;
+    flags += (size_t)b * f_stride;
+    info += b;
+  }
+  const size_t r0 = 128 * (size_t)tj, ci = 128 * (size_t)ti;
+  int* const frow = flags + (size_t)tj * Mt;
+
+  d4 acc[4][4];
+  double* Cw = W + r0 + wm * 64 + 2 * l15 + (ci + wn * 64 + 2 * l4) * (size_t)ldw;
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double2 v = *reinterpret_cast<const double2*>(Cw + 32 * g + (size_t)(32 * (ni >> 1) + 8 * r + (ni & 1)) * ldw);
+        acc[ni][2 * g][r] = v.x;
+        acc[ni][2 * g + 1][r] = v.y;
+      }
+  int kdone = tj;
+  while (kdone < ti) {
+    if (tid == 0) {
+      int kr = kdone;
+      const unsigned long long t_wait = __builtin_amdgcn_s_memrealtime();
+      for (;;) {
+        while (kr < ti && __hip_atomic_load(frow + kr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ++kr;
+        if (kr > kdone) break;
+        if (__builtin_amdgcn_s_memrealtime() - t_wait > GPG_TILE_WAIT_TICKS ||
+            __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+          __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          atomicMax(info, GPG_INFO_INTERNAL);
+          kr = -1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+      sh_kr = kr;
+    }
+    __syncthreads();
+    const int kr = sh_kr;
+    if (kr < 0) return false;
+    GPG_ACQUIRE();
+    const size_t ck = 128 * (size_t)kdone;
+    direct_tile_gemm_x2<3>(acc, W + r0 + wm * 64 + 2 * l15 + (ck + l4) * (size_t)ldw, ldw,
+                           A + ci + wn * 64 + 2 * l15 + (ck + l4) * (size_t)ld, ld, 32 * (kr - kdone));
+    __syncthreads();   // sh_kr may be rewritten
+    kdone = kr;
+  }
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double2 v;
+        v.x = acc[ni][2 * g][r];
+        v.y = acc[ni][2 * g + 1][r];
+        *reinterpret_cast<double2*>(Cw + 32 * g + (size_t)(32 * (ni >> 1) + 8 * r + (ni & 1)) * ldw) = v;
+      }
+  __syncthreads();
+  // the diagonal tile of L is final: its piece flags are a constant array of ones
+  if (!tile_solve_rows128(A + ci + ci * (size_t)ld, ld, dinv + ci, W + r0 + ci * (size_t)ldw, ldw, t128_U, t128_Ls, t128_sdinv, ones,
+                          ones + 4, ones, abort_word, info, &sh_ok))
+    return false;
+  GPG_PUBLISH_AND_NEXT(ticket, frow + ti)
+  return true;
+}
+
+struct TrinvArgs {
+  const double* A; int ld; const double* dinv; double* W; int ldw, Mt; const int* tasks; int ntask; int* flags; int* ones;
+  int* abort_word; int* ticket; int* info; const int* batch_of; size_t a_stride, w_stride; int d_stride, f_stride;
+};
+
+__global__ void __launch_bounds__(256, 2) tile128_trinv_kernel(TrinvArgs) {
+  int tix;
+  {
+    GPG_KERNARGS(TrinvArgs, ap);
+    tix = next_ticket(ap->ticket, &g_next_ticket, 0);
+  }
+  for (;;) {
+    GPG_KERNARGS(TrinvArgs, ap);
+    if (tix >= ap->ntask) return;
+    if (!tile128_trinv_task(tix, ap->A, ap->ld, ap->dinv, ap->W, ap->ldw, ap->Mt, ap->tasks, ap->flags, ap->ones, ap->abort_word,
+                            ap->ticket, ap->info, ap->batch_of, ap->a_stride, ap->w_stride, ap->d_stride, ap->f_stride))
+      return;
+    tix = g_next_ticket;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// tile128_wwt_kernel: M = - W W^T, lower triangle (second N^3/3 sweep of the explicit inverse: -(L L^T)^-1 = -L^-T L^-1),
+// W = L^-T upper triangular: tile (a, b), a >= b:  M_ab = - sum_{k >= a} W_ak W_bk^T -- independent tiles, no flags;
+// persistent workgroups take them from the ticket counter, longest contraction (smallest a) first.  The same
+// direct-fragment MFMA loop, accumulators start at zero.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256, 2)
+tile128_wwt_kernel(const double* __restrict__ W0, int ldw, double* __restrict__ M0, int ldm, int Mt, const int* __restrict__ tasks,
+                   int ntask, int* ticket, const int* __restrict__ batch_of, size_t w_stride) {
+  __shared__ int sh_tix;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int wm = w & 1, wn = w >> 1;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  for (int round = 0;; ++round) {
+    const int tix = next_ticket(ticket, &sh_tix, round);
+    if (tix >= ntask) return;
+    const int task = tasks[tix];
+    const int ta = task & 0xffff, tb = task >> 16;        // a >= b
+    const size_t boff = batch_of ? (size_t)batch_of[tix] * w_stride : 0;
+    const double* W = W0 + boff;
+    double* M = M0 + boff;
+    const size_t r0 = 128 * (size_t)ta, c0 = 128 * (size_t)tb, ck = 128 * (size_t)ta;
+    d4 acc[4][4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[ni][mi][r] = 0.0;
+    direct_tile_gemm_x2<3>(acc, W + r0 + wm * 64 + 2 * l15 + (ck + l4) * (size_t)ldw, ldw,
+                           W + c0 + wn * 64 + 2 * l15 + (ck + l4) * (size_t)ldw, ldw, 32 * (Mt - ta));
+    double* Cw = M + r0 + wm * 64 + 2 * l15 + (c0 + wn * 64 + 2 * l4) * (size_t)ldm;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          double2 v;
+          v.x = acc[ni][2 * g][r];
+          v.y = acc[ni][2 * g + 1][r];
+          *reinterpret_cast<double2*>(Cw + 32 * g + (size_t)(32 * (ni >> 1) + 8 * r + (ni & 1)) * ldm) = v;
+        }
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // rows_fwd_kernel: W <- W L^-T for right-hand-side rows held OUTSIDE the matrix (rows layout, leading dimension ldw,
@@ -459,9 +730,9 @@ tile128_chol_kernel(double* A, int ld, int Mt, const int* __restrict__ tasks, in
 // (gpg_forward_rows: panel solve + GEMM launch per 512 columns) is bound by ~70 dependent launches of 100+ us each;
 // here the chain per 64 columns is one 64-deep MFMA block, one substitution and one flag hop.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 2)
-rows_fwd_kernel(const double* __restrict__ A, int ld, const double* __restrict__ dinv, double* W, int ldw, int Mt, int nrt,
-                int valid, int* flags, int* abort_word, int* info) {
+__device__ __forceinline__ bool
+rows_fwd_task(int tix, const double* __restrict__ A, int ld, const double* __restrict__ dinv, double* W, int ldw, int Mt, int nrt,
+              int valid, int* flags, int* abort_word, int* info) {
   constexpr int KB = 16, SA = 80, BUF = KB * SA;
   __shared__ __attribute__((aligned(16))) double U[4 * BUF];
   __shared__ __attribute__((aligned(16))) double Ls[64][4][18];
@@ -471,7 +742,7 @@ rows_fwd_kernel(const double* __restrict__ A, int ld, const double* __restrict__
   double* const sB = U + 2 * BUF;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
-  const int tj = blockIdx.x / nrt, rt = blockIdx.x - tj * nrt;      // column-block-major task order
+  const int tj = tix / nrt, rt = tix - tj * nrt;                    // column-block-major task order
   const size_t r0 = 64 * (size_t)rt, cj = 64 * (size_t)tj;
   const int q = tid & 3;
   const int sp = tid & 31, sk = tid >> 5;
@@ -514,7 +785,7 @@ rows_fwd_kernel(const double* __restrict__ A, int ld, const double* __restrict__
     }
     __syncthreads();
     const int kr = sh_kr;
-    if (kr < 0) return;
+    if (kr < 0) return false;
     GPG_ACQUIRE();
     const size_t ck = 64 * (size_t)kdone;
     wave_tile_gemm(acc, W + r0 + 2 * sp + (ck + sk) * (size_t)ldw, ldw, A + cj + 2 * sp + (ck + sk) * (size_t)ld, ld,
@@ -545,6 +816,19 @@ rows_fwd_kernel(const double* __restrict__ A, int ld, const double* __restrict__
   GPG_RELEASE();
   __syncthreads();
   if (tid == 0) GPG_FLAG_UP(frow + tj);
+  return true;
+}
+
+__global__ void __launch_bounds__(256, 2)
+rows_fwd_kernel(const double* __restrict__ A, int ld, const double* __restrict__ dinv, double* W, int ldw, int Mt, int nrt,
+                int valid, int* flags, int* abort_word, int* ticket, int* info) {
+  __shared__ int sh_tix;
+  const int ntask = Mt * nrt;
+  for (int round = 0;; ++round) {
+    const int tix = next_ticket(ticket, &sh_tix, round);
+    if (tix >= ntask) return;
+    if (!rows_fwd_task(tix, A, ld, dinv, W, ldw, Mt, nrt, valid, flags, abort_word, info)) return;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -554,9 +838,9 @@ rows_fwd_kernel(const double* __restrict__ A, int ld, const double* __restrict__
 // published, then runs the reverse substitution against L_jj.  Replaces 2 x Npad/64 dependent launches
 // (gpg_backward_rows).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256, 2)
-rows_bwd_kernel(const double* __restrict__ A, int ld, const double* __restrict__ dinv, double* Z, int ldz, int Mt, int nrt,
-                int valid, int* flags, int* abort_word, int* info) {
+__device__ __forceinline__ bool
+rows_bwd_task(int tix, const double* __restrict__ A, int ld, const double* __restrict__ dinv, double* Z, int ldz, int Mt, int nrt,
+              int valid, int* flags, int* abort_word, int* info) {
   constexpr int KB = 16, SA = 80, BUF = KB * SA;
   __shared__ __attribute__((aligned(16))) double U[4 * BUF];
   __shared__ __attribute__((aligned(16))) double Ls[64][4][18];   // transposed image: Ls[j][q][m] = L_jj[j][4m + q]
@@ -566,7 +850,7 @@ rows_bwd_kernel(const double* __restrict__ A, int ld, const double* __restrict__
   double* const sB = U + 2 * BUF;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int l15 = lane & 15, l4 = lane >> 4;
-  const int jr = blockIdx.x / nrt, rt = blockIdx.x - jr * nrt;
+  const int jr = tix / nrt, rt = tix - jr * nrt;
   const int tj = Mt - 1 - jr;                                      // last column block first
   const size_t r0 = 64 * (size_t)rt, cj = 64 * (size_t)tj;
   const int q = tid & 3;
@@ -610,7 +894,7 @@ rows_bwd_kernel(const double* __restrict__ A, int ld, const double* __restrict__
     }
     __syncthreads();
     const int kr = sh_kr;
-    if (kr < 0) return;
+    if (kr < 0) return false;
     GPG_ACQUIRE();
     const size_t ck = 64 * (size_t)kr;                             // contraction rows [64 kr, 64 khi)
     wave_tile_gemm_nn(acc, Z + r0 + 2 * sp + (ck + sk) * (size_t)ldz, ldz, A + ck + cj * (size_t)ld, ld, 4 * (khi - kr), sA, sB, w,
@@ -641,6 +925,19 @@ rows_bwd_kernel(const double* __restrict__ A, int ld, const double* __restrict__
   GPG_RELEASE();
   __syncthreads();
   if (tid == 0) GPG_FLAG_UP(frow + tj);
+  return true;
+}
+
+__global__ void __launch_bounds__(256, 2)
+rows_bwd_kernel(const double* __restrict__ A, int ld, const double* __restrict__ dinv, double* Z, int ldz, int Mt, int nrt,
+                int valid, int* flags, int* abort_word, int* ticket, int* info) {
+  __shared__ int sh_tix;
+  const int ntask = Mt * nrt;
+  for (int round = 0;; ++round) {
+    const int tix = next_ticket(ticket, &sh_tix, round);
+    if (tix >= ntask) return;
+    if (!rows_bwd_task(tix, A, ld, dinv, Z, ldz, Mt, nrt, valid, flags, abort_word, info)) return;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -658,12 +955,12 @@ rows_bwd_kernel(const double* __restrict__ A, int ld, const double* __restrict__
 // ------------------------------------------------------------------------------------------------
 #define GPG_VEC_SENTINEL 0x7ff8dead7ff8deadull     // quiet NaN that no arithmetic produces; both halves equal (memsetD32)
 template <int BWD, int RR>
-__global__ void __launch_bounds__(256)
-vec_solve_kernel(const double* __restrict__ A, int ld, const double* __restrict__ dinv, double* W, int ldw, int Mt, int R,
-                 unsigned long long* xc, int Npad, int* abort_word, int* info) {
+__device__ __forceinline__ bool
+vec_solve_task(int tix, const double* __restrict__ A, int ld, const double* __restrict__ dinv, double* W, int ldw, int Mt, int R,
+               unsigned long long* xc, int Npad, int* abort_word, int* info) {
   __shared__ double part[4][RR][64];     // [wave][row][column] partial sums
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int tj = BWD ? Mt - 1 - (int)blockIdx.x : (int)blockIdx.x;
+  const int tj = BWD ? Mt - 1 - tix : tix;
   const size_t cj = 64 * (size_t)tj;
   const int ktot = BWD ? Mt - 1 - tj : tj;
   const double dv = dinv[cj + lane];
@@ -740,6 +1037,30 @@ vec_solve_kernel(const double* __restrict__ A, int ld, const double* __restrict_
                        __HIP_MEMORY_SCOPE_AGENT);
     W[w + (cj + lane) * (size_t)ldw] = x;
   }
+  return !__syncthreads_or(dead ? 1 : 0);      // a wave that timed out ends the workgroup (the abort word drains the others)
+}
+
+struct VecSolveArgs {
+  const double* A; int ld; const double* dinv; double* W; int ldw, Mt, R; unsigned long long* xc; int Npad; int* abort_word; int* ticket;
+  int* info;
+};
+
+template <int BWD, int RR>
+__device__ __noinline__ int vec_solve_task_call(int tix_v, unsigned long long kernarg_bits) {
+  GPG_KERNARGS_FROM(VecSolveArgs, ap, kernarg_bits);
+  const int tix = __builtin_amdgcn_readfirstlane(tix_v);
+  return vec_solve_task<BWD, RR>(tix, ap->A, ap->ld, ap->dinv, ap->W, ap->ldw, ap->Mt, ap->R, ap->xc, ap->Npad, ap->abort_word, ap->info) ? 1 : 0;
+}
+
+template <int BWD, int RR>
+__global__ void __launch_bounds__(256) vec_solve_kernel(VecSolveArgs) {
+  __shared__ int sh_tix;
+  for (int round = 0;; ++round) {
+    GPG_KERNARGS(VecSolveArgs, ap);
+    const int tix = next_ticket(ap->ticket, &sh_tix, round);
+    if (tix >= ap->Mt) return;
+    if (!__builtin_amdgcn_readfirstlane((vec_solve_task_call<BWD, RR>(tix, (unsigned long long)ap)))) return;
+  }
 }
 
 // Column-major task list of the dataflow factorisation (Mt tile columns, Rt >= Mt tile rows), cached per shape.
@@ -761,6 +1082,25 @@ const TileMap& get_tile_tasks(gpg_ctx* c, int Mt, int Rt) {
   return c->tilemaps.emplace(key, tm).first->second;
 }
 
+// Grid of a persistent launch: as many workgroups as the device holds at once (occupancy x compute units), at most one
+// per task.  More would only queue behind the resident ones, fewer would leave slots empty; neither affects
+// correctness (ticket order, see tile_chol_kernel).
+template <typename K>
+static int persistent_grid(gpg_ctx* c, K kernel, long ntask) {
+  const void* key = reinterpret_cast<const void*>(kernel);
+  auto it = c->occupancy.find(key);
+  if (it == c->occupancy.end()) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 1; }
+    it = c->occupancy.emplace(key, nb).first;
+  }
+  const long cap = (long)it->second * (c->num_cus > 0 ? c->num_cus : 256);
+#if defined(GPG_NO_PERSIST) || defined(GPG_TICKET_ONESHOT)
+  return (int)ntask;
+#endif
+  return (int)(ntask < cap ? ntask : cap);
+}
+
 // Completion flags of the dataflow launches (grown on demand); false: allocation failed, nothing may be launched.
 static bool ensure_tile_flags(gpg_ctx* c, size_t nflag) {
   if (c->tile_flags_cap >= nflag && c->tile_flags) return true;
@@ -778,14 +1118,15 @@ static void launch_tile_chol(gpg_ctx* c, int c0) {
   if (Mt <= 0) return;
   const TileMap& tm = get_tile_tasks(c, Mt, Rt);
   if (!tm.dev) return;
-  const size_t nflag = (size_t)Mt * Rt + 1 + 4 * (size_t)Mt;   // tile flags, abort word, four piece flags per diagonal tile
+  const size_t nflag = (size_t)Mt * Rt + 1 + 4 * (size_t)Mt + 1;   // tile flags, abort word, four piece flags per diagonal tile, ticket
   if (!ensure_tile_flags(c, nflag)) return;
   (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
   const double m = (double)(c->N - c0);                    // algorithmic flops: N^3 / 3 of the real matrix, not of the padded one
   gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, m > 0 ? m * m * m / 3.0 : 0.0);
   int* abort_word = c->tile_flags + (size_t)Mt * Rt;
-  hipLaunchKernelGGL(tile_chol_kernel, dim3(tm.n), dim3(256), 0, c->stream, c->A, c->ld, c0, Mt, (const int*)tm.dev,
-                     c->tile_flags, abort_word + 1, abort_word, c->dinv, c->info, c->N, (const int*)nullptr, (size_t)0, 0, 0);
+  hipLaunchKernelGGL(tile_chol_kernel, dim3(persistent_grid(c, tile_chol_kernel, tm.n)), dim3(256), 0, c->stream,
+                     TileCholArgs{c->A, c->ld, c0, Mt, tm.dev, tm.n, c->tile_flags, abort_word + 1, abort_word, c->tile_flags + (nflag - 1),
+                                  c->dinv, c->info, c->N, nullptr, 0, 0, 0});
   gpg_prof_end(c);
 }
 
@@ -811,15 +1152,15 @@ static void launch_tile_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a_st
     it = c->tilemaps.emplace(key, tm).first;
   }
   const TileMap& tm = it->second;
-  const size_t per = (size_t)Mt * Rt + 1 + 4 * (size_t)Mt, nflag = per * B;
+  const size_t per = (size_t)Mt * Rt + 1 + 4 * (size_t)Mt, nflag = per * B + 1;   // + the ticket of the launch
   if (!ensure_tile_flags(c, nflag)) return;
   (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
   const double m = (double)c->N;
   gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, B * m * m * m / 3.0);
   int* abort_word = c->tile_flags + (size_t)Mt * Rt;      // the abort word of matrix 0 serves the whole launch
-  hipLaunchKernelGGL(tile_chol_kernel, dim3(tm.n), dim3(256), 0, c->stream, Abase, c->ld, 0, Mt, (const int*)tm.dev,
-                     c->tile_flags, abort_word + 1, abort_word, dinv_base, info_base, c->N, (const int*)(tm.dev + tm.n), a_stride,
-                     d_stride, (int)per);
+  hipLaunchKernelGGL(tile_chol_kernel, dim3(persistent_grid(c, tile_chol_kernel, tm.n)), dim3(256), 0, c->stream,
+                     TileCholArgs{Abase, c->ld, 0, Mt, tm.dev, tm.n, c->tile_flags, abort_word + 1, abort_word, c->tile_flags + (nflag - 1),
+                                  dinv_base, info_base, c->N, tm.dev + tm.n, a_stride, d_stride, (int)per});
   gpg_prof_end(c);
 }
 
@@ -828,14 +1169,15 @@ static void launch_tile128_chol(gpg_ctx* c) {
   const int Mt = c->Npad / 128, Rt = c->ld / 128;
   const TileMap& tm = get_tile_tasks(c, Mt, Rt);
   if (!tm.dev) return;
-  const size_t nflag = (size_t)Mt * Rt + 1 + 9 * (size_t)Mt;   // tile flags, abort word, 4 + 4 piece flags and the L21 flag per diagonal tile
+  const size_t nflag = (size_t)Mt * Rt + 1 + 9 * (size_t)Mt + 1;   // tile flags, abort word, 4 + 4 piece flags and the L21 flag per diagonal tile, ticket
   if (!ensure_tile_flags(c, nflag)) return;
   (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
   const double m = (double)c->N;
   gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, m * m * m / 3.0);
   int* abort_word = c->tile_flags + (size_t)Mt * Rt;
-  hipLaunchKernelGGL(tile128_chol_kernel, dim3(tm.n), dim3(256), 0, c->stream, c->A, c->ld, Mt, (const int*)tm.dev,
-                     c->tile_flags, abort_word + 1, abort_word, c->dinv, c->info, c->N, (const int*)nullptr, (size_t)0, 0, 0);
+  hipLaunchKernelGGL(tile128_chol_kernel, dim3(persistent_grid(c, tile128_chol_kernel, tm.n)), dim3(256), 0, c->stream,
+                     TileCholArgs{c->A, c->ld, 0, Mt, tm.dev, tm.n, c->tile_flags, abort_word + 1, abort_word, c->tile_flags + (nflag - 1),
+                                  c->dinv, c->info, c->N, nullptr, 0, 0, 0});
   gpg_prof_end(c);
 }
 
@@ -859,16 +1201,66 @@ static void launch_tile128_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a
     it = c->tilemaps.emplace(key, tm).first;
   }
   const TileMap& tm = it->second;
-  const size_t per = (size_t)Mt * Rt + 1 + 9 * (size_t)Mt, nflag = per * B;
+  const size_t per = (size_t)Mt * Rt + 1 + 9 * (size_t)Mt, nflag = per * B + 1;   // + the ticket of the launch
   if (!ensure_tile_flags(c, nflag)) return;
   (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
   const double m = (double)c->N;
   gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, B * m * m * m / 3.0);
   int* abort_word = c->tile_flags + (size_t)Mt * Rt;
-  hipLaunchKernelGGL(tile128_chol_kernel, dim3(tm.n), dim3(256), 0, c->stream, Abase, c->ld, Mt, (const int*)tm.dev,
-                     c->tile_flags, abort_word + 1, abort_word, dinv_base, info_base, c->N, (const int*)(tm.dev + tm.n), a_stride,
-                     d_stride, (int)per);
+  hipLaunchKernelGGL(tile128_chol_kernel, dim3(persistent_grid(c, tile128_chol_kernel, tm.n)), dim3(256), 0, c->stream,
+                     TileCholArgs{Abase, c->ld, 0, Mt, tm.dev, tm.n, c->tile_flags, abort_word + 1, abort_word, c->tile_flags + (nflag - 1),
+                                  dinv_base, info_base, c->N, tm.dev + tm.n, a_stride, d_stride, (int)per});
   gpg_prof_end(c);
+}
+
+// Minv <- -(L L^T)^-1 (lower triangle, leading dimension Npad) from finished factors, through W = L^-T (Npad x Npad): two
+// dataflow launches of N^3/3 flops each per matrix (tile128_trinv_kernel, tile128_wwt_kernel).  B matrices at once
+// (factor b at Abase + b a_stride with reciprocal pivots dinv_base + b d_stride, W / Minv of matrix b at + b Npad^2;
+// task lists interleaved tile column by tile column like the batched factorisation).  false: not applicable / no memory.
+static bool launch_tile128_inverse_batch(gpg_ctx* c, int B, const double* Abase, size_t a_stride, const double* dinv_base, int d_stride,
+                                         double* Wbase, double* Mbase, int* info_base) {
+  const int Mt = c->Npad / 128, ldw = c->Npad;
+  if (Mt < 1 || Mt > 0xffff || B < 1) return false;
+  const size_t w_stride = (size_t)ldw * c->Npad;
+  const unsigned long long key = (3ull << 61) | ((unsigned long long)B << 40) | (unsigned long long)Mt;
+  auto it = c->tilemaps.find(key);
+  if (it == c->tilemaps.end()) {
+    std::vector<int> list, bof;
+    for (int i = 0; i < Mt; ++i)                    // W tiles (j, i): tile column by tile column, longest accumulation first
+      for (int b = 0; b < B; ++b)
+        for (int j = 0; j <= i; ++j) { list.push_back(j | (i << 16)); bof.push_back(b); }
+    const size_t n1 = list.size();
+    for (int a = 0; a < Mt; ++a)                    // M tiles (a, b), a >= b: longest contraction (smallest a) first
+      for (int b = 0; b < B; ++b)
+        for (int bb = 0; bb <= a; ++bb) { list.push_back(a | (bb << 16)); bof.push_back(b); }
+    TileMap tm;
+    tm.n = (int)n1;
+    if (!gpg_dev_alloc(c, &tm.dev, sizeof(int) * 2 * list.size())) return false;
+    (void)hipMemcpy(tm.dev, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice);
+    (void)hipMemcpy(tm.dev + list.size(), bof.data(), sizeof(int) * bof.size(), hipMemcpyHostToDevice);
+    it = c->tilemaps.emplace(key, tm).first;
+  }
+  const TileMap& tm = it->second;
+  const int* tasks1 = tm.dev;
+  const int* tasks2 = tm.dev + tm.n;
+  const int* bof1 = tm.dev + 2 * (size_t)tm.n;
+  const int* bof2 = bof1 + tm.n;
+  const size_t per = (size_t)Mt * Mt, nflag = per * B + 16;   // W tile flags per matrix | 9 ones | abort | ticket (trinv) | ticket (wwt)
+  if (!ensure_tile_flags(c, nflag)) return false;
+  int* ones = c->tile_flags + per * B;
+  (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
+  (void)hipMemsetD32Async((hipDeviceptr_t)ones, 1, 9, c->stream);
+  for (int b = 0; b < B; ++b) gpg_launch_identity(c, Wbase + (size_t)b * w_stride, ldw);
+  hipLaunchKernelGGL(tile128_trinv_kernel, dim3(persistent_grid(c, tile128_trinv_kernel, tm.n)), dim3(256), 0, c->stream,
+                     TrinvArgs{Abase, c->ld, dinv_base, Wbase, ldw, Mt, tasks1, tm.n, c->tile_flags, ones, ones + 9, ones + 10, info_base,
+                               B > 1 ? bof1 : nullptr, a_stride, w_stride, d_stride, (int)per});
+  hipLaunchKernelGGL(tile128_wwt_kernel, dim3(persistent_grid(c, tile128_wwt_kernel, tm.n)), dim3(256), 0, c->stream,
+                     (const double*)Wbase, ldw, Mbase, ldw, Mt, tasks2, tm.n, ones + 11, B > 1 ? bof2 : (const int*)nullptr, w_stride);
+  return true;
+}
+
+static bool launch_tile128_inverse(gpg_ctx* c, double* W, double* Minv) {
+  return launch_tile128_inverse_batch(c, 1, c->A, 0, c->dinv, 0, W, Minv, c->info);
 }
 
 // W (rows x Npad, rows a multiple of 64) <- W L^-T with the dataflow kernel; returns false if it does not apply.
@@ -881,11 +1273,12 @@ static bool launch_vec_solve(gpg_ctx* c, double* W, int ldw, int R, bool bwd) {
     if (!gpg_dev_alloc(c, &c->vec_x, sizeof(double) * 4 * (size_t)c->Npad)) return false;
     c->vec_x_cols = c->Npad;
   }
-  (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int), c->stream);                              // abort word
+  (void)hipMemsetAsync(c->tile_flags, 0, 2 * sizeof(int), c->stream);                          // abort word, ticket
   (void)hipMemsetD32Async((hipDeviceptr_t)c->vec_x, (int)(GPG_VEC_SENTINEL & 0xffffffffull), (size_t)2 * R * c->Npad, c->stream);
 #define GPG_VEC_LAUNCH(BWD, RR)                                                                                          \
-  hipLaunchKernelGGL((vec_solve_kernel<BWD, RR>), dim3(Mt), dim3(256), 0, c->stream, (const double*)c->A, c->ld,          \
-                     (const double*)c->dinv, W, ldw, Mt, R, (unsigned long long*)c->vec_x, c->Npad, c->tile_flags, c->info)
+  hipLaunchKernelGGL((vec_solve_kernel<BWD, RR>), dim3(persistent_grid(c, vec_solve_kernel<BWD, RR>, Mt)), dim3(256), 0,  \
+                     c->stream, VecSolveArgs{c->A, c->ld, c->dinv, W, ldw, Mt, R, (unsigned long long*)c->vec_x, c->Npad,  \
+                                             c->tile_flags, c->tile_flags + 1, c->info})
   if (bwd) { if (R == 1) GPG_VEC_LAUNCH(1, 1); else GPG_VEC_LAUNCH(1, 4); }
   else     { if (R == 1) GPG_VEC_LAUNCH(0, 1); else GPG_VEC_LAUNCH(0, 4); }
 #undef GPG_VEC_LAUNCH
@@ -897,11 +1290,12 @@ static bool launch_rows_bwd(gpg_ctx* c, double* Z, int ldz, int rows, int valid)
   if (valid >= 1 && valid <= 4 && c->Npad / 64 <= 512) return launch_vec_solve(c, Z, ldz, valid, true);
   const int Mt = c->Npad / 64, nrt = rows / 64;
   if ((long)Mt * nrt > 4096) return false;
-  const size_t nflag = (size_t)Mt * nrt + 1;
+  const size_t nflag = (size_t)Mt * nrt + 2;                    // flags, abort word, ticket
   if (!ensure_tile_flags(c, nflag)) return false;
   (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
-  hipLaunchKernelGGL(rows_bwd_kernel, dim3(Mt * nrt), dim3(256), 0, c->stream, (const double*)c->A, c->ld, (const double*)c->dinv, Z,
-                     ldz, Mt, nrt, valid < 0 ? rows : valid, c->tile_flags, c->tile_flags + (nflag - 1), c->info);
+  hipLaunchKernelGGL(rows_bwd_kernel, dim3(persistent_grid(c, rows_bwd_kernel, (long)Mt * nrt)), dim3(256), 0, c->stream,
+                     (const double*)c->A, c->ld, (const double*)c->dinv, Z, ldz, Mt, nrt, valid < 0 ? rows : valid, c->tile_flags,
+                     c->tile_flags + (nflag - 2), c->tile_flags + (nflag - 1), c->info);
   return true;
 }
 
@@ -910,11 +1304,12 @@ static bool launch_rows_fwd(gpg_ctx* c, double* W, int ldw, int rows, int valid)
   if (valid >= 1 && valid <= 4 && c->Npad / 64 <= 512) return launch_vec_solve(c, W, ldw, valid, false);
   const int Mt = c->Npad / 64, nrt = rows / 64;
   if ((long)Mt * nrt > 4096) return false;             // many rows: the blocked sweep is throughput-bound, not latency-bound
-  const size_t nflag = (size_t)Mt * nrt + 1;
+  const size_t nflag = (size_t)Mt * nrt + 2;                    // flags, abort word, ticket
   if (!ensure_tile_flags(c, nflag)) return false;
   (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
-  hipLaunchKernelGGL(rows_fwd_kernel, dim3(Mt * nrt), dim3(256), 0, c->stream, (const double*)c->A, c->ld, (const double*)c->dinv, W,
-                     ldw, Mt, nrt, valid < 0 ? rows : valid, c->tile_flags, c->tile_flags + (nflag - 1), c->info);
+  hipLaunchKernelGGL(rows_fwd_kernel, dim3(persistent_grid(c, rows_fwd_kernel, (long)Mt * nrt)), dim3(256), 0, c->stream,
+                     (const double*)c->A, c->ld, (const double*)c->dinv, W, ldw, Mt, nrt, valid < 0 ? rows : valid, c->tile_flags,
+                     c->tile_flags + (nflag - 2), c->tile_flags + (nflag - 1), c->info);
   return true;
 }
 
@@ -927,6 +1322,11 @@ void gpg_launch_tile_chol(gpg_ctx* c, int c0) {
 void gpg_launch_tile128_chol(gpg_ctx* c) {
   launch_tile128_chol(c);
   c->last_factor_kernel = 2; c->last_factor_batch = 1;
+}
+bool gpg_launch_tile128_inverse(gpg_ctx* c, double* W, double* Minv) { return launch_tile128_inverse(c, W, Minv); }
+bool gpg_launch_tile128_inverse_batch(gpg_ctx* c, int B, const double* Abase, size_t a_stride, const double* dinv_base, int d_stride,
+                                      double* Wbase, double* Mbase, int* info_base) {
+  return launch_tile128_inverse_batch(c, B, Abase, a_stride, dinv_base, d_stride, Wbase, Mbase, info_base);
 }
 bool gpg_launch_rows_fwd(gpg_ctx* c, double* W, int ldw, int rows, int valid) { return launch_rows_fwd(c, W, ldw, rows, valid); }
 bool gpg_launch_rows_bwd(gpg_ctx* c, double* Z, int ldz, int rows, int valid) { return launch_rows_bwd(c, Z, ldz, rows, valid); }

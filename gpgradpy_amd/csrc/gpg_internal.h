@@ -65,7 +65,9 @@ struct gpg_ctx {
   int last_factor_batch = 0;  // matrices it factorised
   int chol_impl = 0;    // 1: whole factorisation by the 128-tile dataflow kernel
   int tail_cols = 0;    // trailing block of at most this many columns goes to the dataflow tile kernel (0: off)
-  int* tile_flags = nullptr;   // device: completion flags of the dataflow kernel + abort word
+  int* tile_flags = nullptr;   // device: completion flags of the dataflow kernel + abort word + ticket counter
+  int num_cus = 0;             // compute units of the device (grid of the persistent launches)
+  std::map<const void*, int> occupancy;   // workgroups per compute unit of each persistent kernel (occupancy query, cached)
   size_t tile_flags_cap = 0;
   int nb_big = 0;       // wide-panel width used while at least big_rows columns remain (0: off)
   int big_rows = 0;
@@ -95,6 +97,12 @@ struct gpg_ctx {
   double* batchA = nullptr;     // [batch_cap x A_elems] workspaces of the batched small-matrix factorisation (on first use)
   double* batchV = nullptr;     // [batch_cap x 3 x Npad] dvec / invp / dinv of each batched matrix
   int batch_cap = 0;
+  double* batchW = nullptr;     // [gbatch_cap x Npad^2] L^-T of each matrix of a batched gradient call (on first use)
+  double* batchM = nullptr;     // [gbatch_cap x Npad^2] -(L L^T)^-1, lower triangle
+  double* batchZ = nullptr;     // [gbatch_cap x Npad]   p * alpha of each matrix
+  int gbatch_cap = 0;
+  double* gres = nullptr;       // [gres_cap x 2 GPG_GRAD_SLOTS_MAX] gradient sums per restart row
+  int gres_cap = 0;
   int batch_max = -1;           // matrices per batched launch (-1: auto, 0 / 1: off)
   gpg_batch_item* items_dev = nullptr;   // [items_cap] per-row parameters of a batched call (device / pinned host)
   gpg_batch_item* items_host = nullptr;
@@ -141,6 +149,9 @@ void gpg_launch_tile_chol(gpg_ctx* c, int c0);                          // dataf
 void gpg_launch_tile128_chol(gpg_ctx* c);
 // dataflow W <- W L^-T / Z <- Z L^-1 for a few 64-row tiles; rows >= valid must be zero (their substitution is skipped);
 // false: not applicable (caller falls back on the blocked sweep)
+bool gpg_launch_tile128_inverse(gpg_ctx* c, double* W, double* Minv);   // Minv <- -(L L^T)^-1 by two dataflow launches
+bool gpg_launch_tile128_inverse_batch(gpg_ctx* c, int B, const double* Abase, size_t a_stride, const double* dinv_base, int d_stride,
+                                      double* Wbase, double* Mbase, int* info_base);   // the same for B factors at once
 bool gpg_launch_rows_fwd(gpg_ctx* c, double* W, int ldw, int rows, int valid);
 bool gpg_launch_rows_bwd(gpg_ctx* c, double* Z, int ldz, int rows, int valid);
 void gpg_launch_tile_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a_stride, double* dinv_base, int d_stride,
@@ -163,6 +174,8 @@ void gpg_launch_unscale(gpg_ctx* c, const double* v, double* z);          // z =
 int gpg_grad_partial_blocks(const gpg_ctx* c);
 int gpg_factor_apply_dev(gpg_ctx* c, int op, double* v, double* out);       // (L L^T) v or (L L^T)^-1 v, device vectors [Npad]
 void gpg_launch_extract(gpg_ctx* c, int which);                          // dense_tmp <- sym / P L
+int gpg_kern_rtensor_run(int kernel, int d, int n1, int n2, int n1g, int n2g, int use_grad, const double* theta, double hp_kernel,
+                         const double* rt_dev, const int* gpos1_dev, const int* gpos2_dev, double* out_dev, hipStream_t stream);
 int gpg_ws_activate(gpg_ctx* c, int which);                              // make workspace set `which` the active one (allocates set 1 on first use)
 
 // Device allocation inside a launch helper (task lists, flags, carrier tiles): on failure the pointer stays null, the

@@ -418,6 +418,60 @@ class GaussianProcess(HparaOptz):
             raise NotImplementedError('cond_eta_is_const=False (row-sum nugget) is outside the accelerated path')
         return hp, theta   # keep theta alive
 
+    # ---- kernel table (Kernel.py:27-126: bound per kernel type in the reference; same names and arguments here) ------
+    @staticmethod
+    def calc_Rtensor(X, Y, exp=1):
+        """CommonFun.py:56-84: R[k, a, b] = X[a, k] - Y[b, k] (the reference's body does not use `exp` either)."""
+        X, Y = np.asarray(X, dtype=np.float64), np.asarray(Y, dtype=np.float64)
+        assert X.shape[1] == Y.shape[1], 'The dimensions of the arrays do not match'
+        return np.ascontiguousarray(X.T[:, :, None] - Y.T[:, None, :])
+
+    def _kern_from_rtensor(self, Rtensor, theta, hp_kernel, use_grad, bvec1=None, bvec2=None):
+        Rtensor = np.ascontiguousarray(Rtensor, dtype=np.float64)
+        assert Rtensor.ndim == 3, 'Rtensor must have the shape [dim, n1, n2]'
+        dim, n1, n2 = Rtensor.shape
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        assert theta.size == dim, 'theta must have dim entries'
+        m1 = m2 = None
+        n1g, n2g = n1, n2
+        if use_grad:
+            if bvec1 is not None:
+                m1 = np.ascontiguousarray(bvec1, dtype=np.uint8)
+                assert m1.size == n1
+                n1g = int(m1.sum())
+            if bvec2 is not None:
+                m2 = np.ascontiguousarray(bvec2, dtype=np.uint8)
+                assert m2.size == n2
+                n2g = int(m2.sum())
+        shape = (n1 + n1g * dim, n2 + n2g * dim) if use_grad else (n1, n2)
+        out = np.empty(shape)
+        alpha = 0.0
+        if self.kernel_has_hp:
+            assert hp_kernel is not None and not np.isnan(hp_kernel), 'this kernel needs its hyperparameter hp_kernel'
+            alpha = float(np.asarray(hp_kernel).reshape(-1)[0])
+        ub = C.POINTER(C.c_ubyte)
+        rc = self._lib.gpg_kern_rtensor(self.device, _lib.GPG_KERNEL[self.kernel_type], dim, n1, n2, _lib.as_dp(Rtensor),
+                                        _lib.as_dp(theta), alpha, int(use_grad),
+                                        None if m1 is None else m1.ctypes.data_as(ub), None if m2 is None else m2.ctypes.data_as(ub),
+                                        _lib.as_dp(out))
+        if rc != 0:
+            raise _lib.GpgError(f'gpg_kern_rtensor failed ({rc}): {self._lib.gpg_last_error(None).decode()}')
+        return out
+
+    def calc_KernBase(self, Rtensor, theta, hp_kernel=None):
+        """Gradient-free kernel matrix [n1, n2] from the difference tensor -- sq_exp_calc_KernBase (KernelSqExp.py:16-46),
+        matern_5f2_calc_KernBase (KernelMatern5f2.py:16-52), rat_quad_calc_KernBase (KernelRatQuad.py:439-476), on the device."""
+        return self._kern_from_rtensor(Rtensor, theta, hp_kernel, False)
+
+    def calc_KernGrad(self, Rtensor, theta, hp_kernel=None, bvec_use_grad1=None, bvec_use_grad2=None):
+        """Gradient-enhanced kernel matrix [n1 + n1g d, n2 + n2g d] -- sq_exp_calc_KernGrad (KernelSqExp.py:320-410),
+        matern_5f2_calc_KernGrad (KernelMatern5f2.py:352-450), rat_quad_calc_KernGrad (KernelRatQuad.py:478-554), on the device."""
+        return self._kern_from_rtensor(Rtensor, theta, hp_kernel, True, bvec_use_grad1, bvec_use_grad2)
+
+    def calc_Kern(self, Rtensor, theta, hp_kernel=None, *masks):
+        """Kernel.py:116,122: calc_KernGrad when the model uses gradients, calc_KernBase otherwise."""
+        return self.calc_KernGrad(Rtensor, theta, hp_kernel, *masks) if self.use_grad else self.calc_KernBase(Rtensor, theta, hp_kernel)
+
     # ---- kernel + factorisation (compat entry points; the hot path does not materialise N x N arrays) ----
     def calc_Kern_w_chofac(self, Rtensor, hp_vals, noise_vec=None, calc_chofac=True, calc_cond=False,
                            materialize=False):
@@ -602,6 +656,48 @@ class GaussianProcess(HparaOptz):
         if return_all:
             return ln, outs
         return ln
+
+    def calc_lkd_grad_batch(self, hp_x0):
+        """Value and adjoint gradient (d ln_lkd / d hp in hp_info_optz_lkd order, with respect to the hyperparameter VALUES
+        like calc_lkd_all(calc_grad=True), CalcLkd.py:170-177 / 230-235) of every row of hp_x0 in ONE device call
+        (gpg_lkd_grad_batch).  Returns (ln_lkd [m], ln_lkd_grad [m, n_hp], ok [m]); rows whose factorisation failed have
+        ok False and NaN entries (the caller decides what a failure means: OptzLkd.py:74-77)."""
+        if self.bvec_use_grad is not None and not np.all(self.bvec_use_grad):
+            raise NotImplementedError('likelihood gradient with a bvec_use_grad mask is not supported')
+        rows = np.ascontiguousarray(self._rows_from_hp_x0(hp_x0))
+        m, d = rows.shape[0], self.dim
+        outs = (_lib.GpgLkdOut * m)()
+        g_aa, g_inv = np.zeros((m, d + 4)), np.zeros((m, d + 4))
+        noisy = self.b_has_noisy_data
+        t0 = time.time()
+        rc = self._lib.gpg_lkd_grad_batch(self._ctx, m, _lib.as_dp(rows), rows.shape[1], float(self._etaK),
+                                          _lib.GPG_WELLCOND[self.wellcond_mtd], int(not noisy), outs, _lib.as_dp(g_aa), _lib.as_dp(g_inv))
+        self._time_chofac += time.time() - t0
+        if rc != 0:
+            raise _lib.GpgError(f'gpg_lkd_grad_batch failed ({rc}): {self._err()}')
+        hi = self.hp_info_optz_lkd
+        ln, grad, ok = np.full(m, np.nan), np.full((m, hi.n_hp), np.nan), np.zeros(m, dtype=bool)
+        for i, o in enumerate(outs):
+            if o.info != 0:
+                continue
+            ok[i] = True
+            if noisy:
+                s_aa, pn = 0.5, 0.0
+            else:
+                pnlt = self.calc_lkd_varK_pnlt(o.varK, self._fval_in)
+                s_aa, pn = pnlt[1] / self.n_data + 1.0 / (2.0 * o.varK), pnlt[0]
+            ln[i] = o.ln_lkd - pn
+            g_all = s_aa * g_aa[i] + g_inv[i]
+            grad[i, hi.idx_theta] = g_all[:d]
+            if hi.has_kernel:
+                grad[i, hi.idx_kernel] = g_all[d + 3]
+            if hi.has_varK:
+                grad[i, hi.idx_varK] = g_all[d]
+            if hi.has_var_fval:
+                grad[i, hi.idx_var_fval] = g_all[d + 1]
+            if hi.has_var_fgrad:
+                grad[i, hi.idx_var_fgrad] = g_all[d + 2]
+        return ln, grad, ok
 
     def select_hp_best(self, hp_x0):
         """hp_best selection of GpHparaX0.py:33-59 for explicit start rows: the row of highest ln_lkd."""

@@ -19,6 +19,7 @@ the rescale well-conditioning methods are not available; the Latin-hypercube sou
 (`scipy.stats.qmc.LatinHypercube`, seed 1) because `smt` is not installed here -- its sample sequence differs
 from smt's, the bounds and everything downstream are the reference's.
 """
+import threading
 import time
 
 import numpy as np
@@ -42,6 +43,54 @@ def _nanmedian(a, width=None):
     return np.median(a, axis=0)
 
 
+class _LockstepObjective:
+    """The SLSQP runs of one multi-start advancing in lock step (the reference runs them one after the other,
+    OptzLkd.py:249-290, one value + gradient evaluation per iterate).  Every run lives in a thread of its own and is
+    SciPy's unmodified SLSQP; a run's objective request blocks until every run still alive has one pending, then ONE
+    batched device call (`calc_lkd_grad_batch`) serves them all.  SciPy's SLSQP keeps its state in the arrays of each
+    call, so the iterates of a run are exactly those of the sequential loop."""
+
+    def __init__(self, evaluate_rows, n_runs):
+        self._evaluate_rows = evaluate_rows                  # X [k, n_hp] -> list of k (value, gradient) pairs
+        self._cv = threading.Condition()
+        self._pending, self._results = {}, {}
+        self._live = n_runs
+        self._error = None
+        self.n_batches = 0
+        self.n_rows = 0
+
+    def _fire_if_complete(self):                             # caller holds the lock
+        if self._error is None and self._pending and len(self._pending) == self._live:
+            runs = sorted(self._pending)
+            X = np.array([self._pending[r] for r in runs])
+            self._pending.clear()
+            try:
+                vals = self._evaluate_rows(X)
+                self.n_batches += 1
+                self.n_rows += len(runs)
+                for r, v in zip(runs, vals):
+                    self._results[r] = v
+            except Exception as e:     # noqa: BLE001 -- every waiting run must be released with the error
+                self._error = e
+            self._cv.notify_all()
+
+    def request(self, run, x):
+        with self._cv:
+            self._pending[run] = np.array(x, dtype=float, copy=True)
+            self._fire_if_complete()
+            while run not in self._results and self._error is None:
+                self._cv.wait()
+            if self._error is not None:
+                raise self._error
+            return self._results.pop(run)
+
+    def finished(self, run):
+        with self._cv:
+            self._live -= 1
+            self._pending.pop(run, None)
+            self._fire_if_complete()
+
+
 class HparaOptz:
     """Mixin for `gpgradpy_amd.GaussianProcess`."""
 
@@ -60,6 +109,7 @@ class HparaOptz:
     hp_var_fval_range = [1e-8, 1e8]
     hp_var_fgrad_range = [1e-8, 1e8]
     b_use_cond_cstr = False
+    optz_lockstep = True          # run the SLSQP starts of a rank in lock step: one batched value + gradient call per round
     restart_group = None          # torch.distributed process group the restarts are sharded over (None: no sharding)
     _last_chofac_good = True
     _save_data = False
@@ -215,37 +265,60 @@ class HparaOptz:
     def calc_store_likelihood(self, hp_vec, always_calc_cond=False, calc_grad=True):
         hp_vec = np.atleast_1d(hp_vec).ravel()
         if not np.array_equal(hp_vec, self._last_hp_vec):
-            hp_vals = self.hp_vec2dataclass(self.hp_info_optz_lkd, hp_vec)
-            calc_cond = self.b_use_cond_cstr or always_calc_cond                   # OptzLkd.py:51
-            lkd_info, b_chofac_good = self.calc_lkd_all(hp_vals, calc_lkd=True, calc_cond=calc_cond, calc_grad=calc_grad)
-            cond_val, cond_grad = lkd_info.cond, lkd_info.cond_grad
-            if b_chofac_good:
-                ln_lkd_val = lkd_info.ln_lkd
-                ln_lkd_grad = lkd_info.ln_lkd_grad
-                if calc_grad:
-                    bvec = self.hp_info_optz_lkd.bvec_log_optz
-                    transformation = 10 ** hp_vec[bvec] * np.log(10)             # log10 chain rule, OptzLkd.py:65-73
-                    ln_lkd_grad[bvec] *= transformation
-                    if self.b_use_cond_cstr and cond_grad is not None:
-                        cond_grad[bvec] *= transformation
-            else:
-                # OptzLkd.py:74-77: a failed Cholesky makes minus the condition number the objective (and minus its
-                # gradient, WITHOUT the log10 chain rule, the slope), so that SLSQP walks back into the region where
-                # the matrix can be factorised.  calc_lkd_all computes both for the failed matrix up to N = 4096
-                # (host SVD / eigenvectors of the downloaded matrix); above that, and for 'precon' (where the
-                # reference has no cond_grad and stops with a TypeError), a large finite penalty / zero slope.
-                n_hp = self.hp_info_optz_lkd.n_hp
-                if cond_val is None or not np.isfinite(cond_val):
-                    cond_val = self.cond_max_abs
-                cond_grad = np.zeros(n_hp) if cond_grad is None else cond_grad
-                ln_lkd_val = -cond_val
-                ln_lkd_grad = -cond_grad
+            ln_lkd_val, ln_lkd_grad, cond_val, cond_grad, b_chofac_good = self._objective_at(hp_vec, always_calc_cond, calc_grad)
             self._last_hp_vec = hp_vec.copy()
             self._last_chofac_good = bool(b_chofac_good)
             self._lkd_val, self._lkd_grad = ln_lkd_val, ln_lkd_grad
             self._cond_val = np.nan if cond_val is None else cond_val
             self._cond_grad = cond_grad
         return self._lkd_val, self._lkd_grad, self._cond_val, self._cond_grad
+
+    def _objective_at(self, hp_vec, always_calc_cond=False, calc_grad=True):
+        """(ln_lkd, d ln_lkd / d hp_vec, cond, d cond / d hp_vec, Cholesky ok) at one optimiser vector -- the body of
+        calc_store_likelihood (OptzLkd.py:47-83), without the memo."""
+        hp_vals = self.hp_vec2dataclass(self.hp_info_optz_lkd, hp_vec)
+        calc_cond = self.b_use_cond_cstr or always_calc_cond                   # OptzLkd.py:51
+        lkd_info, b_chofac_good = self.calc_lkd_all(hp_vals, calc_lkd=True, calc_cond=calc_cond, calc_grad=calc_grad)
+        cond_val, cond_grad = lkd_info.cond, lkd_info.cond_grad
+        if b_chofac_good:
+            ln_lkd_val = lkd_info.ln_lkd
+            ln_lkd_grad = lkd_info.ln_lkd_grad
+            if calc_grad:
+                bvec = self.hp_info_optz_lkd.bvec_log_optz
+                transformation = 10 ** hp_vec[bvec] * np.log(10)             # log10 chain rule, OptzLkd.py:65-73
+                ln_lkd_grad[bvec] *= transformation
+                if self.b_use_cond_cstr and cond_grad is not None:
+                    cond_grad[bvec] *= transformation
+        else:
+            # OptzLkd.py:74-77: a failed Cholesky makes minus the condition number the objective (and minus its
+            # gradient, WITHOUT the log10 chain rule, the slope), so that SLSQP walks back into the region where
+            # the matrix can be factorised.  calc_lkd_all computes both for the failed matrix up to N = 4096
+            # (host SVD / eigenvectors of the downloaded matrix); above that, and for 'precon' (where the
+            # reference has no cond_grad and stops with a TypeError), a large finite penalty / zero slope.
+            n_hp = self.hp_info_optz_lkd.n_hp
+            if cond_val is None or not np.isfinite(cond_val):
+                cond_val = self.cond_max_abs
+            cond_grad = np.zeros(n_hp) if cond_grad is None else cond_grad
+            ln_lkd_val = -cond_val
+            ln_lkd_grad = -cond_grad
+        return ln_lkd_val, ln_lkd_grad, cond_val, cond_grad, b_chofac_good
+
+    def _objective_rows(self, X):
+        """Value and gradient (with respect to the optimiser vector: log10 chain rule, OptzLkd.py:65-70) at every row of X
+        by ONE batched device call; rows whose Cholesky failed go through the one-row path (condition-number objective)."""
+        X = np.atleast_2d(np.asarray(X, dtype=float))
+        ln, grad, ok = self.calc_lkd_grad_batch(X)
+        bvec = self.hp_info_optz_lkd.bvec_log_optz
+        out = []
+        for i in range(X.shape[0]):
+            if ok[i]:
+                g = grad[i].copy()
+                g[bvec] *= 10 ** X[i, bvec] * np.log(10)
+                out.append((ln[i], g))
+            else:
+                v, g = self._objective_at(X[i])[:2]
+                out.append((v, np.asarray(g, dtype=float)))
+        return out
 
     def return_optz_val(self, hp_vec):
         return -self.calc_store_likelihood(np.atleast_1d(hp_vec).ravel())[0]
@@ -291,8 +364,12 @@ class HparaOptz:
         if self.b_use_cond_cstr:                                                 # OptzLkd.py:245, GaussianProcess.py:210-212
             nlc = NonlinearConstraint(self.return_cond_val, -np.inf, self.cond_max, jac=self.return_cond_grad)
         err = None
+        lockstep = self.optz_lockstep and not self.b_use_cond_cstr and (hi - lo) > 1 and self.optz_mtd == 'SLSQP'
+        if lockstep:
+            err = self._run_starts_lockstep(hp_x0_all, lo, hi, optz_bound, optz_opt, optz_sol_all, optz_obj_all, all_optz_success,
+                                            all_total_fun_iter)
         try:
-            for i in range(lo, hi):
+            for i in range(lo, hi if not lockstep else lo):
                 x0_i = hp_x0_all[i, :]
                 if self.b_use_cond_cstr:                                         # OptzLkd.py:255-259
                     self._last_hp_vec = np.full((1, x0_i.size), np.nan)
@@ -344,6 +421,40 @@ class HparaOptz:
         if self.b_use_cond_cstr:                                                 # final condition number, OptzLkd.py:324-331
             cond_val = self.calc_lkd_all(self.hp_vec2dataclass(self.hp_info_optz_lkd, best_hp), calc_cond=True)[0].cond
         return best_hp, cond_val, surr_optz_info
+
+    def _run_starts_lockstep(self, hp_x0_all, lo, hi, optz_bound, optz_opt, sol, obj, success, nit):
+        """Starts [lo, hi) as concurrent SLSQP runs served by batched value + gradient calls (_LockstepObjective).
+        Fills the result arrays in place; returns the first exception raised by a run (or None)."""
+        ev = _LockstepObjective(self._objective_rows, hi - lo)
+        errors = {}
+
+        def run(i):
+            memo = {'x': None, 'v': None, 'g': None}
+
+            def at(x):
+                x = np.atleast_1d(x).ravel()
+                if memo['x'] is None or not np.array_equal(x, memo['x']):
+                    memo['v'], memo['g'] = ev.request(i, x)
+                    memo['x'] = x.copy()
+                return memo
+            try:
+                res = minimize(lambda x: -at(x)['v'], hp_x0_all[i, :], method='SLSQP', jac=lambda x: -at(x)['g'],
+                               bounds=optz_bound, constraints=[], options=optz_opt)
+                sol[i, :], obj[i], success[i], nit[i] = res.x, res.fun, res.success, res.nit
+                if not res.success:
+                    print(f'Surr hpara optz: Con GOOD, Optimizer: {res.message}')
+            except Exception as e:      # noqa: BLE001
+                errors[i] = e
+            finally:
+                ev.finished(i)
+        threads = [threading.Thread(target=run, args=(i,), name=f'slsqp-start-{i}') for i in range(lo, hi)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        self.optz_lockstep_batches, self.optz_lockstep_rows = ev.n_batches, ev.n_rows
+        self._last_hp_vec = None
+        return errors[min(errors)] if errors else None
 
     # ---- driver (GpHparaOptz.py:140-218) -------------------------------------------------------------------------
     def get_init_hp_vals(self):

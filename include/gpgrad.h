@@ -109,6 +109,15 @@ int gpg_lkd_grad(gpg_ctx* ctx, const gpg_hp* hp, gpg_lkd_out* out, double* g_aa,
 int gpg_lkd_batch(gpg_ctx* ctx, int m, const double* hp_rows, int row_len, double eta, int wellcond,
                   int closed_form_varK, gpg_lkd_out* out);
 
+/* Value AND adjoint gradient of m restart rows in one call: what m SLSQP runs of the reference's multi-start
+ * (OptzLkd.py:249-290, one calc_store_likelihood per iterate: OptzLkd.py:15-100) ask for when they advance in lock step.
+ * Rows as gpg_lkd_batch; out [m]; g_aa, g_inv [m, dim + 4] row-major with the slots of gpg_lkd_grad.  Rows whose
+ * factorisation fails get info > 0 and NaN gradients.  The factorisations, the two N^3/3 sweeps of the explicit inverse
+ * (W = L^-T, -(W W^T)) run as ONE dataflow launch each per group of up to 8 rows; results are bit-identical to m calls
+ * of gpg_lkd_grad. */
+int gpg_lkd_grad_batch(gpg_ctx* ctx, int m, const double* hp_rows, int row_len, double eta, int wellcond,
+                       int closed_form_varK, gpg_lkd_out* out, double* g_aa, double* g_inv);
+
 /* Posterior -------------------------------------------------------------------------------------- */
 
 /* Replaces GpEvalModel.setup_eval_model (GpEvalModel.py:17-57): factorises the matrix for hp (the
@@ -158,6 +167,19 @@ int gpg_predict_hess(gpg_ctx* ctx, const double* xq, double varK, double* mu, do
  *   4 the same for the factor KEPT by the last successful gpg_setup_eval, whatever likelihood calls came after it
  *     (hp ignored for 3 and 4). */
 int gpg_get_matrix(gpg_ctx* ctx, const gpg_hp* hp, int which, double* out);
+
+/* Kernel table of the reference (Kernel.py:27-126): calc_KernBase / calc_KernGrad as functions of the difference
+ * tensor, exactly as the reference's bound attributes take it -- replaces sq_exp_calc_KernBase / _KernGrad
+ * (KernelSqExp.py:16-46, 320-410), matern_5f2_calc_KernBase / _KernGrad (KernelMatern5f2.py:16-52, 352-450),
+ * rat_quad_calc_KernBase / _KernGrad (KernelRatQuad.py:439-554).  rtensor [dim, n1, n2] row-major with
+ * R[k, a, b] = X1[a, k] - X2[b, k] (CommonFun.py:56-84); two DIFFERENT point sets are fine.  use_grad = 0: out
+ * [n1, n2] = KernBase.  use_grad != 0: out [n1 + n1g dim, n2 + n2g dim] row-major = KernGrad in the derivative-major
+ * block layout, where use_grad1 [n1] / use_grad2 [n2] (NULL = all) are bvec_use_grad1 / 2 and n1g, n2g their counts.
+ * No context: a self-contained call on `device` (uploads the tensor, downloads the matrix); errors through
+ * gpg_last_error(NULL). */
+int gpg_kern_rtensor(int device, int kernel, int dim, int n1, int n2, const double* rtensor, const double* theta,
+                     double hp_kernel, int use_grad, const unsigned char* use_grad1, const unsigned char* use_grad2,
+                     double* out);
 
 /* Products with the matrix that was factorised last (gpg_lkd / gpg_setup_eval), through its factor in HBM:
  * op 0: out = (L L^T) v, op 1: out = (L L^T)^-1 v; v, out host [N].  L L^T is Kcov_precon = varK (Kcor + eta I)

@@ -27,9 +27,10 @@ def _shared_gpu_worker(rank, q):
 
 @pytest.mark.gpu
 def test_two_processes_share_one_gpu():
-    """Two dataflow factorisations on the same device can starve each other (each launch's waiting workgroups may hold
-    the slots the other one's oldest pending workgroup needs).  Every wait is bounded; the library then repeats the
-    call with the blocked schedule.  Either way both processes must get the single-process numbers."""
+    """Two processes run dataflow launches on the same device at the same time.  The persistent workgroups take their
+    tasks from a ticket counter and only ever wait for smaller tickets, so a launch needs nobody else's slots to make
+    progress (cholesky_dataflow.hip: tile_chol_kernel): neither process may have timed out into the blocked fallback
+    (factor_fallbacks() == 0), and both must get the single-process numbers."""
     import multiprocessing as mp
     import numpy as np
     ctx = mp.get_context("spawn")
@@ -46,10 +47,9 @@ def test_two_processes_share_one_gpu():
     p.start()
     _, ref, fb = q1.get(timeout=300)
     p.join(timeout=60)
-    assert fb == 0                                     # alone on the device: no fallback
-    for _, ln, _ in res:
+    assert fb == 0
+    for _, ln, fb2 in res:
+        assert fb2 == 0                                # sharing the device costs time, never the schedule
         assert np.all(np.isfinite(ln))
         np.testing.assert_allclose(ln[:6], ref[:6], rtol=1e-9)
-        # posterior values: the blocked sweeps of the fallback sum in another order (kappa-amplified, cf. the 5.8e-8
-        # worst case of profiles/r01_parity_report.txt)
         np.testing.assert_allclose(ln[6:], ref[6:], rtol=1e-6, atol=1e-8)

@@ -98,11 +98,22 @@ def _optz_worker(rank, world, port, out_dir):
             b = 2 * (x[0] - 1) ** 2 + (x[1] + 1) ** 2
             return np.array([2 * (x[0] + 2), 2 * (x[1] - 1)]) if a < b else np.array([4 * (x[0] - 1), 2 * (x[1] + 1)])
 
+    def rows(self, X):           # the lock-step path's batched evaluator: (ln_lkd, gradient) = minus the objective
+        self.batches.append(len(X))
+        return [(-self.return_optz_val(x), -self.return_optz_grad(x)) for x in X]
+
+    Fake.batches = []
+    Fake._objective_rows = rows
     gp = Fake()
     gp.shard_restarts = lambda g: setattr(gp, "restart_group", g)
     gp.shard_restarts(dist.group.WORLD)
     x0 = np.array([[-2.5, 1.5], [-1.5, 0.5], [0.5, -0.5], [2.0, -2.0], [0.9, -1.2]])
     best, cond, info = gp.optz_hp_max_lkd(x0, Bounds([-5, -5], [5, 5], keep_feasible=True))
+    # rank 0 owns starts 0..2, rank 1 starts 3..4: their SLSQP runs advanced together, one batched call per round
+    assert Fake.batches and max(Fake.batches) == (3 if rank == 0 else 2) and gp.optz_lockstep_batches == len(Fake.batches)
+    gp.optz_lockstep = False     # and the sequential loop (the reference's order) ends at the same optimum
+    best_seq, _, _ = gp.optz_hp_max_lkd(x0, Bounds([-5, -5], [5, 5], keep_feasible=True))
+    np.testing.assert_array_equal(best_seq, best)
     np.save(os.path.join(out_dir, f"best_{rank}.npy"), best)
     np.save(os.path.join(out_dir, f"obj_{rank}.npy"), gp.optz_obj_all_last)
     dist.destroy_process_group()
