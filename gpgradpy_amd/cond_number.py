@@ -7,8 +7,14 @@ reorthogonalisation, the small tridiagonal eigenproblem by LAPACK on the host) o
 through the factor: v -> (L L^T) v and v -> (L L^T)^-1 v (``gpg_factor_apply``).  Each step moves one vector of
 N doubles over PCIe.
 """
+import warnings
+
 import numpy as np
 from scipy.linalg import eigh_tridiagonal
+
+
+class LanczosNotConverged(RuntimeWarning):
+    """The Ritz value returned by lanczos_largest did not meet its residual bound within k_max steps."""
 
 
 def lanczos_largest(apply, n, k_max=120, rtol=1e-9, seed=0, want_vector=False):
@@ -43,7 +49,14 @@ def lanczos_largest(apply, n, k_max=120, rtol=1e-9, seed=0, want_vector=False):
                 return done(theta, ritz, j)
         else:
             theta = a
-        if b <= 1e-300 or j + 1 >= k_max:
+        if b <= 1e-300:                                      # invariant subspace: the Ritz values are exact
+            return done(theta, ritz, j)
+        if j + 1 >= k_max:
+            if k_max < n:                                    # (k_max = n is the full Krylov space: exact up to rounding)
+                res = b * abs(evec[-1, -1]) / abs(theta) if j >= 1 else np.inf
+                warnings.warn(f'Lanczos: largest Ritz value not converged after {k_max} steps '
+                              f'(relative residual bound {res:.2e} > {rtol:.1e}); the condition number is a lower bound',
+                              LanczosNotConverged, stacklevel=2)
             return done(theta, ritz, j)
         beta.append(b)
         Q[j + 1] = w / b

@@ -391,14 +391,18 @@ static int batch_plan(gpg_ctx* c, int m) {
       // from 8 to 16); none at 68k columns
       bmax = (1280 + c->Npad / 128 - 1) / (c->Npad / 128);
     } else {
+      // very large matrices (cfg5: 68096 padded columns, 37 GB per workspace): the chain-bound ends are ~3 % of one
+      // factorisation there and several matrices per launch gain nothing (measured: 65.7 TF with three per launch against
+      // 66.0 one at a time, profiles/r02b_bench_cfg5_3perlaunch.json); gpg_set_batch(2..3) still works (288 GB hold them)
       bmax = 1;
     }
     if (bmax > 1) bmax = bmax < 8 ? 8 : (bmax > 64 ? 64 : bmax);
   }
+  if (c->batch_max > 1 && c->Npad > 32768 && bmax > 3) bmax = 3;
   if (!(small || large_df) || bmax <= 1 || m <= 1) return 1;
   const size_t bytesA = sizeof(double) * c->A_elems;
   int Bcap = bmax;
-  while (Bcap > 1 && bytesA * Bcap > ((size_t)96 << 30)) --Bcap;   // at most 96 GB of extra workspaces (288 GB per GPU)
+  while (Bcap > 1 && bytesA * Bcap > ((size_t)120 << 30)) --Bcap;  // at most 120 GB of extra workspaces (288 GB per GPU)
   if (Bcap > c->batch_cap) {
     if (c->batchA) (void)hipFree(c->batchA);
     if (c->batchV) (void)hipFree(c->batchV);

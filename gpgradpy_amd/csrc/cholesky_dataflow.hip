@@ -5,6 +5,14 @@
 
 namespace {
 
+// One ticket counter, or (A/B builds, -DGPG_TICKET_QUEUES) eight of them: workgroup b draws from queue b % 8, whose tasks
+// are the list positions q, q + 8, ... -- the static task -> XCD deal of a one-task-per-workgroup launch, kept persistent.
+#ifdef GPG_TICKET_QUEUES
+#define GPG_TICKET_FETCH(ticket) ((int)(blockIdx.x & 7) + 8 * __hip_atomic_fetch_add((ticket) + (blockIdx.x & 7), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+#else
+#define GPG_TICKET_FETCH(ticket) __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#endif
+
 // Next task of a persistent workgroup: one relaxed agent-scope fetch-add by thread 0, shared through LDS.  The two
 // barriers also separate the LDS use of consecutive tasks.
 __device__ __forceinline__ int next_ticket(int* ticket, int* sh, int round) {
@@ -17,11 +25,23 @@ __device__ __forceinline__ int next_ticket(int* ticket, int* sh, int round) {
 #endif
   (void)round;
   __syncthreads();
-  if (threadIdx.x == 0) *sh = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) *sh = GPG_TICKET_FETCH(ticket);
   __syncthreads();
   return *sh;
 #endif
 }
+
+// Wave priority by phase.  The two workgroups of a compute unit share every SIMD, and between equal priorities the
+// OLDER wave wins the issue arbitration.  With one-task workgroups that order follows the task order by itself (the
+// workgroup nearer its end is the older one); persistent workgroups keep their launch age for the whole factorisation,
+// so half of the latency-bound finalisations (dependent fp64 VALU chains: pivots, substitutions) would queue behind the
+// partner's MFMA stream whatever their place on the critical path.  The finalisation therefore raises its priority
+// explicitly, the accumulation of a diagonal tile (the head of its tile column) runs above ordinary accumulation.
+#ifndef GPG_NO_SETPRIO
+#define GPG_PRIO(n) __builtin_amdgcn_s_setprio(n)
+#else
+#define GPG_PRIO(n)
+#endif
 
 // Ticket of the NEXT task, fetched by the publish step of the current one (GPG_PUBLISH_AND_NEXT): the fetch-add travels
 // with the drain of the tile's write-through stores, so a workgroup that finishes a task knows its next one without a
@@ -34,16 +54,18 @@ __shared__ int g_next_ticket;
 #define GPG_PUBLISH_AND_NEXT(ticket, flag_ptr)                                             \
   GPG_RELEASE();                                                                            \
   __syncthreads();                                                                          \
-  if (threadIdx.x == 0) { GPG_FLAG_UP(flag_ptr); g_next_ticket = 0x7fffffff; }
+  if (threadIdx.x == 0) { GPG_FLAG_UP(flag_ptr); g_next_ticket = 0x7fffffff; }             \
+  GPG_PRIO(0);
 #else
 #define GPG_PUBLISH_AND_NEXT(ticket, flag_ptr)                                             \
   {                                                                                         \
     int nxt_ = 0;                                                                           \
-    if (threadIdx.x == 0) nxt_ = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+    if (threadIdx.x == 0) nxt_ = GPG_TICKET_FETCH(ticket);                                  \
     GPG_RELEASE();                                                                          \
     if (threadIdx.x == 0) g_next_ticket = nxt_;                                             \
     __syncthreads();                                                                        \
     if (threadIdx.x == 0) GPG_FLAG_UP(flag_ptr);                                            \
+    GPG_PRIO(0);                                                                            \
   }
 #endif
 
@@ -128,6 +150,7 @@ tile_chol_task(int tix, double* A, int ld, int c0, int Mt, const int* __restrict
   }
 
   // ---- (1) left-looking accumulation over the finished tile columns ------------------------------------------
+  if (ti == tj) GPG_PRIO(1);
   int kdone = 0;
   while (kdone < tj) {
     if (tid == 0) {
@@ -160,6 +183,7 @@ tile_chol_task(int tix, double* A, int ld, int c0, int Mt, const int* __restrict
   }
 
   // ---- (2) accumulators -> LDS tile Ts[col][row] --------------------------------------------------------------
+  if (ti == tj) { GPG_PRIO(3); } else { GPG_PRIO(2); }
   {
     double* Ts = U;
 #pragma unroll
@@ -458,6 +482,7 @@ tile128_chol_task(int tix, double* A, int ld, int Mt, const int* __restrict__ ta
       }
 
   // ---- (1) left-looking accumulation ----------------------------------------------------------------------------
+  if (ti == tj) GPG_PRIO(1);
   int kdone = 0;
   while (kdone < tj) {
     GPG_TR(q0)
@@ -498,6 +523,7 @@ tile128_chol_task(int tix, double* A, int ld, int Mt, const int* __restrict__ ta
 #ifdef GPG_STAMP
   const unsigned long long tk_fin0 = __builtin_amdgcn_s_memrealtime();
 #endif
+  if (ti == tj) { GPG_PRIO(3); } else { GPG_PRIO(2); }
   // ---- (2) the updated tile goes back to memory; the finalisation works on it in place.  Diagonal tile: the
   //      top-left 64 x 64 block goes straight into the LDS tile its own wave factors next, the strictly upper
   //      block is dropped. ---------------------------------------------------------------------------------------
@@ -647,6 +673,7 @@ tile128_trinv_task(int tix, const double* __restrict__ A, int ld, const double* 
         *reinterpret_cast<double2*>(Cw + 32 * g + (size_t)(32 * (ni >> 1) + 8 * r + (ni & 1)) * ldw) = v;
       }
   __syncthreads();
+  GPG_PRIO(2);
   // the diagonal tile of L is final: its piece flags are a constant array of ones
   if (!tile_solve_rows128(A + ci + ci * (size_t)ld, ld, dinv + ci, W + r0 + ci * (size_t)ldw, ldw, t128_U, t128_Ls, t128_sdinv, ones,
                           ones + 4, ones, abort_word, info, &sh_ok))
@@ -1118,14 +1145,14 @@ static void launch_tile_chol(gpg_ctx* c, int c0) {
   if (Mt <= 0) return;
   const TileMap& tm = get_tile_tasks(c, Mt, Rt);
   if (!tm.dev) return;
-  const size_t nflag = (size_t)Mt * Rt + 1 + 4 * (size_t)Mt + 1;   // tile flags, abort word, four piece flags per diagonal tile, ticket
+  const size_t nflag = (size_t)Mt * Rt + 1 + 4 * (size_t)Mt + 8;   // tile flags, abort word, four piece flags per diagonal tile, ticket words
   if (!ensure_tile_flags(c, nflag)) return;
   (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
   const double m = (double)(c->N - c0);                    // algorithmic flops: N^3 / 3 of the real matrix, not of the padded one
   gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, m > 0 ? m * m * m / 3.0 : 0.0);
   int* abort_word = c->tile_flags + (size_t)Mt * Rt;
   hipLaunchKernelGGL(tile_chol_kernel, dim3(persistent_grid(c, tile_chol_kernel, tm.n)), dim3(256), 0, c->stream,
-                     TileCholArgs{c->A, c->ld, c0, Mt, tm.dev, tm.n, c->tile_flags, abort_word + 1, abort_word, c->tile_flags + (nflag - 1),
+                     TileCholArgs{c->A, c->ld, c0, Mt, tm.dev, tm.n, c->tile_flags, abort_word + 1, abort_word, c->tile_flags + (nflag - 8),
                                   c->dinv, c->info, c->N, nullptr, 0, 0, 0});
   gpg_prof_end(c);
 }
@@ -1152,14 +1179,14 @@ static void launch_tile_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a_st
     it = c->tilemaps.emplace(key, tm).first;
   }
   const TileMap& tm = it->second;
-  const size_t per = (size_t)Mt * Rt + 1 + 4 * (size_t)Mt, nflag = per * B + 1;   // + the ticket of the launch
+  const size_t per = (size_t)Mt * Rt + 1 + 4 * (size_t)Mt, nflag = per * B + 8;   // + the ticket words of the launch
   if (!ensure_tile_flags(c, nflag)) return;
   (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
   const double m = (double)c->N;
   gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, B * m * m * m / 3.0);
   int* abort_word = c->tile_flags + (size_t)Mt * Rt;      // the abort word of matrix 0 serves the whole launch
   hipLaunchKernelGGL(tile_chol_kernel, dim3(persistent_grid(c, tile_chol_kernel, tm.n)), dim3(256), 0, c->stream,
-                     TileCholArgs{Abase, c->ld, 0, Mt, tm.dev, tm.n, c->tile_flags, abort_word + 1, abort_word, c->tile_flags + (nflag - 1),
+                     TileCholArgs{Abase, c->ld, 0, Mt, tm.dev, tm.n, c->tile_flags, abort_word + 1, abort_word, c->tile_flags + (nflag - 8),
                                   dinv_base, info_base, c->N, tm.dev + tm.n, a_stride, d_stride, (int)per});
   gpg_prof_end(c);
 }
@@ -1169,14 +1196,14 @@ static void launch_tile128_chol(gpg_ctx* c) {
   const int Mt = c->Npad / 128, Rt = c->ld / 128;
   const TileMap& tm = get_tile_tasks(c, Mt, Rt);
   if (!tm.dev) return;
-  const size_t nflag = (size_t)Mt * Rt + 1 + 9 * (size_t)Mt + 1;   // tile flags, abort word, 4 + 4 piece flags and the L21 flag per diagonal tile, ticket
+  const size_t nflag = (size_t)Mt * Rt + 1 + 9 * (size_t)Mt + 8;   // tile flags, abort word, 4 + 4 piece flags and the L21 flag per diagonal tile, ticket words
   if (!ensure_tile_flags(c, nflag)) return;
   (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
   const double m = (double)c->N;
   gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, m * m * m / 3.0);
   int* abort_word = c->tile_flags + (size_t)Mt * Rt;
   hipLaunchKernelGGL(tile128_chol_kernel, dim3(persistent_grid(c, tile128_chol_kernel, tm.n)), dim3(256), 0, c->stream,
-                     TileCholArgs{c->A, c->ld, 0, Mt, tm.dev, tm.n, c->tile_flags, abort_word + 1, abort_word, c->tile_flags + (nflag - 1),
+                     TileCholArgs{c->A, c->ld, 0, Mt, tm.dev, tm.n, c->tile_flags, abort_word + 1, abort_word, c->tile_flags + (nflag - 8),
                                   c->dinv, c->info, c->N, nullptr, 0, 0, 0});
   gpg_prof_end(c);
 }
@@ -1201,14 +1228,14 @@ static void launch_tile128_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a
     it = c->tilemaps.emplace(key, tm).first;
   }
   const TileMap& tm = it->second;
-  const size_t per = (size_t)Mt * Rt + 1 + 9 * (size_t)Mt, nflag = per * B + 1;   // + the ticket of the launch
+  const size_t per = (size_t)Mt * Rt + 1 + 9 * (size_t)Mt, nflag = per * B + 8;   // + the ticket words of the launch
   if (!ensure_tile_flags(c, nflag)) return;
   (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
   const double m = (double)c->N;
   gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, B * m * m * m / 3.0);
   int* abort_word = c->tile_flags + (size_t)Mt * Rt;
   hipLaunchKernelGGL(tile128_chol_kernel, dim3(persistent_grid(c, tile128_chol_kernel, tm.n)), dim3(256), 0, c->stream,
-                     TileCholArgs{Abase, c->ld, 0, Mt, tm.dev, tm.n, c->tile_flags, abort_word + 1, abort_word, c->tile_flags + (nflag - 1),
+                     TileCholArgs{Abase, c->ld, 0, Mt, tm.dev, tm.n, c->tile_flags, abort_word + 1, abort_word, c->tile_flags + (nflag - 8),
                                   dinv_base, info_base, c->N, tm.dev + tm.n, a_stride, d_stride, (int)per});
   gpg_prof_end(c);
 }

@@ -327,13 +327,15 @@ __global__ void __launch_bounds__(256) grad_contract_kernel(AsmParams P, const d
   }
 }
 
-// fixed-order sum of the per-workgroup partials -> out[2 * NS]
+// fixed-order sum of the per-workgroup partials -> out[2 * NS]: one wave per value, lane l adds the partials of the
+// workgroups l, l + 64, ... in order, then the 64 lane sums are combined by a fixed shuffle tree (deterministic)
 __global__ void grad_final_reduce_kernel(const double* __restrict__ partial, int nblocks, int nvals, double* __restrict__ out) {
-  const int k = threadIdx.x;
+  const int k = blockIdx.x, lane = threadIdx.x;
   if (k >= nvals) return;
   double s = 0.0;
-  for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * (2 * GPG_GRAD_SLOTS_MAX) + k];
-  out[k] = s;
+  for (int b = lane; b < nblocks; b += 64) s += partial[(size_t)b * (2 * GPG_GRAD_SLOTS_MAX) + k];
+  s = wave_sum_g(s);
+  if (lane == 0) out[k] = s;
 }
 
 template <int KERN>
@@ -372,7 +374,7 @@ void gpg_launch_grad_contract(gpg_ctx* c, const AsmParams& p, double* partial, d
   else if (p.kernel == GPG_KERNEL_RATQU) launch_contract_d<GPG_KERNEL_RATQU>(c, p, partial, grid, zvec, Minv);
   else launch_contract_d<GPG_KERNEL_MA5F2>(c, p, partial, grid, zvec, Minv);
   const int ns = p.d + 3 + (p.kernel == GPG_KERNEL_RATQU ? 1 : 0);
-  hipLaunchKernelGGL(grad_final_reduce_kernel, dim3(1), dim3(64), 0, c->stream, partial, (int)(grid.x * grid.y),
+  hipLaunchKernelGGL(grad_final_reduce_kernel, dim3(2 * ns), dim3(64), 0, c->stream, partial, (int)(grid.x * grid.y),
                      2 * ns, out_dev);
 }
 

@@ -241,7 +241,7 @@ int gpg_last_factor(gpg_ctx* ctx, int* kernel, int* matrices);
  * dataflow launch (task lists interleaved tile column by tile column).  A single small factorisation is
  * latency-bound and leaves most of the chip idle; a large one does so at its two ends.  Results are bit-identical to
  * the one-at-a-time path.  -1 (default): automatic (8 .. 64 rows, fewer the larger the matrix, 8 from ~18000 padded
- * columns up to 32768, 1 above); 0 / 1: off.  With enough rows per launch (rows x Npad / 128 >= 320, Npad >= 2048)
+ * columns up to 32768, 1 above, where 2 .. 3 can be asked for explicitly); 0 / 1: off.  With enough rows per launch (rows x Npad / 128 >= 320, Npad >= 2048)
  * the 128 x 128-tile kernel is used whatever the single-matrix choice of GPG_FACTOR_AUTO would be. */
 int gpg_set_batch(gpg_ctx* ctx, int max_matrices);
 /* Allocates the batch workspaces a gpg_lkd_batch call with `rows` rows will use (otherwise done by the first such

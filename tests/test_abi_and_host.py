@@ -139,3 +139,21 @@ def test_shard_rows_partition():
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
     assert shard_rows(64, 8, 3) == (24, 32)     # BASELINE cfg4: 8 rows per GPU in rank order
+
+
+def test_lanczos_reports_non_convergence():
+    """cond_number.lanczos_largest must not hand back an unconverged Ritz value silently (k_max reached)."""
+    import warnings
+    from gpgradpy_amd.cond_number import LanczosNotConverged, lanczos_largest
+    rng = np.random.default_rng(0)
+    Q, _ = np.linalg.qr(rng.standard_normal((200, 200)))
+    A = (Q * np.linspace(1.0, 1.0001, 200)) @ Q.T               # clustered spectrum: five steps cannot resolve the top
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        lanczos_largest(lambda v: A @ v, 200, k_max=5)
+    assert any(issubclass(x.category, LanczosNotConverged) for x in w)
+    B = (Q * np.linspace(1.0, 100.0, 200)) @ Q.T
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        lam = lanczos_largest(lambda v: B @ v, 200)
+    assert not w and abs(lam - 100.0) < 1e-6

@@ -553,6 +553,11 @@ def test_cfg5_size_properties():
     hp = GP.hp_vec2dataclass(GP.hp_info_optz_lkd, row)
     ln_df = GP.calc_lkd_all(hp)[0].ln_lkd
     assert GP.last_factor() == ('tile128', 1)
+    # several 37 GB workspaces fit in 288 GB: restart rows are factorised two / three per launch at this size too, bit for bit
+    GP.set_batch(2)
+    ln_b = GP.calc_lkd_batch(tab[:2])
+    assert GP.last_factor() == ('tile128', 2) and ln_b[0] == ln_df and np.isfinite(ln_b[1])
+    GP.set_batch(-1)
     GP.set_factor_mode('blocked')
     ln_bl = GP.calc_lkd_all(hp)[0].ln_lkd
     assert GP.last_factor()[0] == 'blocked'

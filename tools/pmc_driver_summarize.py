@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Summarise tools/profile_driver.sh output: per-dispatch HBM traffic of the dominant kernel from the PMC passes, next
+to its durations from the kernel trace of the same command.
+
+    python tools/pmc_driver_summarize.py gpurun_out/<tag> --config cfg3 --mats 5,10,10 [--update profiles/pmc_traffic.json]
+
+--mats: matrices factorised by each dispatch of the dominant kernel, in dispatch order (bench.py: one warm-up launch with
+`warmup` rows, then the timed launches).  FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB; on gfx950 FETCH_SIZE
+counts a wide streamed read at half its bytes (MI355X_MICROARCH.md, HBM section): traffic = 2 x FETCH + WRITE.
+Prints a text table (redirect into profiles/) and, with --update, rewrites the entries of that configuration in the
+JSON table bench.py reads `roofline.traffic` from."""
+import argparse
+import collections
+import csv
+import glob
+import json
+import os
+
+ap = argparse.ArgumentParser()
+ap.add_argument("root")
+ap.add_argument("--config", default="cfg3")
+ap.add_argument("--mats", default="")
+ap.add_argument("--kernel", default="tile128_chol_kernel")
+ap.add_argument("--update", default="")
+ap.add_argument("--source", default="")
+args = ap.parse_args()
+
+
+def short(name):
+    return name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+
+
+def newest(pattern):
+    c = sorted(glob.glob(pattern, recursive=True), key=os.path.getmtime)
+    return c[-1] if c else None
+
+
+# per-dispatch counter totals of the dominant kernel, in dispatch order, per pass
+per_pass = {}
+for d in sorted(glob.glob(os.path.join(args.root, "pmc_*"))):
+    if not os.path.isdir(d):
+        continue
+    f = newest(os.path.join(d, "**", "*counter_collection.csv"))
+    if not f:
+        continue
+    tot = collections.OrderedDict()
+    for r in csv.DictReader(open(f)):
+        if short(r["Kernel_Name"]) != args.kernel:
+            continue
+        key = int(r["Dispatch_Id"])
+        tot.setdefault(key, collections.defaultdict(float))
+        tot[key][r["Counter_Name"]] += float(r["Counter_Value"])
+        tot[key]["_ns"] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+    per_pass[os.path.basename(d)] = [tot[k] for k in sorted(tot)]
+
+# durations from the un-instrumented kernel trace of the same command
+trace = newest(os.path.join(args.root, "stats", "**", "*kernel_trace.csv"))
+durs = []
+if trace:
+    for r in csv.DictReader(open(trace)):
+        if short(r["Kernel_Name"]) == args.kernel:
+            durs.append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6))
+    durs = [d for _, d in sorted(durs)]
+ndisp = max([len(v) for v in per_pass.values()] + [len(durs)])
+mats = [int(x) for x in args.mats.split(",")] if args.mats else [1] * ndisp
+
+
+def col(pass_name, counter, i):
+    v = per_pass.get(pass_name, [])
+    return v[i].get(counter, 0.0) if i < len(v) else float("nan")
+
+
+cmd = open(os.path.join(args.root, "command.txt")).read().strip() if os.path.exists(os.path.join(args.root, "command.txt")) else "?"
+print(f"# rocprofv3 over `{cmd}` (tools/profile_driver.sh): {args.kernel}, one line per dispatch")
+print(f"# FETCH_SIZE / WRITE_SIZE passes are separate runs of the same command; ms (trace) = un-instrumented kernel trace of that command")
+print(f"{'disp':>4s} {'mats':>4s} {'ms (trace)':>10s} {'FETCH GB raw':>12s} {'FETCH GB x2':>11s} {'WRITE GB':>9s} {'traffic GB':>10s} {'per matrix':>10s} {'L2 hit':>6s} {'MFMA busy':>9s} {'TB/s':>6s}")
+entries = []
+for i in range(ndisp):
+    fetch = col("pmc_FETCH_SIZE", "FETCH_SIZE", i) * 1024
+    write = col("pmc_WRITE_SIZE", "WRITE_SIZE", i) * 1024
+    hit, miss = col("pmc_TCC_HIT_sum", "TCC_HIT_sum", i), col("pmc_TCC_HIT_sum", "TCC_MISS_sum", i)
+    cyc = col("pmc_GRBM_GUI_ACTIVE", "GRBM_GUI_ACTIVE", i) / 8.0
+    busy = col("pmc_GRBM_GUI_ACTIVE", "SQ_VALU_MFMA_BUSY_CYCLES", i) / (1024.0 * cyc) if cyc and cyc == cyc else float("nan")
+    ms = durs[i] if i < len(durs) else float("nan")
+    m = mats[i] if i < len(mats) else 1
+    traffic = 2 * fetch + write
+    print(f"{i:4d} {m:4d} {ms:10.3f} {fetch / 1e9:12.2f} {2 * fetch / 1e9:11.2f} {write / 1e9:9.2f} {traffic / 1e9:10.2f} {traffic / m / 1e9:10.2f} "
+          f"{hit / max(1.0, hit + miss):6.2f} {busy:9.2f} {traffic / (ms * 1e-3) / 1e12 if ms == ms and ms > 0 else float('nan'):6.2f}")
+    entries.append(dict(config=args.config, kernel=args.kernel, matrices_per_launch=m, fetch_bytes_raw=fetch, write_bytes=write,
+                        traffic_bytes_per_launch=traffic, l2_hit=hit / max(1.0, hit + miss), mfma_busy=busy, launch_ms_trace=ms,
+                        source=args.source or f"rocprofv3 --pmc over `{cmd}` (FETCH_SIZE x 2 + WRITE_SIZE)"))
+if args.update:
+    try:
+        table = json.load(open(args.update))
+    except (OSError, ValueError):
+        table = {"entries": []}
+    keep = [e for e in table.get("entries", []) if not (e.get("config") == args.config and e.get("kernel") == args.kernel)]
+    best = {}
+    for e in entries:                     # one entry per matrices_per_launch: the LAST dispatch of that size (timed region)
+        best[e["matrices_per_launch"]] = e
+    table["entries"] = keep + [best[k] for k in sorted(best)]
+    table["note"] = "per-launch HBM traffic of the dominant kernel from rocprofv3 PMC passes; written by tools/pmc_driver_summarize.py, read by bench.py"
+    json.dump(table, open(args.update, "w"), indent=1)
