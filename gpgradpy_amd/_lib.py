@@ -19,7 +19,8 @@ PROF_NCAT = len(PROF_CATS)
 ABI_SYMBOLS = (
     "gpg_create", "gpg_destroy", "gpg_last_error", "gpg_set_grad_mask", "gpg_set_data", "gpg_lkd", "gpg_lkd_grad", "gpg_lkd_batch", "gpg_lkd_grad_batch",
     "gpg_setup_eval", "gpg_predict", "gpg_predict_grad", "gpg_predict_var", "gpg_predict_hess", "gpg_get_matrix", "gpg_kern_rtensor", "gpg_factor_apply", "gpg_dcov_quadform", "gpg_prof_enable", "gpg_prof_read", "gpg_set_panel", "gpg_set_lookahead", "gpg_set_factor_mode", "gpg_factor_fallbacks", "gpg_last_factor", "gpg_set_batch", "gpg_reserve_batch",
-    "gpg_device_info",
+    "gpg_device_info", "gpg_multi_create", "gpg_multi_destroy", "gpg_multi_last_error", "gpg_multi_count", "gpg_multi_set_data",
+    "gpg_multi_lkd_batch",
 )
 
 
@@ -107,6 +108,18 @@ def load():
     lib.gpg_factor_fallbacks.restype = C.c_int
     lib.gpg_last_factor.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     lib.gpg_last_factor.restype = C.c_int
+    lib.gpg_multi_create.argtypes = [C.POINTER(vp), C.c_int, ip, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.gpg_multi_create.restype = C.c_int
+    lib.gpg_multi_destroy.argtypes = [vp]
+    lib.gpg_multi_destroy.restype = None
+    lib.gpg_multi_last_error.argtypes = [vp]
+    lib.gpg_multi_last_error.restype = C.c_char_p
+    lib.gpg_multi_count.argtypes = [vp]
+    lib.gpg_multi_count.restype = C.c_int
+    lib.gpg_multi_set_data.argtypes = [vp, dp, dp, dp]
+    lib.gpg_multi_set_data.restype = C.c_int
+    lib.gpg_multi_lkd_batch.argtypes = [vp, C.c_int, dp, C.c_int, C.c_double, C.c_int, C.c_int, C.POINTER(GpgLkdOut), ip]
+    lib.gpg_multi_lkd_batch.restype = C.c_int
     lib.gpg_device_info.argtypes = [C.c_int, C.c_char_p, C.c_int]
     lib.gpg_device_info.restype = C.c_int
     _lib = lib

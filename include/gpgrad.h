@@ -118,6 +118,23 @@ int gpg_lkd_batch(gpg_ctx* ctx, int m, const double* hp_rows, int row_len, doubl
 int gpg_lkd_grad_batch(gpg_ctx* ctx, int m, const double* hp_rows, int row_len, double eta, int wellcond,
                        int closed_form_varK, gpg_lkd_out* out, double* g_aa, double* g_inv);
 
+/* Several devices, one process -------------------------------------------------------------------- */
+
+/* The restart table of GpHparaX0.select_hp_optz_x0 (GpHparaX0.py:33-59) sharded over the devices of ONE process: one
+ * context per listed device (devices == NULL: 0 .. ndev-1; a device may be listed more than once), one host thread per
+ * context, contiguous row blocks (rows differ by at most one between devices), the results gathered in `out` [m] and
+ * the row of the highest ln_lkd among the successfully factorised ones in *best (-1 if none; may be NULL).  The data
+ * set is replicated by gpg_multi_set_data.  This is the in-library form of the partition DESIGN.md section 5 runs with
+ * one process per GPU over torch.distributed / RCCL. */
+typedef struct gpg_multi gpg_multi;
+int gpg_multi_create(gpg_multi** out, int ndev, const int* devices, int n_eval, int dim, int use_grad, int kernel);
+void gpg_multi_destroy(gpg_multi* m);
+const char* gpg_multi_last_error(const gpg_multi* m); /* m may be NULL: error of the last failed create */
+int gpg_multi_count(const gpg_multi* m);
+int gpg_multi_set_data(gpg_multi* m, const double* x, const double* data_vec, const double* noise_var);
+int gpg_multi_lkd_batch(gpg_multi* m, int nrows, const double* hp_rows, int row_len, double eta, int wellcond,
+                        int closed_form_varK, gpg_lkd_out* out, int* best);
+
 /* Posterior -------------------------------------------------------------------------------------- */
 
 /* Replaces GpEvalModel.setup_eval_model (GpEvalModel.py:17-57): factorises the matrix for hp (the

@@ -111,3 +111,40 @@ def test_bench_refuses_more_ranks_than_gpus_under_nccl():
                         "--config", "cfg2", "--steps", "2", "--warmup", "0", "--no-cpu-baseline"], capture_output=True,
                        text=True, env=env, timeout=300)
     assert r.returncode != 0 and "LOCAL_RANK" in r.stderr
+
+
+def test_multi_device_driver_in_one_process():
+    """gpg_multi_*: the restart table sharded over the devices of ONE process, below Python.  A test box has
+    one GPU, so the device list names it twice: two contexts factorise their halves of the reference's 64-row table
+    CONCURRENTLY on one device (which the ticket-scheduled dataflow launches allow) and must reproduce the reference's
+    table and its argmax."""
+    import ctypes as C
+    import gpgradpy_amd
+    from gpgradpy_amd import _lib
+    lib = _lib.load()
+    z = np.load(os.path.join(GOLDEN_DIR, "multistart_SqExp_n64_d4.npz"))
+    n, d = z["x"].shape
+    GP = gpgradpy_amd.GaussianProcess(d, True, "SqExp", "precon")          # host side only: row decoding and the nugget
+    GP.set_data(z["x"], z["f"], np.zeros(n), z["g"], np.zeros((n, d)))
+    rows = np.ascontiguousarray(GP._rows_from_hp_x0(z["hp_x0"]))
+    y = np.ascontiguousarray(GP.make_data_vec(z["f"], z["g"]))
+    x = np.ascontiguousarray(z["x"])
+    for devices in ([0], [0, 0], [0, 0, 0]):
+        m = C.c_void_p()
+        devs = (C.c_int * len(devices))(*devices)
+        rc = lib.gpg_multi_create(C.byref(m), len(devices), devs, n, d, 1, 0)
+        assert rc == 0, lib.gpg_multi_last_error(None)
+        try:
+            assert lib.gpg_multi_count(m) == len(devices)
+            assert lib.gpg_multi_set_data(m, _lib.as_dp(x), _lib.as_dp(y), None) == 0
+            outs = (_lib.GpgLkdOut * len(rows))()
+            best = C.c_int(-2)
+            rc = lib.gpg_multi_lkd_batch(m, len(rows), _lib.as_dp(rows), rows.shape[1], float(GP._etaK), 1, 1, outs, C.byref(best))
+            assert rc == 0, lib.gpg_multi_last_error(m)
+            ln = np.array([o.ln_lkd for o in outs])
+            np.testing.assert_allclose(ln, z["ln_lkd_all"], rtol=1e-8)
+            assert best.value == int(z["idx_max"])
+        finally:
+            lib.gpg_multi_destroy(m)
+    bad = C.c_void_p()
+    assert lib.gpg_multi_create(C.byref(bad), 1, (C.c_int * 1)(99), n, d, 1, 0) != 0 and b"device" in lib.gpg_multi_last_error(None)

@@ -53,6 +53,7 @@ if cfg == 'cfg2' or '--optz' in sys.argv:
         t0 = time.perf_counter()
         GPo.set_hpara('optz', 0)
         out[f'set_hpara_optz_lhs5_s_{mode}'] = time.perf_counter() - t0
+        out[f'device_call_s_{mode}'] = float(GPo.time_chofac_all[0])
         out[f'optz_iter_mean_{mode}'] = float(GPo.hp_optz_iter_mean[0])
         out[f'ln_lkd_best_{mode}'] = float(-np.nanmin(GPo.optz_obj_all_last))
         if lock:

@@ -68,16 +68,16 @@ int main(int argc, char** argv) {
   {
     std::vector<unsigned long long> hb(GPG_STAMP_MAX * 16);
     hipMemcpy(hb.data(), dbuf, hb.size() * 8, hipMemcpyDeviceToHost);
-    FILE* f = fopen("../gpurun_out/tile_timeline.csv", "w");
+    FILE* f = fopen(argc > 4 ? argv[4] : "../gpurun_out/tile_timeline.csv", "w");
     if (f) {
-      fprintf(f, "block,ti,tj,start,end,spin_cyc,gemm_cyc,runs,fin0,f0,f1,f2,f3,f4\n");
+      fprintf(f, "block,ti,tj,start,end,spin_cyc,gemm_cyc,runs,fin0,f0,f1,f2,f3,f4,wg\n");
       unsigned long long t0 = ~0ull;
       for (int b = 0; b < GPG_STAMP_MAX; ++b) if (hb[b * 8 + 1] && hb[b * 8] < t0) t0 = hb[b * 8];
       for (int b = 0; b < GPG_STAMP_MAX; ++b) {
         const unsigned long long* o = &hb[(size_t)b * 8];
         if (o[1] == 0) continue;
         const unsigned long long* g = &hb[(size_t)GPG_STAMP_MAX * 8 + (size_t)b * 8];
-        fprintf(f, "%d,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu\n", b, o[6] & 0xffff, o[6] >> 16, o[0] - t0, o[1] - t0, o[2], o[3], o[4], o[5] - t0, g[0] - t0, g[1] - t0, g[2] - t0, g[3] - t0, g[4] ? g[4] - t0 : 0ull);
+        fprintf(f, "%d,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu\n", b, o[6] & 0xffff, o[6] >> 16, o[0] - t0, o[1] - t0, o[2], o[3], o[4], o[5] - t0, g[0] - t0, g[1] - t0, g[2] - t0, g[3] - t0, g[4] ? g[4] - t0 : 0ull, o[7]);
       }
       fclose(f);
     }
