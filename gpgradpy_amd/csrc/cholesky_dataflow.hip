@@ -42,6 +42,15 @@ __device__ __forceinline__ int next_ticket(int* ticket, int* sh, int round) {
 #else
 #define GPG_PRIO(n)
 #endif
+// Priority by distance from the diagonal, dd = i - j of the tile: the head of a tile column (diagonal tile, the next few
+// rows) is what the following columns' heads wait for.  Timelines (tools/timeline_compare.py) show tile (j+1, j) finishing
+// 12 us after diag(j) with one-task workgroups (where the older = earlier task wins the arbitration) but 124 us after it
+// with persistent ones at equal priorities.
+#ifndef GPG_PRIO_NEAR
+#define GPG_PRIO_NEAR 3
+#endif
+#define GPG_PRIO_ACC(dd) { if ((dd) == 0) { GPG_PRIO(2); } else if ((dd) <= GPG_PRIO_NEAR) { GPG_PRIO(1); } }
+#define GPG_PRIO_FIN(dd) { if ((dd) <= GPG_PRIO_NEAR) { GPG_PRIO(3); } else { GPG_PRIO(2); } }
 
 // Ticket of the NEXT task, fetched by the publish step of the current one (GPG_PUBLISH_AND_NEXT): the fetch-add travels
 // with the drain of the tile's write-through stores, so a workgroup that finishes a task knows its next one without a
@@ -150,7 +159,7 @@ tile_chol_task(int tix, double* A, int ld, int c0, int Mt, const int* __restrict
   }
 
   // ---- (1) left-looking accumulation over the finished tile columns ------------------------------------------
-  if (ti == tj) GPG_PRIO(1);
+  GPG_PRIO_ACC(ti - tj)
   int kdone = 0;
   while (kdone < tj) {
     if (tid == 0) {
@@ -183,7 +192,7 @@ tile_chol_task(int tix, double* A, int ld, int c0, int Mt, const int* __restrict
   }
 
   // ---- (2) accumulators -> LDS tile Ts[col][row] --------------------------------------------------------------
-  if (ti == tj) { GPG_PRIO(3); } else { GPG_PRIO(2); }
+  GPG_PRIO_FIN(ti - tj)
   {
     double* Ts = U;
 #pragma unroll
@@ -482,7 +491,7 @@ tile128_chol_task(int tix, double* A, int ld, int Mt, const int* __restrict__ ta
       }
 
   // ---- (1) left-looking accumulation ----------------------------------------------------------------------------
-  if (ti == tj) GPG_PRIO(1);
+  GPG_PRIO_ACC(ti - tj)
   int kdone = 0;
   while (kdone < tj) {
     GPG_TR(q0)
@@ -523,7 +532,7 @@ tile128_chol_task(int tix, double* A, int ld, int Mt, const int* __restrict__ ta
 #ifdef GPG_STAMP
   const unsigned long long tk_fin0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  if (ti == tj) { GPG_PRIO(3); } else { GPG_PRIO(2); }
+  GPG_PRIO_FIN(ti - tj)
   // ---- (2) the updated tile goes back to memory; the finalisation works on it in place.  Diagonal tile: the
   //      top-left 64 x 64 block goes straight into the LDS tile its own wave factors next, the strictly upper
   //      block is dropped. ---------------------------------------------------------------------------------------

@@ -6,6 +6,13 @@ import numpy as np
 def load(path):
     rows = list(csv.DictReader(open(path)))
     d = {k: np.array([float(r[k]) for r in rows]) for k in rows[0]}
+    # the CSV holds raw 100 MHz stamps when junk records (panel-solve cycle counters that share the buffer) spoil the
+    # writer's time origin: keep the records that are task records and re-base them
+    ok = (d['start'] > 1e9) & (d['end'] > d['start']) & (d['fin0'] >= d['start']) & (d['fin0'] <= d['end'])
+    d = {k: v[ok] for k, v in d.items()}
+    t0 = d['start'].min()
+    for k in ('start', 'end', 'fin0'):
+        d[k] = d[k] - t0
     return d
 
 for path in sys.argv[1:]:
