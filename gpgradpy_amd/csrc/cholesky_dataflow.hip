@@ -868,6 +868,130 @@ rows_fwd_kernel(const double* __restrict__ A, int ld, const double* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// tile64_trinv_kernel: W = L^-T with 64 x 64 tiles, for small matrices (the 128-tile version's dependency chain -- one
+// 128-row substitution per tile column -- is what a 2560-column inverse spends its time on).  Task (rt, tj), rt <= tj (row
+// tile rt, column tile tj of the upper triangular W, which starts as the identity; list order: tile column by tile
+// column): acc = W_(rt,tj) - sum_{k=rt}^{tj-1} W_(rt,k) L_(tj,k)^T on MFMA as the tiles of W's row rt are published, then the
+// quad-row substitution against L_(tj,tj): the body of rows_fwd_kernel restricted to the non-zero tiles, batched.
+// ------------------------------------------------------------------------------------------------
+struct Trinv64Args {
+  const double* A; int ld; const double* dinv; double* W; int ldw, Mt; const int* tasks; int ntask; int* flags; int* abort_word;
+  int* ticket; int* info; const int* batch_of; size_t a_stride, w_stride; int d_stride, f_stride;
+};
+
+__device__ __forceinline__ bool
+tile64_trinv_task(int tix, const double* __restrict__ A, int ld, const double* __restrict__ dinv, double* W, int ldw, int Mt,
+                  const int* __restrict__ tasks, int* flags, int* abort_word, int* ticket, int* info,
+                  const int* __restrict__ batch_of, size_t a_stride, size_t w_stride, int d_stride, int f_stride) {
+  constexpr int KB = 16, SA = 80, BUF = KB * SA;
+  __shared__ __attribute__((aligned(16))) double U[4 * BUF];
+  __shared__ __attribute__((aligned(16))) double Ls[64][4][18];
+  __shared__ double sdinv[64];
+  __shared__ int sh_kr;
+  double* const sA = U;
+  double* const sB = U + 2 * BUF;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int task = tasks[tix];
+  const int rt = task & 0xffff, tj = task >> 16;
+  if (batch_of) {
+    const int b = batch_of[tix];
+    A += (size_t)b * a_stride;
+    dinv += (size_t)b * d_stride;
+    W += (size_t)b * w_stride;
+    flags += (size_t)b * f_stride;
+    info += b;
+  }
+  const size_t r0 = 64 * (size_t)rt, cj = 64 * (size_t)tj;
+  const int q = tid & 3;
+  const int sp = tid & 31, sk = tid >> 5;
+  int* const frow = flags + (size_t)rt * Mt;
+
+  d4 acc[4];
+  {
+    const double* Cw = W + r0 + 16 * w + l15 + (cj + l4) * (size_t)ldw;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[ni][r] = Cw[(size_t)(ni * 16 + 4 * r) * ldw];
+  }
+  {   // L_jj is final: its image is fetched before the first wait
+    const double* Ljj = A + cj + cj * (size_t)ld;
+    for (int t = tid; t < 64 * 64; t += 256) {
+      const int jj = t >> 6, k = t & 63;
+      Ls[jj][k & 3][k >> 2] = Ljj[k + (size_t)jj * ld];
+    }
+    if (tid < 64) sdinv[tid] = dinv[cj + tid];
+  }
+  int kdone = rt;
+  while (kdone < tj) {
+    if (tid == 0) {
+      int kr = kdone;
+      const unsigned long long t_wait = __builtin_amdgcn_s_memrealtime();
+      for (;;) {
+        while (kr < tj && __hip_atomic_load(frow + kr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ++kr;
+        if (kr > kdone) break;
+        if (__builtin_amdgcn_s_memrealtime() - t_wait > GPG_TILE_WAIT_TICKS ||
+            __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+          __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          atomicMax(info, GPG_INFO_INTERNAL);
+          kr = -1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      sh_kr = kr;
+    }
+    __syncthreads();
+    const int kr = sh_kr;
+    if (kr < 0) return false;
+    GPG_ACQUIRE();
+    const size_t ck = 64 * (size_t)kdone;
+    wave_tile_gemm(acc, W + r0 + 2 * sp + (ck + sk) * (size_t)ldw, ldw, A + cj + 2 * sp + (ck + sk) * (size_t)ld, ld,
+                   4 * (kr - kdone), sA, sB, w, l15, l4, sp, sk);
+    __syncthreads();
+    kdone = kr;
+  }
+  GPG_PRIO(2);
+  {
+    double* Ts = U;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Ts[(ni * 16 + 4 * r + l4) * SA + 16 * w + l15] = acc[ni][r];
+  }
+  __syncthreads();
+  double x[16];
+  {
+    const double* Tr = U + q * SA + (tid >> 2);
+#pragma unroll
+    for (int m = 0; m < 16; ++m) x[m] = Tr[(4 * m) * SA];
+  }
+  GPG_QUAD_SUBST(x, Ls, sdinv, q)
+  double* Xr = W + r0 + (tid >> 2) + (cj + q) * (size_t)ldw;
+#pragma unroll
+  for (int m = 0; m < 16; ++m) GPG_ST(&Xr[(size_t)(4 * m) * ldw], x[m]);
+  GPG_PUBLISH_AND_NEXT(ticket, frow + tj)
+  return true;
+}
+
+__global__ void __launch_bounds__(256, 2) tile64_trinv_kernel(Trinv64Args) {
+  int tix;
+  {
+    GPG_KERNARGS(Trinv64Args, ap);
+    tix = next_ticket(ap->ticket, &g_next_ticket, 0);
+  }
+  for (;;) {
+    GPG_KERNARGS(Trinv64Args, ap);
+    if (tix >= ap->ntask) return;
+    if (!tile64_trinv_task(tix, ap->A, ap->ld, ap->dinv, ap->W, ap->ldw, ap->Mt, ap->tasks, ap->flags, ap->abort_word, ap->ticket,
+                           ap->info, ap->batch_of, ap->a_stride, ap->w_stride, ap->d_stride, ap->f_stride))
+      return;
+    tix = g_next_ticket;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // rows_bwd_kernel: Z <- Z L^-1 (every row solved against L^T) for right-hand-side rows in the rows layout, ONE
 // dataflow launch, column blocks from the last to the first: workgroup (rt, j) accumulates
 // Z_j - sum_{k>j} Z_k L_kj on MFMA (L_kj used untransposed: k-major staging) as the Z_k of its row tile are
@@ -1258,11 +1382,15 @@ static bool launch_tile128_inverse_batch(gpg_ctx* c, int B, const double* Abase,
   const int Mt = c->Npad / 128, ldw = c->Npad;
   if (Mt < 1 || Mt > 0xffff || B < 1) return false;
   const size_t w_stride = (size_t)ldw * c->Npad;
-  const unsigned long long key = (3ull << 61) | ((unsigned long long)B << 40) | (unsigned long long)Mt;
+  // small matrices: W = L^-T with 64 x 64 tiles (half the substitution chain per tile column); -(W W^T) stays on 128-tiles
+  const bool small = c->inv_tile64_cols > 0 && c->Npad <= c->inv_tile64_cols;
+  const int Mt64 = c->Npad / 64;
+  const unsigned long long key = (3ull << 61) | ((unsigned long long)(small ? 1 : 0) << 60) | ((unsigned long long)B << 40) | (unsigned long long)Mt;
   auto it = c->tilemaps.find(key);
   if (it == c->tilemaps.end()) {
     std::vector<int> list, bof;
-    for (int i = 0; i < Mt; ++i)                    // W tiles (j, i): tile column by tile column, longest accumulation first
+    const int Mw = small ? Mt64 : Mt;
+    for (int i = 0; i < Mw; ++i)                    // W tiles (j, i): tile column by tile column, longest accumulation first
       for (int b = 0; b < B; ++b)
         for (int j = 0; j <= i; ++j) { list.push_back(j | (i << 16)); bof.push_back(b); }
     const size_t n1 = list.size();
@@ -1271,27 +1399,34 @@ static bool launch_tile128_inverse_batch(gpg_ctx* c, int B, const double* Abase,
         for (int bb = 0; bb <= a; ++bb) { list.push_back(a | (bb << 16)); bof.push_back(b); }
     TileMap tm;
     tm.n = (int)n1;
-    if (!gpg_dev_alloc(c, &tm.dev, sizeof(int) * 2 * list.size())) return false;
+    if (!gpg_dev_alloc(c, &tm.dev, sizeof(int) * 2 * list.size())) return false;       // [tasks W | tasks M | matrix of W task | matrix of M task]
     (void)hipMemcpy(tm.dev, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice);
     (void)hipMemcpy(tm.dev + list.size(), bof.data(), sizeof(int) * bof.size(), hipMemcpyHostToDevice);
     it = c->tilemaps.emplace(key, tm).first;
   }
   const TileMap& tm = it->second;
+  const int n2 = B * (Mt * (Mt + 1) / 2);           // tiles of -(W W^T), always 128 x 128
   const int* tasks1 = tm.dev;
   const int* tasks2 = tm.dev + tm.n;
-  const int* bof1 = tm.dev + 2 * (size_t)tm.n;
+  const int* bof1 = tm.dev + (size_t)tm.n + n2;
   const int* bof2 = bof1 + tm.n;
-  const size_t per = (size_t)Mt * Mt, nflag = per * B + 16;   // W tile flags per matrix | 9 ones | abort | ticket (trinv) | ticket (wwt)
+  const size_t per = small ? (size_t)Mt64 * Mt64 : (size_t)Mt * Mt;
+  const size_t nflag = per * B + 16;                // W tile flags per matrix | 9 ones | abort | ticket (trinv) | ticket (wwt)
   if (!ensure_tile_flags(c, nflag)) return false;
   int* ones = c->tile_flags + per * B;
   (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
   (void)hipMemsetD32Async((hipDeviceptr_t)ones, 1, 9, c->stream);
   for (int b = 0; b < B; ++b) gpg_launch_identity(c, Wbase + (size_t)b * w_stride, ldw);
-  hipLaunchKernelGGL(tile128_trinv_kernel, dim3(persistent_grid(c, tile128_trinv_kernel, tm.n)), dim3(256), 0, c->stream,
-                     TrinvArgs{Abase, c->ld, dinv_base, Wbase, ldw, Mt, tasks1, tm.n, c->tile_flags, ones, ones + 9, ones + 10, info_base,
-                               B > 1 ? bof1 : nullptr, a_stride, w_stride, d_stride, (int)per});
-  hipLaunchKernelGGL(tile128_wwt_kernel, dim3(persistent_grid(c, tile128_wwt_kernel, tm.n)), dim3(256), 0, c->stream,
-                     (const double*)Wbase, ldw, Mbase, ldw, Mt, tasks2, tm.n, ones + 11, B > 1 ? bof2 : (const int*)nullptr, w_stride);
+  if (small)
+    hipLaunchKernelGGL(tile64_trinv_kernel, dim3(persistent_grid(c, tile64_trinv_kernel, tm.n)), dim3(256), 0, c->stream,
+                       Trinv64Args{Abase, c->ld, dinv_base, Wbase, ldw, Mt64, tasks1, tm.n, c->tile_flags, ones + 9, ones + 10, info_base,
+                                   B > 1 ? bof1 : nullptr, a_stride, w_stride, d_stride, (int)per});
+  else
+    hipLaunchKernelGGL(tile128_trinv_kernel, dim3(persistent_grid(c, tile128_trinv_kernel, tm.n)), dim3(256), 0, c->stream,
+                       TrinvArgs{Abase, c->ld, dinv_base, Wbase, ldw, Mt, tasks1, tm.n, c->tile_flags, ones, ones + 9, ones + 10, info_base,
+                                 B > 1 ? bof1 : nullptr, a_stride, w_stride, d_stride, (int)per});
+  hipLaunchKernelGGL(tile128_wwt_kernel, dim3(persistent_grid(c, tile128_wwt_kernel, n2)), dim3(256), 0, c->stream,
+                     (const double*)Wbase, ldw, Mbase, ldw, Mt, tasks2, n2, ones + 11, B > 1 ? bof2 : (const int*)nullptr, w_stride);
   return true;
 }
 
