@@ -557,17 +557,27 @@ __device__ __forceinline__ int wg_wait_flag(int* flag, int* abort_word, int* inf
 // operand blocks: 4 load instructions per k-step instead of 8 (the texture-address unit handles ~4 lanes per
 // clock whatever the access width; measured +1.5 %).  acc[2p + e][2g + m][r] of lane (t, l4) <-> tile row 32 g + 2 t + m, tile column
 // 32 p + 2 (4 r + l4) + e.  pa / pb: slice + 2 t, k = l4.
+typedef double gpg_d2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 gpg_nt_load2(const double* p) {
+  const gpg_d2v v = __builtin_nontemporal_load(reinterpret_cast<const gpg_d2v*>(p));
+  double2 r; r.x = v.x; r.y = v.y; return r;
+}
 template <int PF>
 __device__ __forceinline__ void direct_tile_gemm_x2(d4 (&acc)[4][4], const double* pa, int lda, const double* pb, int ldb,
                                                     int nstep) {
   const size_t sa = (size_t)4 * lda, sb = (size_t)4 * ldb;
   double2 fa0[PF + 1], fa1[PF + 1], fb0[PF + 1], fb1[PF + 1];
+#ifdef GPG_NT_LOADS   // A/B builds: non-temporal hint on the operand stream
+#define GPG_DX_LD(p) gpg_nt_load2(p)
+#else
+#define GPG_DX_LD(p) (*reinterpret_cast<const double2*>(p))
+#endif
 #define GPG_DX_LOAD(set)                                                              \
   {                                                                                   \
-    fa0[set] = *reinterpret_cast<const double2*>(pa);                                 \
-    fa1[set] = *reinterpret_cast<const double2*>(pa + 32);                            \
-    fb0[set] = *reinterpret_cast<const double2*>(pb);                                 \
-    fb1[set] = *reinterpret_cast<const double2*>(pb + 32);                            \
+    fa0[set] = GPG_DX_LD(pa);                                                         \
+    fa1[set] = GPG_DX_LD(pa + 32);                                                    \
+    fb0[set] = GPG_DX_LD(pb);                                                         \
+    fb1[set] = GPG_DX_LD(pb + 32);                                                    \
     pa += sa;                                                                         \
     pb += sb;                                                                         \
   }
@@ -591,6 +601,7 @@ __device__ __forceinline__ void direct_tile_gemm_x2(d4 (&acc)[4][4], const doubl
     }
   }
 #undef GPG_DX_LOAD
+#undef GPG_DX_LD
 #undef GPG_DX_MFMA
 }
 
