@@ -376,3 +376,25 @@ def test_lockstep_multistart_equals_sequential():
     np.testing.assert_allclose(res[True][1], res[False][1], rtol=1e-9)
     np.testing.assert_allclose(res[True][0], res[False][0], rtol=1e-6, atol=1e-8)
     np.testing.assert_allclose(res[True][2], res[False][2], rtol=1e-6)
+
+
+@pytest.mark.parametrize("n,d", [(455, 8), (470, 8), (130, 3)])
+def test_dataflow_inverse_against_blocked_inverse(n, d):
+    """The explicit inverse behind the adjoint gradient exists three times: W = L^-T on 64 x 64 tiles (up to 4096 padded
+    columns: N = 4095 here), on 128 x 128 tiles (N = 4230), and the blocked sweeps of the 'blocked' factor mode.  Independent
+    kernels, same gradient."""
+    import gpgradpy_amd
+    from oracle import gp_oracle as orc
+    X, f, g = orc.synthetic_design(n, d, seed=n)
+    theta = 10.0 ** np.random.default_rng(n).uniform(-2.0, -0.7, d)
+    out = {}
+    for mode in ("auto", "blocked"):
+        GP = gpgradpy_amd.GaussianProcess(d, True, "SqExp", "precon")
+        GP.set_data(X, f, np.zeros(n), g, np.zeros((n, d)))
+        GP.set_factor_mode(mode)
+        info, ok = GP.calc_lkd_all(GP.make_hp_class(theta=theta), calc_grad=True)
+        assert ok
+        out[mode] = (info.ln_lkd, info.ln_lkd_grad)
+    assert abs(out["auto"][0] - out["blocked"][0]) <= 1e-9 * abs(out["blocked"][0])
+    # both contract with an explicitly formed inverse of a matrix with cond up to 1e10: agreement to cond * eps of the largest component
+    np.testing.assert_allclose(out["auto"][1], out["blocked"][1], rtol=1e-5, atol=1e-5 * np.abs(out["blocked"][1]).max())
