@@ -365,6 +365,10 @@ class HparaOptz:
             nlc = NonlinearConstraint(self.return_cond_val, -np.inf, self.cond_max, jac=self.return_cond_grad)
         err = None
         lockstep = self.optz_lockstep and not self.b_use_cond_cstr and (hi - lo) > 1 and self.optz_mtd == 'SLSQP'
+        cls = type(self)
+        if lockstep and (cls.return_optz_val is not HparaOptz.return_optz_val or cls.return_optz_grad is not HparaOptz.return_optz_grad) \
+                and cls._objective_rows is HparaOptz._objective_rows:
+            lockstep = False          # a subclass replaced the one-row objective only: keep calling that one
         if lockstep:
             err = self._run_starts_lockstep(hp_x0_all, lo, hi, optz_bound, optz_opt, optz_sol_all, optz_obj_all, all_optz_success,
                                             all_total_fun_iter)
