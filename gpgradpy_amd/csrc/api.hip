@@ -225,7 +225,7 @@ void gpg_destroy(gpg_ctx* c) {
                     c->ws[1].A, c->ws[1].dvec, c->ws[1].invp, c->ws[1].zvec, c->ws[1].tmpv, c->ws[1].dinv,
                     c->Xt, c->y, c->noise, c->scal, c->Wt, c->xq_dev,
                     c->musig, c->gradbuf, c->dense_tmp, c->Wfull, c->Minv, c->gpartial, c->batchA, c->batchV, c->vec_rows, c->vec_x, c->apply_buf,
-                    c->batchW, c->batchM, c->batchZ, c->gres};
+                    c->batchW, c->batchM, c->batchZ, c->gres, c->Kbuf, c->Tbuf};
   for (double* b : bufs) if (b) (void)hipFree(b);
   if (c->info) (void)hipFree(c->info);
   if (c->gpos) (void)hipFree(c->gpos);
@@ -262,6 +262,7 @@ int gpg_set_grad_mask(gpg_ctx* c, const unsigned char* use_grad_pt) {
   if (c->dense_tmp) { (void)hipFree(c->dense_tmp); c->dense_tmp = nullptr; }
   if (c->batchA) { (void)hipFree(c->batchA); (void)hipFree(c->batchV); c->batchA = c->batchV = nullptr; c->batch_cap = 0; }
   if (c->Wfull) { (void)hipFree(c->Wfull); (void)hipFree(c->Minv); c->Wfull = c->Minv = nullptr; }
+  if (c->Kbuf) { (void)hipFree(c->Kbuf); (void)hipFree(c->Tbuf); c->Kbuf = c->Tbuf = nullptr; }
   if (c->batchW) { (void)hipFree(c->batchW); (void)hipFree(c->batchM); (void)hipFree(c->batchZ); c->batchW = c->batchM = c->batchZ = nullptr; c->gbatch_cap = 0; }
   if (c->Wt) { (void)hipFree(c->Wt); (void)hipFree(c->xq_dev); (void)hipFree(c->musig); (void)hipFree(c->gradbuf); c->Wt = c->xq_dev = c->musig = c->gradbuf = nullptr; c->xq_cap = 0; }
   return 0;
@@ -983,6 +984,86 @@ int gpg_dcov_quadform(gpg_ctx* c, const gpg_hp* hp, const double* v, double* out
   GPG_LAUNCH_OK(c);
   out[c->d + 3] = 0.0;
   for (int k = 0; k < ns; ++k) out[k] = h[k];
+  return 0;
+}
+
+int gpg_cond_fro(gpg_ctx* c, const gpg_hp* hp, double* cond, double* cond_grad) {
+  int rc = check_hp(c, hp);
+  if (rc) return rc;
+  if (!cond) { c->err = "cond is NULL"; return -1; }
+  if (cond_grad && hp->wellcond == GPG_WELLCOND_PRECON) {
+    c->err = "Not setup to calculate the gradient of the condition number if wellcond_mtd = \"precon\" (GpHparaCon.py:249)";
+    return -1;
+  }
+  GPG_HIP_OK(c, hipSetDevice(c->device));
+  GPG_WS(c, 0);
+  const size_t nn = (size_t)c->Npad * c->Npad;
+  if (!c->Wfull) {
+    GPG_HIP_OK(c, hipMalloc(&c->Wfull, sizeof(double) * nn));
+    GPG_HIP_OK(c, hipMalloc(&c->Minv, sizeof(double) * nn));
+  }
+  if (cond_grad && !c->Kbuf) {
+    GPG_HIP_OK(c, hipMalloc(&c->Kbuf, sizeof(double) * nn));
+    GPG_HIP_OK(c, hipMalloc(&c->Tbuf, sizeof(double) * nn));
+  }
+  const int nblk = gpg_grad_partial_blocks(c);
+  const int nval = 2 * GPG_GRAD_SLOTS_MAX;
+  if (!c->gpartial) GPG_HIP_OK(c, hipMalloc(&c->gpartial, sizeof(double) * (size_t)nval * (nblk + 1)));
+  if (!c->apply_buf) GPG_HIP_OK(c, hipMalloc(&c->apply_buf, sizeof(double) * 2 * (size_t)c->vec_rows_cols));
+  double* colsum = c->apply_buf;                       // [N] per-column partial sums of the two norms
+  double* norms = c->scal + 8;                         // scal slot 1: ||K||_F^2, ||K^-1||_F^2
+  AsmParams p = make_params(c, hp, 0);
+  c->last_precon = p.precon;
+  c->prep_valid = true;
+  c->last_factor_ws = 0;
+  GPG_HIP_OK(c, hipMemsetAsync(c->info, 0, sizeof(int), c->stream));
+  gpg_launch_prep(c, p, hp->var_fval, hp->var_fgrad, 0.0, 0.0, 0.0, 0.0);
+  gpg_launch_assembly(c, p);                           // the matrix that is factorised: Kcov_precon / Kcov (Kernel.py:240, 280)
+  gpg_launch_frob_lower(c, c->A, c->ld, colsum, norms);
+  if (cond_grad)                                       // keep K: the factorisation overwrites it (columns of ld doubles -> Npad doubles)
+    GPG_HIP_OK(c, hipMemcpy2DAsync(c->Kbuf, sizeof(double) * c->Npad, c->A, sizeof(double) * c->ld, sizeof(double) * c->Npad, c->Npad,
+                                   hipMemcpyDeviceToDevice, c->stream));
+  gpg_cholesky(c);
+  GPG_HIP_OK(c, hipMemcpyAsync(c->h_info, c->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
+  GPG_HIP_OK(c, hipGetLastError());
+  GPG_LAUNCH_OK(c);
+  if (internal_failure(c, c->h_info, 1)) return -4;
+  c->factor_valid = (c->h_info[0] == 0);
+  if (c->h_info[0] != 0) return c->h_info[0];
+  gpg_inverse_from_factor(c, c->Wfull, c->Minv);       // Minv = -(L L^T)^-1, lower
+  gpg_launch_frob_lower(c, c->Minv, c->Npad, colsum, norms + 1);
+  double h_norm[2] = {0.0, 0.0};
+  GPG_HIP_OK(c, hipMemcpyAsync(h_norm, norms, sizeof(double) * 2, hipMemcpyDeviceToHost, c->stream));
+  GPG_HIP_OK(c, hipMemcpyAsync(c->h_info, c->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
+  GPG_HIP_OK(c, hipGetLastError());
+  GPG_LAUNCH_OK(c);
+  if (solve_failure(c)) return -4;
+  const double nK = sqrt(h_norm[0]), nKi = sqrt(h_norm[1]);
+  *cond = nK * nKi;                                    // GpHparaCon.py:217-220
+  if (!cond_grad) return 0;
+  // d cond / d K = frac K - K^-3 / frac, frac = ||K^-1||_F / ||K||_F (GpHparaCon.py:232-234), contracted with d K / d hp_k.
+  // With S = -K^-1 (full):  T = -S S^T = -K^-2,  M2 = -T S^T = -K^-3 (lower).
+  gpg_launch_symmetrize(c, c->Minv, c->Npad);                                    // S
+  if (!gpg_launch_full_abt(c, c->Minv, nullptr, c->Tbuf)) { c->err = "full product launch failed"; return -2; }
+  gpg_launch_symmetrize(c, c->Tbuf, c->Npad);                                    // T
+  if (!gpg_launch_full_abt(c, c->Tbuf, c->Minv, c->Wfull)) { c->err = "full product launch failed"; return -2; }   // M2 -> Wfull (lower)
+  GPG_HIP_OK(c, hipMemsetAsync(c->zvec, 0, sizeof(double) * c->Npad, c->stream));   // the alpha-alpha^T half of the contraction is not used
+  double* res = c->gpartial + (size_t)nval * nblk;
+  const int ns = c->d + 3 + (c->kernel == GPG_KERNEL_RATQU ? 1 : 0);
+  std::vector<double> h1(2 * ns), h2(2 * ns);
+  gpg_launch_grad_contract(c, p, c->gpartial, res, c->zvec, c->Kbuf);            // g_inv = sum G_k o (K / 2)
+  GPG_HIP_OK(c, hipMemcpyAsync(h1.data(), res, sizeof(double) * 2 * ns, hipMemcpyDeviceToHost, c->stream));
+  GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
+  gpg_launch_grad_contract(c, p, c->gpartial, res, c->zvec, c->Wfull);           // g_inv = sum G_k o (-K^-3 / 2)
+  GPG_HIP_OK(c, hipMemcpyAsync(h2.data(), res, sizeof(double) * 2 * ns, hipMemcpyDeviceToHost, c->stream));
+  GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
+  GPG_HIP_OK(c, hipGetLastError());
+  GPG_LAUNCH_OK(c);
+  const double frac = nKi / nK;
+  for (int k = 0; k < c->d + 4; ++k) cond_grad[k] = 0.0;
+  for (int k = 0; k < ns; ++k) cond_grad[k] = 2.0 * frac * h1[ns + k] + (2.0 / frac) * h2[ns + k];
   return 0;
 }
 

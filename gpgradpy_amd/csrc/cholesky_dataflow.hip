@@ -718,9 +718,11 @@ __global__ void __launch_bounds__(256, 2) tile128_trinv_kernel(TrinvArgs) {
 // persistent workgroups take them from the ticket counter, longest contraction (smallest a) first.  The same
 // direct-fragment MFMA loop, accumulators start at zero.
 // ------------------------------------------------------------------------------------------------
+// Generalised for the Frobenius-norm condition number (gpg_cond_fro): M = - Sa Sb^T with two different full (symmetric) operands
+// and the contraction over ALL tile columns when full_k != 0 (Sb0 == nullptr: Sb = Sa, the W W^T case).
 __global__ void __launch_bounds__(256, 2)
 tile128_wwt_kernel(const double* __restrict__ W0, int ldw, double* __restrict__ M0, int ldm, int Mt, const int* __restrict__ tasks,
-                   int ntask, int* ticket, const int* __restrict__ batch_of, size_t w_stride) {
+                   int ntask, int* ticket, const int* __restrict__ batch_of, size_t w_stride, const double* __restrict__ Sb0, int full_k) {
   __shared__ int sh_tix;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w & 1, wn = w >> 1;
@@ -732,8 +734,9 @@ tile128_wwt_kernel(const double* __restrict__ W0, int ldw, double* __restrict__ 
     const int ta = task & 0xffff, tb = task >> 16;        // a >= b
     const size_t boff = batch_of ? (size_t)batch_of[tix] * w_stride : 0;
     const double* W = W0 + boff;
+    const double* Wb = Sb0 ? Sb0 + boff : W;
     double* M = M0 + boff;
-    const size_t r0 = 128 * (size_t)ta, c0 = 128 * (size_t)tb, ck = 128 * (size_t)ta;
+    const size_t r0 = 128 * (size_t)ta, c0 = 128 * (size_t)tb, ck = full_k ? 0 : 128 * (size_t)ta;
     d4 acc[4][4];
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
@@ -742,7 +745,7 @@ tile128_wwt_kernel(const double* __restrict__ W0, int ldw, double* __restrict__ 
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[ni][mi][r] = 0.0;
     direct_tile_gemm_x2<3>(acc, W + r0 + wm * 64 + 2 * l15 + (ck + l4) * (size_t)ldw, ldw,
-                           W + c0 + wn * 64 + 2 * l15 + (ck + l4) * (size_t)ldw, ldw, 32 * (Mt - ta));
+                           Wb + c0 + wn * 64 + 2 * l15 + (ck + l4) * (size_t)ldw, ldw, 32 * (full_k ? Mt : Mt - ta));
     double* Cw = M + r0 + wm * 64 + 2 * l15 + (c0 + wn * 64 + 2 * l4) * (size_t)ldm;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
@@ -1426,12 +1429,55 @@ static bool launch_tile128_inverse_batch(gpg_ctx* c, int B, const double* Abase,
                        TrinvArgs{Abase, c->ld, dinv_base, Wbase, ldw, Mt, tasks1, tm.n, c->tile_flags, ones, ones + 9, ones + 10, info_base,
                                  B > 1 ? bof1 : nullptr, a_stride, w_stride, d_stride, (int)per});
   hipLaunchKernelGGL(tile128_wwt_kernel, dim3(persistent_grid(c, tile128_wwt_kernel, n2)), dim3(256), 0, c->stream,
-                     (const double*)Wbase, ldw, Mbase, ldw, Mt, tasks2, n2, ones + 11, B > 1 ? bof2 : (const int*)nullptr, w_stride);
+                     (const double*)Wbase, ldw, Mbase, ldw, Mt, tasks2, n2, ones + 11, B > 1 ? bof2 : (const int*)nullptr, w_stride,
+                     (const double*)nullptr, 0);
   return true;
 }
 
 static bool launch_tile128_inverse(gpg_ctx* c, double* W, double* Minv) {
   return launch_tile128_inverse_batch(c, 1, c->A, 0, c->dinv, 0, W, Minv, c->info);
+}
+
+// ---- pieces of the Frobenius-norm condition number (gpg_cond_fro; reference GpHparaCon.py:209-236) --------------------
+// partial[c] = sum over the rows r >= c (r, c < N) of the lower triangle of M of M[r][c]^2, off-diagonal entries twice
+__global__ void __launch_bounds__(256) frob_lower_cols_kernel(const double* __restrict__ M, int ld, int N, double* __restrict__ partial) {
+  __shared__ double red[4];
+  const int c = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const double* col = M + (size_t)c * ld;
+  double s = 0.0;
+  for (int r = c + threadIdx.x; r < N; r += 256) { const double v = col[r]; s += (r == c ? 1.0 : 2.0) * (v * v); }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) red[w] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[c] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void __launch_bounds__(256) sum_fixed_order_kernel(const double* __restrict__ v, int n, double* __restrict__ out) {
+  __shared__ double red[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += v[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) red[w] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) *out = (red[0] + red[1]) + (red[2] + red[3]);
+}
+// upper triangle <- transposed lower triangle (32 x 32 tiles through LDS, coalesced both ways)
+__global__ void __launch_bounds__(256) symmetrize_kernel(double* __restrict__ M, int ld, int n) {
+  __shared__ double t[32][33];
+  const int bi = blockIdx.x, bj = blockIdx.y;            // tile (rows 32 bi.., columns 32 bj..), bi > bj strictly below; diagonal tiles in place
+  if (bi < bj) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = ty; k < 32; k += 8) {
+    const int r = 32 * bi + tx, c = 32 * bj + k;
+    t[k][tx] = (r < n && c < n) ? M[(size_t)r + (size_t)c * ld] : 0.0;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int r = 32 * bj + tx, c = 32 * bi + k;       // element (r, c) of the upper part = element (c, r) of the lower part = t[r - 32 bj][c - 32 bi]
+    if (r < n && c < n && r < c) M[(size_t)r + (size_t)c * ld] = t[tx][k];
+  }
 }
 
 // W (rows x Npad, rows a multiple of 64) <- W L^-T with the dataflow kernel; returns false if it does not apply.
@@ -1495,6 +1541,37 @@ void gpg_launch_tile128_chol(gpg_ctx* c) {
   c->last_factor_kernel = 2; c->last_factor_batch = 1;
 }
 bool gpg_launch_tile128_inverse(gpg_ctx* c, double* W, double* Minv) { return launch_tile128_inverse(c, W, Minv); }
+// out_dev[0] = squared Frobenius norm of the symmetric N x N matrix whose lower triangle sits in M (leading dimension ld)
+void gpg_launch_frob_lower(gpg_ctx* c, const double* M, int ld, double* partial, double* out_dev) {
+  hipLaunchKernelGGL(frob_lower_cols_kernel, dim3(c->N), dim3(256), 0, c->stream, M, ld, c->N, partial);
+  hipLaunchKernelGGL(sum_fixed_order_kernel, dim3(1), dim3(256), 0, c->stream, (const double*)partial, c->N, out_dev);
+}
+void gpg_launch_symmetrize(gpg_ctx* c, double* M, int ld) {
+  const int nt = (c->Npad + 31) / 32;
+  hipLaunchKernelGGL(symmetrize_kernel, dim3(nt, nt), dim3(256), 0, c->stream, M, ld, c->Npad);
+}
+// M (lower triangle, leading dimension Npad) = - Sa Sb^T for full Npad x Npad operands (leading dimension Npad)
+bool gpg_launch_full_abt(gpg_ctx* c, const double* Sa, const double* Sb, double* M) {
+  const int Mt = c->Npad / 128;
+  const unsigned long long key = (3ull << 61) | (1ull << 59) | (unsigned long long)Mt;
+  auto it = c->tilemaps.find(key);
+  if (it == c->tilemaps.end()) {
+    std::vector<int> list;
+    for (int a = 0; a < Mt; ++a)
+      for (int b = 0; b <= a; ++b) list.push_back(a | (b << 16));
+    TileMap tm;
+    tm.n = (int)list.size();
+    if (!gpg_dev_alloc(c, &tm.dev, sizeof(int) * list.size())) return false;
+    (void)hipMemcpy(tm.dev, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice);
+    it = c->tilemaps.emplace(key, tm).first;
+  }
+  const TileMap& tm = it->second;
+  if (!ensure_tile_flags(c, 16)) return false;
+  (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * 16, c->stream);
+  hipLaunchKernelGGL(tile128_wwt_kernel, dim3(persistent_grid(c, tile128_wwt_kernel, tm.n)), dim3(256), 0, c->stream, Sa, c->Npad, M,
+                     c->Npad, Mt, (const int*)tm.dev, tm.n, c->tile_flags, (const int*)nullptr, (size_t)0, Sb, 1);
+  return true;
+}
 bool gpg_launch_tile128_inverse_batch(gpg_ctx* c, int B, const double* Abase, size_t a_stride, const double* dinv_base, int d_stride,
                                       double* Wbase, double* Mbase, int* info_base) {
   return launch_tile128_inverse_batch(c, B, Abase, a_stride, dinv_base, d_stride, Wbase, Mbase, info_base);

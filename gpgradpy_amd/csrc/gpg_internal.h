@@ -111,6 +111,8 @@ struct gpg_ctx {
   double* dense_tmp = nullptr;  // [N x N] materialisation buffer (on request)
   double* Wfull = nullptr;      // [Npad x Npad] L^-T (likelihood gradient, on first use)
   double* Minv = nullptr;       // [Npad x Npad] -(L L^T)^-1, lower triangle
+  double* Kbuf = nullptr;       // [Npad x Npad] copy of the assembled matrix (gpg_cond_fro with gradient, on first use)
+  double* Tbuf = nullptr;       // [Npad x Npad] K^-2 (same)
   double* gpartial = nullptr;   // per-workgroup partial sums of the gradient contraction + 2 (d+3) results
   // pinned host staging
   double* h_scal = nullptr;
@@ -153,6 +155,9 @@ void gpg_launch_tile128_chol(gpg_ctx* c);
 bool gpg_launch_tile128_inverse(gpg_ctx* c, double* W, double* Minv);   // Minv <- -(L L^T)^-1 by two dataflow launches
 bool gpg_launch_tile128_inverse_batch(gpg_ctx* c, int B, const double* Abase, size_t a_stride, const double* dinv_base, int d_stride,
                                       double* Wbase, double* Mbase, int* info_base);   // the same for B factors at once
+void gpg_launch_frob_lower(gpg_ctx* c, const double* M, int ld, double* partial, double* out_dev);   // squared Frobenius norm (lower storage)
+void gpg_launch_symmetrize(gpg_ctx* c, double* M, int ld);                                              // upper <- lower^T
+bool gpg_launch_full_abt(gpg_ctx* c, const double* Sa, const double* Sb, double* M);                    // M (lower) = -Sa Sb^T, full operands
 bool gpg_launch_rows_fwd(gpg_ctx* c, double* W, int ldw, int rows, int valid);
 bool gpg_launch_rows_bwd(gpg_ctx* c, double* Z, int ldz, int rows, int valid);
 void gpg_launch_tile_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a_stride, double* dinv_base, int d_stride,

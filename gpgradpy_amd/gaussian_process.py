@@ -72,7 +72,7 @@ class GaussianProcess(HparaOptz):
     cond_max_target = 1e10
     cond_max = 1e10
     cond_max_abs = 1e16
-    cond_norm = 2                 # GaussianProcess.py:104 (2 or 'fro'; only 2 is on the accelerated path)
+    cond_norm = 2                 # GaussianProcess.py:104: 2 (Lanczos through the factor) or 'fro' (gpg_cond_fro)
 
     b_optz_hp_kernel = True
     b_use_data_scl = False
@@ -523,9 +523,12 @@ class GaussianProcess(HparaOptz):
         self._time_chofac += time.time() - t0
         condK = None
         if calc_cond:                                         # Kernel.py:239-245 / 279-285 (needs the factor here)
-            if self.cond_norm != 2:
-                raise NotImplementedError("only the 2-norm condition number is on the accelerated path (cond_norm = 'fro' is not)")
-            condK = self.calc_cond_device() if chofac is not None else np.nan
+            if chofac is None:
+                condK = np.nan
+            elif self.cond_norm == 2:
+                condK = self.calc_cond_device()
+            else:
+                condK = self.calc_cond_fro_device(hp)[0]
         return Kern, None, Kcov, chofac, condK, self._etaK, None
 
     # ---- likelihood ------------------------------------------------------------------------------------
@@ -536,8 +539,8 @@ class GaussianProcess(HparaOptz):
             raise NotImplementedError('likelihood gradient with a bvec_use_grad mask is not supported')
         if calc_grad and not (lkd_use_adj_mtd is None or lkd_use_adj_mtd) and not self.lkd_use_adj_mtd:
             raise NotImplementedError('only the adjoint gradient method is on the accelerated path')
-        if calc_cond and self.cond_norm != 2:
-            raise NotImplementedError("only the 2-norm condition number is on the accelerated path (cond_norm = 'fro' is not)")
+        if calc_cond and self.cond_norm not in (2, 'fro'):
+            raise Exception(f'cond_norm must be either 2 or "fro" but it is {self.cond_norm}')          # GpHparaCon.py:159
         noisy = self.b_has_noisy_data
         if noisy:
             assert hp_vals.varK is not None, f'varK is not provided and hp_vals.varK is None, hp_vals = {hp_vals}'
@@ -572,7 +575,16 @@ class GaussianProcess(HparaOptz):
                         cond_grad_fail = self._cond_grad_from_vectors(hp, cond_fail, ev[0], evec[:, -1], evec[:, 0])
             return LkdInfo(cond=cond_fail, cond_grad=cond_grad_fail), False
         cond = cond_grad = None
-        if calc_cond:
+        if calc_cond and self.cond_norm == 'fro':                    # calc_cond_fronorm_w_grad (GpHparaCon.py:209-236)
+            assert not (calc_grad and self.wellcond_mtd == 'precon'), \
+                'Not setup to calculate the gradient of the condition number if wellcond_mtd = "precon" '
+            cond, cond_grad = self.calc_cond_fro_device(hp, want_grad=calc_grad)
+            if self.wellcond_mtd == 'precon':
+                if cond > 1.1 * self.cond_max:                                   # Kernel.py:242-243
+                    print(f'*** WARNING: condK = {cond:.2e} which is greater than cond_max = {self.cond_max:.2e} ***')
+            elif cond > self.cond_max_abs:                                       # Kernel.py:282-283
+                return LkdInfo(cond=cond), False
+        elif calc_cond:
             if calc_grad and self.wellcond_mtd != 'precon':          # GpHparaCon.py:171-173: no gradient with 'precon'
                 cond, cond_grad = self.calc_cond_device(want_grad=True, hp_struct=hp)
             else:
@@ -734,8 +746,6 @@ class GaussianProcess(HparaOptz):
 
     def setup_eval_model(self, calc_cond=False):
         """GpEvalModel.py:17-57: factor kept on the device, alpha = K^-1 (y - V beta) returned to the host."""
-        if calc_cond and self.cond_norm != 2:
-            raise NotImplementedError("only the 2-norm condition number is on the accelerated path (cond_norm = 'fro' is not)")
         self._hp_vals_model_setup = copy.copy(self.hp_vals)
         hp, keep = self._make_hp(self.hp_vals, 1.0, closed_form=not self.b_has_noisy_data)   # b_normlz_w_varK=True
         beta = float(np.ravel(self.hp_vals.beta)[0])
@@ -758,7 +768,7 @@ class GaussianProcess(HparaOptz):
             self.invKernEta_fdiff = alpha
             self._eval_ready = True
             if calc_cond:                                 # GpEvalModel.py:39-41 -> Kernel.py:239-245 / 279-285
-                self.condK = self.calc_cond_device()
+                self.condK = self.calc_cond_device() if self.cond_norm == 2 else self.calc_cond_fro_device(hp)[0]
 
     def eval_model(self, x2model_in, calc_grad=False, calc_hess=False, squeeze_nx=False):
         """GpEvalModel.py:59-198: returns (mu, sig, dmudx, dsigdx, d2mudx2, d2sigdx2); the Hessians are
@@ -958,6 +968,32 @@ class GaussianProcess(HparaOptz):
             steps.append(h)
         ln = self.calc_lkd_batch(np.array(rows))
         return (ln[0::2] - ln[1::2]) / (2.0 * np.array(steps))
+
+    def calc_cond_fro_device(self, hp_struct, want_grad=False):
+        """Frobenius-norm condition number ||K||_F ||K^-1||_F of the matrix that is factorised for hp_struct -- what
+        np.linalg.cond(., 'fro') gives in Kernel.py:239-245 / 279-285 -- and, on request, its gradient in hp_info_optz_lkd
+        order (calc_cond_fronorm_w_grad, GpHparaCon.py:209-236), all on the device (gpg_cond_fro)."""
+        cond = C.c_double(0.0)
+        g_all = np.zeros(self.dim + 4) if want_grad else None
+        rc = self._lib.gpg_cond_fro(self._ctx, C.byref(hp_struct), C.byref(cond), None if g_all is None else _lib.as_dp(g_all))
+        if rc < 0:
+            raise _lib.GpgError(f'gpg_cond_fro failed ({rc}): {self._err()}')
+        if rc > 0:
+            return np.nan, None
+        if not want_grad:
+            return cond.value, None
+        hi, d = self.hp_info_optz_lkd, self.dim
+        cond_grad = np.zeros(hi.n_hp)
+        cond_grad[hi.idx_theta] = g_all[:d]
+        if hi.has_kernel:
+            cond_grad[hi.idx_kernel] = g_all[d + 3]
+        if hi.has_varK:
+            cond_grad[hi.idx_varK] = g_all[d]
+        if hi.has_var_fval:
+            cond_grad[hi.idx_var_fval] = g_all[d + 1]
+        if hi.has_var_fgrad:
+            cond_grad[hi.idx_var_fgrad] = g_all[d + 2]
+        return cond.value, cond_grad
 
     def calc_cond_device(self, want_grad=False, hp_struct=None):
         """2-norm condition number of the matrix factorised last -- Kcov_precon = varK (Kcor + eta I) for 'precon',

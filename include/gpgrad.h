@@ -212,6 +212,15 @@ int gpg_factor_apply(gpg_ctx* ctx, int op, const double* v, double* out);
  * (GpHparaCon.py:163-207), without the [n_hp, N, N] derivative tensor or a dense eigendecomposition. */
 int gpg_dcov_quadform(gpg_ctx* ctx, const gpg_hp* hp, const double* v, double* out);
 
+/* Frobenius-norm condition number of the matrix that is factorised for hp -- cond_norm = 'fro' of the reference:
+ * np.linalg.cond(Kcov_precon | Kcov, 'fro') = ||K||_F ||K^-1||_F (Kernel.py:239-245, 279-285; calc_cond_fronorm_w_grad,
+ * GpHparaCon.py:209-236) -- and, when cond_grad != NULL (dim + 4 slots as gpg_lkd_grad; wellcond 'base' only, as in the
+ * reference), its gradient sum_{r,c} (frac K - K^-3 / frac)[r,c] (d K / d hp_k)[r,c], frac = ||K^-1||_F / ||K||_F.
+ * Everything stays on the device: the norms are reductions over the assembled matrix and over the explicit inverse of
+ * the adjoint-gradient path, K^-2 and K^-3 are two full MFMA products, the contraction recomputes d K / d hp_k on the fly.
+ * Returns > 0 (first non-positive pivot) when the Cholesky fails. */
+int gpg_cond_fro(gpg_ctx* ctx, const gpg_hp* hp, double* cond, double* cond_grad);
+
 /* Instrumentation (replaces the wall-clock accumulator _time_chofac, Kernel.py:247,304-305) ------- */
 
 enum {

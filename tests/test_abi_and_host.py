@@ -119,9 +119,9 @@ def test_out_of_scope_features_raise():
         gpgradpy_amd.GaussianProcess(2, True, 'SqExp', 'req_vmin')      # rejected like GaussianProcess.py:194
     GP = _gp_host_only(2, 'SqExp', 4, 'none')
     hp = GP.make_hp_class(theta=np.array([0.5, 0.5]))
-    GP.cond_norm = 'fro'
-    with pytest.raises(NotImplementedError):
-        GP.calc_lkd_all(hp, calc_cond=True, calc_grad=True)            # Frobenius-norm condition number and its gradient
+    GP.cond_norm = 'one'
+    with pytest.raises(Exception, match='cond_norm must be either 2 or "fro"'):
+        GP.calc_lkd_all(hp, calc_cond=True)                            # GpHparaCon.py:159
 
 
 def test_data_vec_layout():

@@ -160,11 +160,10 @@ def test_setup_eval_model_with_cond():
     fac = orc.calc_all_K_w_chofac(c["x"], c["theta"], "Ma5f2", True, "precon", c["etaK"], nv, varK=1.0)   # b_normlz_w_varK: varK := 1
     want = np.linalg.cond(fac.Kcov / np.outer(fac.pvec, fac.pvec))     # Kcov_precon = P^-1 Kcov P^-1 (Kernel.py:236,240)
     np.testing.assert_allclose(GP.condK, want, rtol=1e-6)
-    GP.cond_norm = "fro"
-    with pytest.raises(NotImplementedError):
-        GP.setup_eval_model(calc_cond=True)
-    with pytest.raises(NotImplementedError):
-        GP.calc_lkd_all(hp, calc_cond=True)                          # silently returning the 2-norm would be wrong
+    GP.cond_norm = "fro"                                             # np.linalg.cond(Kcov_precon, 'fro'), Kernel.py:240
+    GP.setup_eval_model(calc_cond=True)
+    Kp = fac.Kcov / np.outer(fac.pvec, fac.pvec)
+    np.testing.assert_allclose(GP.condK, np.linalg.norm(Kp, "fro") * np.linalg.norm(np.linalg.inv(Kp), "fro"), rtol=1e-8)
 
 
 EVAR = ["evar_SqExp_none_n20_d3", "evar_Ma5f2_known_n25_d2", "evar_RatQu_none_n30_d2_nograd"]
@@ -398,3 +397,33 @@ def test_dataflow_inverse_against_blocked_inverse(n, d):
     assert abs(out["auto"][0] - out["blocked"][0]) <= 1e-9 * abs(out["blocked"][0])
     # both contract with an explicitly formed inverse of a matrix with cond up to 1e10: agreement to cond * eps of the largest component
     np.testing.assert_allclose(out["auto"][1], out["blocked"][1], rtol=1e-5, atol=1e-5 * np.abs(out["blocked"][1]).max())
+
+
+_FRO = np.load(os.path.join(GOLDEN_DIR, "cond_fro_table.npz"))
+
+
+@pytest.mark.parametrize("name", [str(x) for x in _FRO["names"]])
+def test_frobenius_condition_number_against_reference(name):
+    """cond_norm = 'fro' (GaussianProcess.py:104): np.linalg.cond(., 'fro') of Kernel.py:239-245 / 279-285 and the gradient of
+    calc_cond_fronorm_w_grad (GpHparaCon.py:209-236) from the reference (tests/golden/cond_fro_table.npz), on the device:
+    norms by reductions, K^-2 and K^-3 by two full MFMA products, derivative entries recomputed in the contraction."""
+    from test_gpu_parity import _gp_from_case, _hp_from_case
+    c = load_case(os.path.join(GOLDEN_DIR, name + ".npz"))
+    GP = _gp_from_case(c)
+    GP.cond_norm = "fro"
+    hp = _hp_from_case(GP, c)
+    want = float(_FRO["cond"][list(_FRO["names"]).index(name)])
+    info, ok = GP.calc_lkd_all(hp, calc_cond=True)
+    assert ok and abs(info.ln_lkd - c["ln_lkd"]) <= tol.LN_LKD_RTOL * abs(c["ln_lkd"])
+    # both sides form an explicit inverse: agreement to cond * eps
+    np.testing.assert_allclose(info.cond, want, rtol=max(1e-9, 1e-15 * want))
+    key = "grad_" + name
+    if key in _FRO.files:
+        info_g, ok_g = GP.calc_lkd_all(hp, calc_cond=True, calc_grad=True)
+        assert ok_g and np.isclose(info_g.cond, info.cond, rtol=1e-12)
+        slots = tol.lkd_grad_slots_to_check(c)                     # gradient-free Matern-5/2: the reference's d K / d theta is not the derivative
+        g, w = info_g.cond_grad[slots], _FRO[key][slots]
+        np.testing.assert_allclose(g, w, rtol=max(1e-7, 1e-14 * want), atol=max(1e-7, 1e-14 * want) * np.abs(w).max())
+    elif GP.wellcond_mtd == "precon":
+        with pytest.raises(AssertionError):                        # as the reference: no gradient with the preconditioner
+            GP.calc_lkd_all(hp, calc_cond=True, calc_grad=True)
