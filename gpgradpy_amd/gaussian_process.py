@@ -328,7 +328,7 @@ class GaussianProcess(HparaOptz):
         self._eta_Kbase, self._eta_Kgrad = self.calc_nugget(self.n_eval)
         self._etaK = self._eta_Kgrad if self.use_grad else self._eta_Kbase
         self.setup_hp_idx4optz()
-        self.Rtensor_init = None        # the [d, n, n] tensor (GaussianProcess.py:363) is never materialised
+        self._Rtensor_init = None       # the [d, n, n] tensor (GaussianProcess.py:363): not built by the hot path, see Rtensor_init
         self.KernEta_chofac = None
         self.invKernEta_fdiff = None
         self._eval_ready = False
@@ -368,6 +368,15 @@ class GaussianProcess(HparaOptz):
         if rc != 0:
             raise _lib.GpgError(f'gpg_set_data failed ({rc}): {self._err()}')
         self._data_vec = y
+
+    @property
+    def Rtensor_init(self):
+        """GaussianProcess.py:363: the difference tensor of the evaluation points with themselves.  The device path never
+        needs it (256 MB at n = 2000, d = 8), so it is only built -- on the host, once per data set -- when a caller reads
+        the attribute, e.g. to hand it to calc_KernGrad like the reference's own code does."""
+        if self._Rtensor_init is None and getattr(self, '_x_eval_in', None) is not None:
+            self._Rtensor_init = self.calc_Rtensor(self._x_eval_in, self._x_eval_in, 1)
+        return self._Rtensor_init
 
     def get_scl_x_w_dist(self):
         return self._x_eval_in, self.Rtensor_init                                # GaussianProcess.py:399-404

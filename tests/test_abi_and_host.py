@@ -157,3 +157,17 @@ def test_lanczos_reports_non_convergence():
         warnings.simplefilter("always")
         lam = lanczos_largest(lambda v: B @ v, 200)
     assert not w and abs(lam - 100.0) < 1e-6
+
+
+def test_rtensor_init_is_built_on_demand():
+    """Rtensor_init (GaussianProcess.py:363) costs nothing until somebody reads it; then it is the reference's tensor
+    R[k, a, b] = x[a, k] - x[b, k] (CommonFun.py:56-84), and get_scl_x_w_dist hands it out like the reference."""
+    GP = _gp_host_only(3, 'SqExp', 5, 'none')
+    assert GP._Rtensor_init is None
+    x, R = GP.get_scl_x_w_dist()
+    assert R.shape == (3, 5, 5) and GP._Rtensor_init is R
+    for k in range(3):
+        np.testing.assert_array_equal(R[k], x[:, k][:, None] - x[:, k][None, :])
+    Y = np.arange(6.0).reshape(2, 3)
+    R2 = GP.calc_Rtensor(x, Y, 1)
+    assert R2.shape == (3, 5, 2) and R2[1, 4, 1] == x[4, 1] - Y[1, 1]
