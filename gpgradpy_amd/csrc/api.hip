@@ -1135,6 +1135,13 @@ int gpg_set_batch(gpg_ctx* c, int max_matrices) {
   return 0;
 }
 
+int gpg_set_max_workgroups(gpg_ctx* c, int n) {
+  if (!c) return -1;
+  if (n < 0) { c->err = "max_workgroups must be >= 0 (0 = as many as the device holds)"; return -1; }
+  c->max_workgroups = n;
+  return 0;
+}
+
 int gpg_set_lookahead(gpg_ctx* c, int on) {
   if (!c) return -1;
   c->lookahead = (on & 1) ? 1 : 0;

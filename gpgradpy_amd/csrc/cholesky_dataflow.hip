@@ -1257,7 +1257,8 @@ static int persistent_grid(gpg_ctx* c, K kernel, long ntask) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 1; }
     it = c->occupancy.emplace(key, nb).first;
   }
-  const long cap = (long)it->second * (c->num_cus > 0 ? c->num_cus : 256);
+  long cap = (long)it->second * (c->num_cus > 0 ? c->num_cus : 256);
+  if (c->max_workgroups > 0 && c->max_workgroups < cap) cap = c->max_workgroups;   // gpg_set_max_workgroups: tests of the progress argument
 #if defined(GPG_NO_PERSIST) || defined(GPG_TICKET_ONESHOT)
   return (int)ntask;
 #endif

@@ -934,6 +934,12 @@ class GaussianProcess(HparaOptz):
         if rc != 0:
             raise _lib.GpgError(f'gpg_set_batch failed ({rc}): {self._err()}')
 
+    def set_max_workgroups(self, n):
+        """Cap on the persistent workgroups of every dataflow launch (include/gpgrad.h: gpg_set_max_workgroups; 0 = default)."""
+        rc = self._lib.gpg_set_max_workgroups(self._ctx, int(n))
+        if rc != 0:
+            raise _lib.GpgError(f'gpg_set_max_workgroups failed ({rc}): {self._err()}')
+
     def reserve_batch(self, rows):
         """Allocate the workspaces calc_lkd_batch(rows) will use (setup, like set_data)."""
         rc = self._lib.gpg_reserve_batch(self._ctx, int(rows))

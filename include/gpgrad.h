@@ -263,6 +263,12 @@ int gpg_factor_fallbacks(gpg_ctx* ctx);
  * tiles, 2 dataflow with 128 x 128 tiles; *matrices = how many matrices that launch factorised.  Either may be NULL. */
 int gpg_last_factor(gpg_ctx* ctx, int* kernel, int* matrices);
 
+/* Caps the number of persistent workgroups of every dataflow launch (0 = default: as many as the device holds at once).  The
+ * launches are correct for ANY number >= 1 -- a workgroup only ever waits for tasks with smaller tickets, all of which are held
+ * by running workgroups or finished -- which is what tests/test_gpu_smoke.py checks with 1, 3 and 17 workgroups; also a way to
+ * leave part of the device to another tenant. */
+int gpg_set_max_workgroups(gpg_ctx* ctx, int n);
+
 /* gpg_lkd_batch: up to max_matrices restart rows are assembled into separate workspaces and factorised by ONE
  * dataflow launch (task lists interleaved tile column by tile column).  A single small factorisation is
  * latency-bound and leaves most of the chip idle; a large one does so at its two ends.  Results are bit-identical to

@@ -53,3 +53,38 @@ def test_two_processes_share_one_gpu():
         assert np.all(np.isfinite(ln))
         np.testing.assert_allclose(ln[:6], ref[:6], rtol=1e-9)
         np.testing.assert_allclose(ln[6:], ref[6:], rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nwg", [1, 3, 17])
+def test_any_number_of_resident_workgroups_makes_progress(nwg):
+    """The progress argument of the ticket-scheduled dataflow launches (cholesky_dataflow.hip: tile_chol_kernel) does not
+    depend on how many workgroups are resident: with the grid capped at 1, 3 or 17 workgroups -- far below what a task's
+    dependencies would need if tasks were bound to workgroups in advance -- every kernel (factorisations on both tile sizes,
+    batched launches, the two sweeps of the inverse, tile and vector solves) still finishes with the full-grid numbers."""
+    import numpy as np
+    import gpgradpy_amd
+    from oracle import gp_oracle as orc
+    n, d = 150, 8                                    # N = 1350: 22 tile columns of 64, 11 of 128
+    X, f, g = orc.synthetic_design(n, d, seed=2)
+    rows = np.random.default_rng(4).uniform(-2.0, -0.7, (5, d))
+    xq = np.random.default_rng(5).uniform(-1, 1, (70, d))
+    out = {}
+    for cap in (0, nwg):
+        res = []
+        for mode in ("tile64", "tile128"):
+            GP = gpgradpy_amd.GaussianProcess(d, True, "SqExp", "precon")
+            GP.set_data(X, f, np.zeros(n), g, np.zeros((n, d)))
+            GP.set_factor_mode(mode)
+            GP.set_max_workgroups(cap)
+            res.append(GP.calc_lkd_batch(rows))                                   # batched factorisation
+            hp = GP.hp_vec2dataclass(GP.hp_info_optz_lkd, rows[0])
+            info = GP.calc_lkd_all(hp, calc_grad=True)[0]                         # factorisation + inverse sweeps + vector solve
+            res.append(np.concatenate(([info.ln_lkd], info.ln_lkd_grad)))
+            GP.set_hpara("set", 0, hp_vals=GP.optz_closed_form_hp(hp))
+            res.append(np.concatenate(GP.eval_model(xq)[:2]))                     # tile solves (70 points)
+            res.append(np.concatenate(GP.eval_model(xq[:1], calc_grad=True)[:2])) # vector solves
+            assert GP.factor_fallbacks() == 0
+        out[cap] = res
+    for a, b in zip(out[0], out[nwg]):
+        np.testing.assert_array_equal(a, b)           # same tasks, same arithmetic: bit for bit
