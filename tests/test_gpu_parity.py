@@ -558,6 +558,19 @@ def test_cfg5_size_properties():
     ln_b = GP.calc_lkd_batch(tab[:2])
     assert GP.last_factor() == ('tile128', 2) and ln_b[0] == ln_df and np.isfinite(ln_b[1])
     GP.set_batch(-1)
+    # the adjoint gradient at this size (W = L^-T and -(W W^T) of a 68096-column factor: 532 x 532 tiles, 111 GB of workspaces)
+    # against a central difference of the device likelihood in its largest component
+    info_g, ok_g = GP.calc_lkd_all(hp, calc_grad=True)
+    assert ok_g and abs(info_g.ln_lkd - ln_df) <= 1e-12 * abs(ln_df)
+    k = int(np.argmax(np.abs(info_g.ln_lkd_grad[:d])))
+    th = hp.theta.copy()
+    h = 1e-4 * th[k]
+    tp, tm = th.copy(), th.copy()
+    tp[k] += h
+    tm[k] -= h
+    mk = lambda t: GP.make_hp_class(theta=t, varK=hp.varK)
+    fd = (GP.calc_lkd_all(mk(tp))[0].ln_lkd - GP.calc_lkd_all(mk(tm))[0].ln_lkd) / (2 * h)
+    assert abs(fd - info_g.ln_lkd_grad[k]) <= 5e-3 * abs(fd), (fd, info_g.ln_lkd_grad[k])
     GP.set_factor_mode('blocked')
     ln_bl = GP.calc_lkd_all(hp)[0].ln_lkd
     assert GP.last_factor()[0] == 'blocked'
