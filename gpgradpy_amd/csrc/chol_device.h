@@ -594,6 +594,7 @@ __device__ __forceinline__ void direct_tile_gemm_x2(d4 (&acc)[4][4], const doubl
   for (int s0 = 0; s0 < nstep; s0 += PF + 1) {
 #pragma unroll
     for (int u = 0; u <= PF; ++u) {
+      if (((PF + 1) & PF) != 0 && s0 + u >= nstep) break;   // prefetch depths whose period does not divide the 32 k-steps of a tile column
       if (s0 + u + PF < nstep) GPG_DX_LOAD((u + PF) % (PF + 1))
       __builtin_amdgcn_sched_barrier(0);
       GPG_DX_MFMA(u)

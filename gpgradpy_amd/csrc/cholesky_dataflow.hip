@@ -3,6 +3,10 @@
 // tile_chol_kernel: 64 x 64 tiles (small matrices), tile128_chol_kernel: 128 x 128 tiles.
 #include "chol_device.h"
 
+#ifndef GPG_MFMA_PF
+#define GPG_MFMA_PF 3      // k-steps of operand fragments in flight ahead of the MFMAs (16 VGPRs each)
+#endif
+
 namespace {
 
 // One ticket counter, or (A/B builds, -DGPG_TICKET_QUEUES) eight of them: workgroup b draws from queue b % 8, whose tasks
@@ -519,7 +523,7 @@ tile128_chol_task(int tix, double* A, int ld, int Mt, const int* __restrict__ ta
     GPG_ACQUIRE();
     GPG_TR(q1)
     const size_t ck = 128 * (size_t)kdone;
-    direct_tile_gemm_x2<3>(acc, A + r0 + wm * 64 + 2 * l15 + (ck + l4) * (size_t)ld, ld,
+    direct_tile_gemm_x2<GPG_MFMA_PF>(acc, A + r0 + wm * 64 + 2 * l15 + (ck + l4) * (size_t)ld, ld,
                            A + cj + wn * 64 + 2 * l15 + (ck + l4) * (size_t)ld, ld, 32 * (kr - kdone));
     __syncthreads();   // sh_kr may be rewritten
     GPG_TR(q2)
@@ -665,7 +669,7 @@ tile128_trinv_task(int tix, const double* __restrict__ A, int ld, const double* 
     if (kr < 0) return false;
     GPG_ACQUIRE();
     const size_t ck = 128 * (size_t)kdone;
-    direct_tile_gemm_x2<3>(acc, W + r0 + wm * 64 + 2 * l15 + (ck + l4) * (size_t)ldw, ldw,
+    direct_tile_gemm_x2<GPG_MFMA_PF>(acc, W + r0 + wm * 64 + 2 * l15 + (ck + l4) * (size_t)ldw, ldw,
                            A + ci + wn * 64 + 2 * l15 + (ck + l4) * (size_t)ld, ld, 32 * (kr - kdone));
     __syncthreads();   // sh_kr may be rewritten
     kdone = kr;
@@ -744,7 +748,7 @@ tile128_wwt_kernel(const double* __restrict__ W0, int ldw, double* __restrict__ 
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[ni][mi][r] = 0.0;
-    direct_tile_gemm_x2<3>(acc, W + r0 + wm * 64 + 2 * l15 + (ck + l4) * (size_t)ldw, ldw,
+    direct_tile_gemm_x2<GPG_MFMA_PF>(acc, W + r0 + wm * 64 + 2 * l15 + (ck + l4) * (size_t)ldw, ldw,
                            Wb + c0 + wn * 64 + 2 * l15 + (ck + l4) * (size_t)ldw, ldw, 32 * (full_k ? Mt : Mt - ta));
     double* Cw = M + r0 + wm * 64 + 2 * l15 + (c0 + wn * 64 + 2 * l4) * (size_t)ldm;
 #pragma unroll

@@ -29,6 +29,8 @@ int main(int argc, char** argv) {
   c.stream_upd = c.stream; c.lookahead = 0;
   c.Npad = n; c.N = n; c.ld = n + 128; c.nb_outer = 512;
   c.chol_impl = impl == 1; c.tail_cols = impl == 2 ? n : 0;
+  if (getenv("GPG_PROBE_MAX_WG")) c.max_workgroups = atoi(getenv("GPG_PROBE_MAX_WG"));   // cap on the persistent grid (e.g. 256 = one workgroup per CU)
+  c.num_cus = 256;
   hipMalloc(&c.A, sizeof(double) * (size_t)c.ld * n);
   hipMalloc(&c.dinv, sizeof(double) * n);
   hipMalloc(&c.info, sizeof(int));
