@@ -47,7 +47,7 @@ __global__ void unscale_kernel(const double* __restrict__ v, const double* __res
 }
 
 template <int KERN, int D>
-__global__ void __launch_bounds__(256) grad_contract_kernel(AsmParams P, const double* __restrict__ Xt,
+__global__ void __launch_bounds__(256, 2) grad_contract_kernel(AsmParams P, const double* __restrict__ Xt,
                                                             const double* __restrict__ invp,
                                                             const double* __restrict__ zvec,
                                                             const double* __restrict__ Minv, int ldm,
