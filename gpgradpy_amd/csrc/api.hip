@@ -446,7 +446,7 @@ static int gpg_lkd_batch_once(gpg_ctx* c, int m, const double* hp_rows, int row_
     hps[i].varK_mat = row[c->d];
     hps[i].var_fval = row[c->d + 1];
     hps[i].var_fgrad = row[c->d + 2];
-    hps[i].eta = eta;
+    hps[i].eta = row_len > c->d + 4 ? hp_rows[(size_t)i * row_len + c->d + 4] : eta;
     hps[i].wellcond = wellcond;
     hps[i].closed_form_varK = closed_form_varK;
     hps[i].hp_kernel = row_len >= c->d + 4 ? row[c->d + 3] : 0.0;   // RatQu: alpha in column d + 3
@@ -540,7 +540,7 @@ static int gpg_lkd_grad_batch_once(gpg_ctx* c, int m, const double* hp_rows, int
     hps[i].varK_mat = row[c->d];
     hps[i].var_fval = row[c->d + 1];
     hps[i].var_fgrad = row[c->d + 2];
-    hps[i].eta = eta;
+    hps[i].eta = row_len > c->d + 4 ? hp_rows[(size_t)i * row_len + c->d + 4] : eta;
     hps[i].wellcond = wellcond;
     hps[i].closed_form_varK = closed_form_varK;
     hps[i].hp_kernel = row_len >= c->d + 4 ? row[c->d + 3] : 0.0;
@@ -956,6 +956,38 @@ int gpg_kern_rtensor(int device, int kernel, int dim, int n1, int n2, const doub
   if (d_g2) (void)hipFree(d_g2);
   if (st) (void)hipStreamDestroy(st);
   return rc;
+}
+
+int gpg_abs_rowsum(gpg_ctx* c, const gpg_hp* hp, double* rowsum) {
+  int rc = check_hp(c, hp);
+  if (rc) return rc;
+  if (!rowsum) { c->err = "rowsum is NULL"; return -1; }
+  GPG_HIP_OK(c, hipSetDevice(c->device));
+  GPG_WS(c, 0);
+  if (!c->apply_buf) GPG_HIP_OK(c, hipMalloc(&c->apply_buf, sizeof(double) * 2 * (size_t)c->vec_rows_cols));
+  gpg_hp h0 = *hp;
+  h0.eta = 0.0;
+  const bool precon = hp->wellcond == GPG_WELLCOND_PRECON;
+  AsmParams p = make_params(c, &h0, precon ? 0 : 1);      // Kcor (Kernel.py:227, times varK) or the raw kernel matrix (:272)
+  c->last_precon = p.precon;
+  c->prep_valid = true;
+  c->factor_valid = false;
+  gpg_launch_prep(c, p, hp->var_fval, hp->var_fgrad, 0.0, 0.0, 0.0, 0.0);
+  unsigned save = c->prof_mask; c->prof_mask = 0;
+  gpg_launch_assembly(c, p);
+  c->prof_mask = save;
+  gpg_launch_abs_rowsum(c, precon ? 1.0 / hp->varK_mat : 1.0, c->apply_buf);
+  GPG_HIP_OK(c, hipMemcpyAsync(rowsum, c->apply_buf, sizeof(double) * c->N, hipMemcpyDeviceToHost, c->stream));
+  GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
+  GPG_HIP_OK(c, hipGetLastError());
+  GPG_LAUNCH_OK(c);
+  return 0;
+}
+
+int gpg_set_gradient_nugget(gpg_ctx* c, double eta) {
+  if (!c) return -1;
+  c->grad_eta = eta >= 0.0 ? eta : -1.0;
+  return 0;
 }
 
 int gpg_dcov_quadform(gpg_ctx* c, const gpg_hp* hp, const double* v, double* out) {

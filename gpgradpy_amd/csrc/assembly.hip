@@ -411,6 +411,28 @@ void gpg_launch_prep_assembly_batch(gpg_ctx* c, const AsmParams& p, int B, const
   gpg_prof_end(c);
 }
 
+// Row sums of |M| for the symmetric matrix whose lower triangle sits in A -- the quantity the reference's variable nugget
+// is made of (Kernel.py:232-234, 272-274: sum_rows = np.sum(np.abs(K), axis=1)).  One wave per row i: the row part
+// A(i, 0..i) is a strided read, the column part A(i+1.., i) a contiguous one; lanes add in a fixed order, so the result is
+// reproducible from run to run.  HBM-read bound: N^2 / 2 entries, the strided half in 64-byte sectors.
+__global__ void __launch_bounds__(256) abs_rowsum_kernel(const double* __restrict__ A, int ld, int N, double scale,
+                                                         double* __restrict__ out) {
+  const int i = (int)(((size_t)blockIdx.x * 256 + threadIdx.x) >> 6), lane = threadIdx.x & 63;
+  if (i >= N) return;
+  double s = 0.0;
+  for (int j = lane; j <= i; j += 64) s += fabs(A[(size_t)j * ld + i]);
+  const double* col = A + (size_t)i * ld;
+  for (int j = i + 1 + lane; j < N; j += 64) s += fabs(col[j]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) out[i] = s * scale;
+}
+
+void gpg_launch_abs_rowsum(gpg_ctx* c, double scale, double* out_dev) {
+  hipLaunchKernelGGL(abs_rowsum_kernel, dim3((unsigned)(((size_t)c->N * 64 + 255) / 256)), dim3(256), 0, c->stream, c->A, c->ld, c->N,
+                     scale, out_dev);
+}
+
 void gpg_launch_cross(gpg_ctx* c, const AsmParams& p, int nx, int nxp) {
   if (p.kernel == GPG_KERNEL_SQEXP) launch_cross_d<GPG_KERNEL_SQEXP>(c, p, nx, nxp);
   else if (p.kernel == GPG_KERNEL_RATQU) launch_cross_d<GPG_KERNEL_RATQU>(c, p, nx, nxp);

@@ -68,6 +68,7 @@ struct gpg_ctx {
   int inv_tile64_cols = 4096;   // explicit inverse: W = L^-T on 64 x 64 tiles up to this many padded columns (0: always 128-tiles)
   int* tile_flags = nullptr;   // device: completion flags of the dataflow kernel + abort word + ticket counter
   int num_cus = 0;             // compute units of the device (grid of the persistent launches)
+  double grad_eta = -1.0;      // >= 0: nugget the hyperparameter derivatives are formed with instead of hp->eta (gpg_set_gradient_nugget)
   int max_workgroups = 0;      // > 0: cap on the grid of every persistent launch (gpg_set_max_workgroups; 0 = co-resident capacity)
   std::map<const void*, int> occupancy;   // workgroups per compute unit of each persistent kernel (occupancy query, cached)
   size_t tile_flags_cap = 0;
@@ -149,6 +150,7 @@ void gpg_launch_prep_assembly_batch(gpg_ctx* c, const AsmParams& p, int B, const
                                     size_t a_stride);
 void gpg_launch_lkd_reduce_batch(gpg_ctx* c, int slot0, int B, size_t v_stride, size_t a_stride);
 void gpg_launch_cross(gpg_ctx* c, const AsmParams& p, int nx, int nxp);   // Wt <- P^-1 Kyx (transposed)
+void gpg_launch_abs_rowsum(gpg_ctx* c, double scale, double* out_dev);    // out[i] = scale * sum_j |M_ij|, M symmetric, lower triangle in A
 void gpg_launch_tile_chol(gpg_ctx* c, int c0);                          // dataflow factorisation of A[c0:, c0:], 64-tiles
 void gpg_launch_tile128_chol(gpg_ctx* c);
 // dataflow W <- W L^-T / Z <- Z L^-1 for a few 64-row tiles; rows >= valid must be zero (their substitution is skipped);

@@ -367,8 +367,10 @@ void gpg_launch_identity(gpg_ctx* c, double* W, int ldw) {
 // out_dev[0 .. ns) = g_aa, out_dev[ns .. 2 ns) = g_inv, ns = d + 3 (+ 1 for RatQu: alpha last)
 // zvec = P alpha-like vector (the kernel forms alpha = zvec * invp), Minv = -(L L^T)^-1 or nullptr (then only the
 // quadratic forms g_aa[k] = alpha^T G_k alpha are meaningful: gpg_dcov_quadform)
-void gpg_launch_grad_contract(gpg_ctx* c, const AsmParams& p, double* partial, double* out_dev, const double* zvec,
+void gpg_launch_grad_contract(gpg_ctx* c, const AsmParams& p_in, double* partial, double* out_dev, const double* zvec,
                               const double* Minv) {
+  AsmParams p = p_in;
+  if (c->grad_eta >= 0.0) p.eta = c->grad_eta;   // the reference differentiates with self._etaK whatever nugget the matrix got
   dim3 grid((p.n + 255) / 256, (p.n + kTBg - 1) / kTBg);
   if (p.kernel == GPG_KERNEL_SQEXP) launch_contract_d<GPG_KERNEL_SQEXP>(c, p, partial, grid, zvec, Minv);
   else if (p.kernel == GPG_KERNEL_RATQU) launch_contract_d<GPG_KERNEL_RATQU>(c, p, partial, grid, zvec, Minv);

@@ -14,6 +14,7 @@ import numpy as np
 
 from . import _lib
 from .hpara import HparaOptzInfo, HparaOptzVal, LkdInfo
+from .rescaling import Rescaling, calc_dist_min, calc_dist_max
 from .hpara_optz import HparaOptz
 
 
@@ -73,6 +74,14 @@ class GaussianProcess(HparaOptz):
     cond_max = 1e10
     cond_max_abs = 1e16
     cond_norm = 2                 # GaussianProcess.py:104: 2 (Lanczos through the factor) or 'fro' (gpg_cond_fro)
+    cond_dist_min_dflt = 1        # wellcond_mtd 'dflt_vmin' (GaussianProcess.py:106)
+    cond_dist_max_dflt = 1        # wellcond_mtd 'dflt_vmax' (:107)
+    cond_vreq_max_iter = 3        # rescale methods: re-optimisations with a theta-informed anisotropic scaling (:111)
+    vmin_rescale_eta_vary = 1.0   # (:112)
+    cond_vreq_iter_tol = 1e-1     # (:113)
+    _vmin_req_grad = np.nan
+    _vmin_init = np.nan
+    DataScl = None
 
     b_optz_hp_kernel = True
     b_use_data_scl = False
@@ -133,13 +142,15 @@ class GaussianProcess(HparaOptz):
         # reference GaussianProcess.py:192-217
         assert wellcond_mtd in self.wellcond_mtd_avail, \
             f'Requested method not available, wellcond_mtd : {wellcond_mtd}'
+        if wellcond_mtd == 'rescale_eta_vary':
+            self.cond_eta_is_const = False                    # nugget from the largest absolute row sum of the matrix
         if not self.use_grad:
             wellcond_mtd = 'base'
-        if wellcond_mtd not in ('base', 'precon'):
-            raise NotImplementedError(f"wellcond_mtd '{wellcond_mtd}' (data rescaling) is outside the accelerated path")
         self.wellcond_mtd = wellcond_mtd
         self.b_use_cond_cstr = wellcond_mtd != 'precon'
-        self.b_use_data_scl = False
+        # the rescale / dflt_v methods work on shifted and scaled data (gpgradpy_amd/rescaling.py); what the device sees
+        # then is the 'base' covariance of the scaled points
+        self.b_use_data_scl = ('rescale' in wellcond_mtd) or ('dflt_v' in wellcond_mtd)
 
     def theta2gamma(self, theta):
         # KernelSqExp.py:580-583 / KernelMatern5f2.py:654-657
@@ -173,11 +184,65 @@ class GaussianProcess(HparaOptz):
                 ub = (n_eval - 1) * (1 + (dim + np.sqrt(3 * dim)) * al + dim * (1 + np.sqrt(3 * dim)) * al ** 2) \
                     * np.exp(-np.sqrt(3 * dim) * al)
             return eta_Kbase, (1 + ub) / (self.cond_max_target - 1)
+        if 'rescale' in self.wellcond_mtd:
+            return eta_Kbase, self.calc_nugget_Kfull_vreq(n_eval)                 # GpWellCond.py:140-141
         if self.cond_eta_set_mtd == 'Kbase_eta':
             return eta_Kbase, eta_Kbase
         if self.cond_eta_set_mtd == 'Kbase_eta_w_dim':
             return eta_Kbase, eta_Kbase * (self.dim + 1)
         raise Exception(f'Uknown method for cond_eta_set_mtd = {self.cond_eta_set_mtd}')
+
+    # ---- rescaling method (GpWellCond.py:18-100; "A Non-intrusive Solution to the Ill-Conditioning Problem of the
+    #      Gradient-Enhanced Gaussian Covariance Matrix for Gaussian Processes") ---------------------------------------
+    calc_dist_min = staticmethod(calc_dist_min)                                   # CommonFun.py:16-34
+    calc_dist_max = staticmethod(calc_dist_max)                                   # CommonFun.py:36-54
+
+    def calc_mtd_rescale_origin_vreq(self, n_eval, dim=None):
+        """Minimum distance between scaled points that bounds the condition number with the constant nugget
+        (GpWellCond.py:26-41): min(2 sqrt(d), (2 + sqrt(4 + 2 e^2 ln((n - 1)(1 + 2 sqrt(d)) / 2))) / e)."""
+        if dim is None:
+            dim = self.dim
+        if n_eval == 1:
+            return 1
+        dist_star = 2 * np.sqrt(dim)
+        root = np.sqrt(4 + 2 * np.exp(2) * np.log((n_eval - 1) * (1 + dist_star) / 2))
+        return np.minimum((2 + root) / np.exp(1), dist_star)
+
+    def calc_nugget_Kfull_vreq(self, n_eval, vmin=None):
+        """Nugget that goes with that distance (GpWellCond.py:78-100)."""
+        if vmin is None:
+            vmin = self.calc_mtd_rescale_origin_vreq(n_eval)
+        cond_max = self.cond_max_target
+        if n_eval == 1:
+            return n_eval / (cond_max - 1)
+        assert vmin >= np.sqrt(2), f'This method requires that vmin = {vmin} >= sqrt(2)'
+        v_frac = 2 * np.sqrt(self.dim) / vmin
+        eta_Kgrad = (1 + (n_eval - 1) * v_frac * np.exp(1 / v_frac - 1)) / (cond_max - 1)
+        eta_Kbase = self.calc_nugget_Kbase(n_eval, cond_max)
+        assert v_frac >= 0.99, f'This term should be greater or equal to 1, v_frac = {v_frac}'
+        assert eta_Kgrad >= 0.99 * eta_Kbase, \
+            f'We expect that eta_Kgrad > eta_Kbase but eta_Kgrad = {eta_Kgrad}, eta_Kbase = {eta_Kbase}'
+        return eta_Kgrad
+
+    def rescaling_data_w_theta_sol(self, X_scl_v1, xvec_scale_v1, hp_theta, tol_min_dist_x=1e-15):
+        """From an optimised theta to the next anisotropic scaling (GpWellCond.py:43-76): scale direction k by
+        sqrt(theta_k / theta*) with theta* the geometric mean, restore the required minimum distance, and return the
+        isotropic theta that solution corresponds to, its squared log-distance from the line theta_1 = ... = theta_d, and
+        the new scale vector."""
+        n_eval = X_scl_v1.shape[0]
+        assert n_eval > 1, 'This method should only be called if n_eval > 1'
+        if self.optz_log_hp_theta:
+            theta_sol, log_theta = 10 ** hp_theta, hp_theta
+        else:
+            theta_sol, log_theta = hp_theta, np.log10(hp_theta)
+        vreq = self.calc_mtd_rescale_origin_vreq(n_eval, self.dim)
+        theta_star = 10 ** np.mean(log_theta)
+        scale_v2 = np.sqrt(theta_sol / theta_star)
+        correction = vreq / np.max((calc_dist_min(X_scl_v1 * scale_v2[None, :]), tol_min_dist_x))
+        xvec_scale_new = xvec_scale_v1 * scale_v2 * correction
+        dist2th_star = np.dot(log_theta, log_theta) - np.dot(log_theta, np.ones(self.dim)) ** 2 / self.dim
+        theta_est = np.ones(self.dim) * theta_star / correction ** 2
+        return (np.log10(theta_est) if self.optz_log_hp_theta else theta_est), dist2th_star, xvec_scale_new
 
     @staticmethod
     def make_data_vec(fval, fgrad=None):
@@ -327,7 +392,24 @@ class GaussianProcess(HparaOptz):
         self.b_has_noisy_data = not (self.b_fval_zero and self.b_fgrad_zero)
         self._eta_Kbase, self._eta_Kgrad = self.calc_nugget(self.n_eval)
         self._etaK = self._eta_Kgrad if self.use_grad else self._eta_Kbase
+        self._vmin_init = calc_dist_min(x_eval)                                   # GaussianProcess.py:338
         self.setup_hp_idx4optz()
+        self.DataScl = None
+        if self.b_use_data_scl:                                                   # GaussianProcess.py:342-361
+            if self.wellcond_mtd == 'rescale_origin':
+                dist_set = self._vmin_req_grad = self.calc_mtd_rescale_origin_vreq(n_eval, self.dim)
+                x_scl_method = 'set_vmin'
+            elif self.wellcond_mtd == 'rescale_eta_vary':
+                dist_set, x_scl_method = self.vmin_rescale_eta_vary, 'set_vmin'
+            elif self.wellcond_mtd == 'dflt_vmin':
+                dist_set, x_scl_method = self.cond_dist_min_dflt, 'set_vmin'
+            elif self.wellcond_mtd == 'dflt_vmax':
+                dist_set, x_scl_method = self.cond_dist_max_dflt, 'set_vmax'
+            else:
+                raise Exception(f'Unknown method wellcond_mtd = {self.wellcond_mtd}')
+            self.DataScl = Rescaling(x_eval, x_scl_method=x_scl_method, dist_set=dist_set)
+            self.DataScl.set_obj_data(fval, std_fval, grad, std_grad)
+            self.DataScl.on_change = self._on_rescale          # a later set_xscale_data() re-sends the scaled data to the device
         self._Rtensor_init = None       # the [d, n, n] tensor (GaussianProcess.py:363): not built by the hot path, see Rtensor_init
         self.KernEta_chofac = None
         self.invKernEta_fdiff = None
@@ -354,20 +436,32 @@ class GaussianProcess(HparaOptz):
             rc = self._lib.gpg_set_grad_mask(self._ctx, None if mask is None else mask.ctypes.data_as(C.POINTER(C.c_ubyte)))
             if rc != 0:
                 raise _lib.GpgError(f'gpg_set_grad_mask failed ({rc}): {self._err()}')
-        x = np.ascontiguousarray(self._x_eval_in, dtype=np.float64)
-        y = np.ascontiguousarray(self.make_data_vec(self._fval_in, self._grad_in if self.use_grad else None),
-                                 dtype=np.float64)
+        x_scl = self.get_scl_x_w_dist(want_tensor=False)[0]
+        fval_scl, std_fval_scl, grad_scl, std_grad_scl = self.get_scl_eval_data()
+        self._fval_scl = fval_scl
+        x = np.ascontiguousarray(x_scl, dtype=np.float64)
+        y = np.ascontiguousarray(self.make_data_vec(fval_scl, grad_scl if self.use_grad else None), dtype=np.float64)
         noise = np.zeros(self.n_data)
-        if self.b_has_noisy_data:                                                 # Kernel.py:324-353
+        if self.b_has_noisy_data:                                                 # Kernel.py:324-353 (on the scaled data: :328)
             if self.known_eps_fval:
-                noise[:self.n_eval] = self._std_fval_in ** 2
+                noise[:self.n_eval] = std_fval_scl ** 2
             if self.use_grad and self.known_eps_fgrad:
-                noise[self.n_eval:] = (self._std_grad_in ** 2).reshape(self._std_grad_in.size, order='f')
+                noise[self.n_eval:] = (std_grad_scl ** 2).reshape(std_grad_scl.size, order='f')
         self._noise_known = noise
         rc = self._lib.gpg_set_data(self._ctx, _lib.as_dp(x), _lib.as_dp(y), _lib.as_dp(noise))
         if rc != 0:
             raise _lib.GpgError(f'gpg_set_data failed ({rc}): {self._err()}')
+        # the reference differentiates with the constant nugget even when the matrix gets the row-sum one (GpHparaGrad.py:43,107,126)
+        self._lib.gpg_set_gradient_nugget(self._ctx, -1.0 if self.cond_eta_is_const else float(self._etaK))
         self._data_vec = y
+
+    def _on_rescale(self):
+        """DataScl.set_xscale_data / set_obj_scaling changed the scaled data (OptzLkd.py:176): the device copy and every
+        factor made from the old one are stale."""
+        self.KernEta_chofac = None
+        self.invKernEta_fdiff = None
+        self._eval_ready = False
+        self._push_data()
 
     @property
     def Rtensor_init(self):
@@ -378,26 +472,52 @@ class GaussianProcess(HparaOptz):
             self._Rtensor_init = self.calc_Rtensor(self._x_eval_in, self._x_eval_in, 1)
         return self._Rtensor_init
 
-    def get_scl_x_w_dist(self):
-        return self._x_eval_in, self.Rtensor_init                                # GaussianProcess.py:399-404
+    def get_scl_x_w_dist(self, want_tensor=True):
+        """GaussianProcess.py:399-404: (scaled points, their [dim, n, n] difference tensor).  The tensor is only built when
+        it is asked for (want_tensor=False is this package's own use)."""
+        if self.b_use_data_scl:
+            return (self.DataScl.x_scl, self.DataScl.Rtensor_scl if want_tensor else None)
+        return self._x_eval_in, (self.Rtensor_init if want_tensor else None)
+
+    def x_init_2_scl(self, x_init):
+        return self.DataScl.x_init_2_scl(x_init) if self.b_use_data_scl else x_init      # GaussianProcess.py:406-411
+
+    def x_scl_2_init(self, x_scl):
+        return self.DataScl.x_scl_2_init(x_scl) if self.b_use_data_scl else x_scl        # GaussianProcess.py:413-418
+
+    def get_init_eval_data(self):
+        return self._fval_in, self._std_fval_in, self._grad_in, self._std_grad_in         # GaussianProcess.py:420-421
 
     def get_scl_eval_data(self):
-        return self._fval_in, self._std_fval_in, self._grad_in, self._std_grad_in   # GaussianProcess.py:423-433
+        # GaussianProcess.py:423-433
+        fval, std_fval, grad, std_grad = self.data_init_2_scl(*self.get_init_eval_data())[:4]
+        return fval, (std_fval if self.known_eps_fval else None), grad, (std_grad if self.known_eps_fgrad else None)
+
+    def data_init_2_scl(self, mu_in=None, sig_in=None, dmudx_in=None, dsigdx_in=None, d2mudx2_in=None, d2sigdx2_in=None):
+        if self.b_use_data_scl:                                                           # GaussianProcess.py:435-445
+            return self.DataScl.obj_init_2_scl(mu_in, sig_in, dmudx_in, dsigdx_in, d2mudx2_in, d2sigdx2_in)
+        return mu_in, sig_in, dmudx_in, dsigdx_in, d2mudx2_in, d2sigdx2_in
+
+    def data_scl_2_init(self, mu_scl=None, sig_scl=None, dmudx_scl=None, dsigdx_scl=None, d2mudx2_scl=None, d2sigdx2_scl=None):
+        if self.b_use_data_scl:                                                           # GaussianProcess.py:447-457
+            return self.DataScl.obj_scl_2_init(mu_scl, sig_scl, dmudx_scl, dsigdx_scl, d2mudx2_scl, d2sigdx2_scl)
+        return mu_scl, sig_scl, dmudx_scl, dsigdx_scl, d2mudx2_scl, d2sigdx2_scl
 
     def calc_noise_vec(self, hp_vals):
         # Kernel.py:309-357 (host copy; the device builds the same vector from var_fval / var_fgrad)
         if self.b_fval_zero and self.b_fgrad_zero:
             return np.zeros(self.n_data)
+        std_fval, _, std_fgrad = self.get_scl_eval_data()[1:]                    # Kernel.py:328
         out = np.zeros(self.n_data)
         if self.known_eps_fval:
             assert hp_vals.var_fval is None
-            out[:self.n_eval] = self._std_fval_in ** 2
+            out[:self.n_eval] = std_fval ** 2
         else:
             out[:self.n_eval] = hp_vals.var_fval
         if self.use_grad:
             if self.known_eps_fgrad:
                 assert hp_vals.var_fgrad is None
-                out[self.n_eval:] = (self._std_grad_in ** 2).reshape(self._std_grad_in.size, order='f')
+                out[self.n_eval:] = (std_fgrad ** 2).reshape(std_fgrad.size, order='f')
             else:
                 out[self.n_eval:] = hp_vals.var_fgrad
         return out
@@ -416,16 +536,42 @@ class GaussianProcess(HparaOptz):
         else:
             hp.var_fgrad = -1.0 if (self.known_eps_fgrad or not self.b_has_noisy_data) else float(hp_vals.var_fgrad)
         hp.eta = float(self._etaK)
-        hp.wellcond = _lib.GPG_WELLCOND[self.wellcond_mtd]
+        hp.wellcond = self._wellcond_code
         hp.closed_form_varK = int(closed_form)
         if self.kernel_has_hp:
             assert hp_vals.kernel is not None, 'hp_vals.kernel (alpha of RatQu) must be set'
             hp.hp_kernel = float(np.asarray(hp_vals.kernel).reshape(-1)[0])
         else:
             hp.hp_kernel = 0.0
+        self._etaK_last, self._idx_etaK_argmax_last = self._etaK, None
         if not self.cond_eta_is_const:
-            raise NotImplementedError('cond_eta_is_const=False (row-sum nugget) is outside the accelerated path')
+            # Kernel.py:229-236 / 269-276: nugget from the largest absolute row sum of Kcor ('precon') or of the kernel matrix
+            rowsum = np.empty(self.n_data)
+            rc = self._lib.gpg_abs_rowsum(self._ctx, C.byref(hp), _lib.as_dp(rowsum))
+            if rc != 0:
+                raise _lib.GpgError(f'gpg_abs_rowsum failed ({rc}): {self._err()}')
+            idx = int(np.argmax(rowsum))
+            hp.eta = float(rowsum[idx] / (self.cond_max_target - 1))
+            self._etaK_last, self._idx_etaK_argmax_last = hp.eta, idx
         return hp, theta   # keep theta alive
+
+    @property
+    def _wellcond_code(self):
+        """The two matrix constructions of Kernel.py:220-302: 'precon', or -- for every other method -- nugget only."""
+        return _lib.GPG_WELLCOND['precon' if self.wellcond_mtd == 'precon' else 'base']
+
+    def _rows_with_eta(self, rows):
+        """cond_eta_is_const = False: the batched calls take the nugget of every row in an extra column (include/gpgrad.h)."""
+        if self.cond_eta_is_const:
+            return rows
+        out = np.empty((rows.shape[0], rows.shape[1] + 1))
+        out[:, :-1] = rows
+        d = self.dim
+        for i, r in enumerate(rows):
+            hp_vals = HparaOptzVal(None, r[:d], r[d + 3] if self.kernel_has_hp else None, r[d],
+                                   r[d + 1] if r[d + 1] >= 0 else None, r[d + 2] if r[d + 2] >= 0 else None)
+            out[i, -1] = self._make_hp(hp_vals, r[d], closed_form=not self.b_has_noisy_data)[0].eta
+        return np.ascontiguousarray(out)
 
     # ---- kernel table (Kernel.py:27-126: bound per kernel type in the reference; same names and arguments here) ------
     @staticmethod
@@ -538,7 +684,7 @@ class GaussianProcess(HparaOptz):
                 condK = self.calc_cond_device()
             else:
                 condK = self.calc_cond_fro_device(hp)[0]
-        return Kern, None, Kcov, chofac, condK, self._etaK, None
+        return Kern, None, Kcov, chofac, condK, self._etaK_last, self._idx_etaK_argmax_last
 
     # ---- likelihood ------------------------------------------------------------------------------------
     def calc_lkd_all(self, hp_vals, calc_lkd=True, calc_cond=False, calc_grad=False, lkd_use_adj_mtd=None):
@@ -607,14 +753,14 @@ class GaussianProcess(HparaOptz):
                 return LkdInfo(cond=cond), False
         ln_lkd = out.ln_lkd
         if not noisy:
-            ln_lkd -= self.calc_lkd_varK_pnlt(out.varK, self._fval_in)[0]        # CalcLkd.py:162,168
+            ln_lkd -= self.calc_lkd_varK_pnlt(out.varK, self._fval_scl)[0]        # CalcLkd.py:162,168
         ln_lkd_grad = None
         if calc_grad and calc_lkd:
             # adjoint weights: CalcLkd.py:173-177 (noise-free), :233-235 (noisy)
             if noisy:
                 s_aa = 0.5
             else:
-                s_aa = self.calc_lkd_varK_pnlt(out.varK, self._fval_in)[1] / self.n_data + 1.0 / (2.0 * out.varK)
+                s_aa = self.calc_lkd_varK_pnlt(out.varK, self._fval_scl)[1] / self.n_data + 1.0 / (2.0 * out.varK)
             g_all = s_aa * g_aa + g_inv
             hi, d = self.hp_info_optz_lkd, self.dim
             ln_lkd_grad = np.zeros(hi.n_hp)
@@ -660,20 +806,18 @@ class GaussianProcess(HparaOptz):
     def calc_lkd_batch(self, hp_x0, return_all=False):
         """ln_lkd of every restart row on this device, queued back-to-back -- the loop body of
         GpHparaX0.py:39-45.  Failed factorisations give NaN (GpHparaX0.py:34,43-45)."""
-        rows = np.ascontiguousarray(self._rows_from_hp_x0(hp_x0))
+        rows = self._rows_with_eta(np.ascontiguousarray(self._rows_from_hp_x0(hp_x0)))
         m = rows.shape[0]
-        if not self.cond_eta_is_const:
-            raise NotImplementedError('cond_eta_is_const=False is outside the accelerated path')
         outs = (_lib.GpgLkdOut * m)()
         t0 = time.time()
         rc = self._lib.gpg_lkd_batch(self._ctx, m, _lib.as_dp(rows), rows.shape[1], float(self._etaK),
-                                     _lib.GPG_WELLCOND[self.wellcond_mtd], int(not self.b_has_noisy_data), outs)
+                                     self._wellcond_code, int(not self.b_has_noisy_data), outs)
         self._time_chofac += time.time() - t0
         if rc != 0:
             raise _lib.GpgError(f'gpg_lkd_batch failed ({rc}): {self._err()}')
         ln = np.array([o.ln_lkd if o.info == 0 else np.nan for o in outs])
         if self.lkd_varK_pnlt_use and not self.b_has_noisy_data:
-            ln = ln - np.array([self.calc_lkd_varK_pnlt(o.varK, self._fval_in)[0] if o.info == 0 else 0.0 for o in outs])
+            ln = ln - np.array([self.calc_lkd_varK_pnlt(o.varK, self._fval_scl)[0] if o.info == 0 else 0.0 for o in outs])
         if return_all:
             return ln, outs
         return ln
@@ -685,14 +829,14 @@ class GaussianProcess(HparaOptz):
         ok False and NaN entries (the caller decides what a failure means: OptzLkd.py:74-77)."""
         if self.bvec_use_grad is not None and not np.all(self.bvec_use_grad):
             raise NotImplementedError('likelihood gradient with a bvec_use_grad mask is not supported')
-        rows = np.ascontiguousarray(self._rows_from_hp_x0(hp_x0))
+        rows = self._rows_with_eta(np.ascontiguousarray(self._rows_from_hp_x0(hp_x0)))
         m, d = rows.shape[0], self.dim
         outs = (_lib.GpgLkdOut * m)()
         g_aa, g_inv = np.zeros((m, d + 4)), np.zeros((m, d + 4))
         noisy = self.b_has_noisy_data
         t0 = time.time()
         rc = self._lib.gpg_lkd_grad_batch(self._ctx, m, _lib.as_dp(rows), rows.shape[1], float(self._etaK),
-                                          _lib.GPG_WELLCOND[self.wellcond_mtd], int(not noisy), outs, _lib.as_dp(g_aa), _lib.as_dp(g_inv))
+                                          self._wellcond_code, int(not noisy), outs, _lib.as_dp(g_aa), _lib.as_dp(g_inv))
         self._time_chofac += time.time() - t0
         if rc != 0:
             raise _lib.GpgError(f'gpg_lkd_grad_batch failed ({rc}): {self._err()}')
@@ -705,7 +849,7 @@ class GaussianProcess(HparaOptz):
             if noisy:
                 s_aa, pn = 0.5, 0.0
             else:
-                pnlt = self.calc_lkd_varK_pnlt(o.varK, self._fval_in)
+                pnlt = self.calc_lkd_varK_pnlt(o.varK, self._fval_scl)
                 s_aa, pn = pnlt[1] / self.n_data + 1.0 / (2.0 * o.varK), pnlt[0]
             ln[i] = o.ln_lkd - pn
             g_all = s_aa * g_aa[i] + g_inv[i]
@@ -767,7 +911,7 @@ class GaussianProcess(HparaOptz):
         self.data_vec = self._data_vec
         self.Kern = self.KernEta = None
         self.condK = None
-        self.etaK_eval = self._etaK
+        self.etaK_eval = self._etaK_last
         if rc > 0:
             self.KernEta_chofac = None
             self.invKernEta_fdiff = None
@@ -801,6 +945,8 @@ class GaussianProcess(HparaOptz):
             raise Exception('Cannot change hp_vals between calling setup_eval_model() and eval_model()')
         if not self._eval_ready:
             raise Exception('setup_eval_model() must be called (again): set_data() replaced the data of the device model')
+        if self.b_use_data_scl:
+            x2model = self.DataScl.x_init_2_scl(x2model)                                   # GpEvalModel.py:121-122
         xq = np.ascontiguousarray(x2model, dtype=np.float64)
         mu, sig, s2 = np.empty(nx), np.empty(nx), np.empty(nx)
         dmudx = dsigdx = d2mudx2 = d2sigdx2 = None
@@ -823,6 +969,8 @@ class GaussianProcess(HparaOptz):
             raise _lib.GpgError(f'gpg_predict failed ({rc}): {self._err()}')
         assert np.min(s2) >= 0, \
             f'The variance of the surr should be non-negative but min(sig2_wo_sigK) = {np.min(s2)}'   # GpEvalModel.py:163
+        if self.b_use_data_scl:                                                            # GpEvalModel.py:181-183
+            mu, sig, dmudx, dsigdx, d2mudx2, d2sigdx2 = self.data_scl_2_init(mu, sig, dmudx, dsigdx, d2mudx2, d2sigdx2)
         if squeeze_nx:
             if calc_hess:
                 return mu[0], sig[0], dmudx[0, :], dsigdx[0, :], d2mudx2[0], d2sigdx2[0]  # GpEvalModel.py:186-196
@@ -846,6 +994,8 @@ class GaussianProcess(HparaOptz):
             assert nx == 1, 'If squeeze_nx is True, then x_acq must only have one point'
         if (self.hp_vals == self._hp_vals_model_setup) is False:
             raise Exception('Cannot change hp_vals between calling setup_eval_model() and eval_model()')
+        if self.b_use_data_scl:                                                            # GpEvalModel.py:253-256
+            raise Exception('The method eval_model_var() is not setup for cases where data must be rescaled')
         if calc_hess:
             assert calc_grad, 'To return the hessian calc_grad must also be set to True'
         if not self._eval_ready:

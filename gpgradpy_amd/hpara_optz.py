@@ -13,11 +13,11 @@ Every likelihood value and gradient comes from the device (`calc_lkd_all` -> `gp
 `hp_best` pre-selection (40 value-only evaluations in the reference's loop, GpHparaX0.py:39-45) is ONE
 `gpg_lkd_batch` call, sharded over ranks when `torch.distributed` is initialised.
 
-Differences from the reference, all outside the accelerated path: the condition-number constraint
-(`b_use_cond_cstr`, optz/GpHparaCon.py) and the final SVD condition number are not computed (`cond_val` is NaN);
-the rescale well-conditioning methods are not available; the Latin-hypercube source is SciPy's
-(`scipy.stats.qmc.LatinHypercube`, seed 1) because `smt` is not installed here -- its sample sequence differs
-from smt's, the bounds and everything downstream are the reference's.
+Differences from the reference: the Latin-hypercube source is SciPy's (`scipy.stats.qmc.LatinHypercube`, seed 1)
+because `smt` is not installed here -- its sample sequence differs from smt's, the bounds and everything downstream are
+the reference's; condition numbers come from the factor on the device (Lanczos / gpg_cond_fro) instead of a dense SVD.
+The condition-number constraint of the non-'precon' methods and the rescale methods' outer loop
+(`optz_hp_max_lkd_mtd_rescale`, OptzLkd.py:114-185) are here.
 """
 import threading
 import time
@@ -117,7 +117,7 @@ class HparaOptz:
 
     # ---- history (GpParaDef.py:20-65, 67-113, 219-284) -----------------------------------------------------------
     _HIST_1D = ('hp_varK_all', 'hp_var_fval_all', 'hp_var_fgrad_all', 'hp_kernel_all', 'min_nugget_all', 'Kcov_cond_all',
-                'eta_Kbase_all', 'eta_Kgrad_all', 'hp_optz_success', 'hp_optz_iter_mean', 'hp_optz_iter_max',
+                'eta_Kbase_all', 'eta_Kgrad_all', 'vmin_init_all', 'vmin_req_grad_all', 'hp_optz_success', 'hp_optz_iter_mean', 'hp_optz_iter_max',
                 'hp_optz_con_good', 'optz_n_cho_fail_all', 'optz_n_cond2big_all', 'optz_max_init_cond_all',
                 'time_pick_hp0_all', 'time_hp_optz_all', 'time_chofac_all', 'var_fval', 'varK_var_fval')
 
@@ -129,12 +129,14 @@ class HparaOptz:
         for name in self._HIST_1D:
             setattr(self, name, np.full(n_optz_max, np.nan))
         self.Kcov_cond_at_max_all = np.full(n_optz_max, False, dtype=bool)
+        self.xvec_rescaling_all = np.full((n_optz_max, self.dim), np.nan)
 
     def finish_optz_surr(self, n_optz_final):
         assert self._save_data, 'If the method init_optz_surr has not been called, then finish_optz_surr cannot be used'
         idx = n_optz_final
         self.hp_beta_all = self.hp_beta_all[:idx, :]
         self.hp_theta_all = self.hp_theta_all[:idx, :]
+        self.xvec_rescaling_all = self.xvec_rescaling_all[:idx]
         for name in self._HIST_1D + ('Kcov_cond_at_max_all',):
             setattr(self, name, getattr(self, name)[:idx])
 
@@ -158,6 +160,10 @@ class HparaOptz:
         self.Kcov_cond_at_max_all[idx] = cond_val >= (0.99 * self.cond_max)
         self.eta_Kbase_all[idx] = self._eta_Kbase
         self.eta_Kgrad_all[idx] = self._eta_Kgrad
+        self.vmin_init_all[idx] = self._vmin_init                                # GpParaDef.py:254-258
+        self.vmin_req_grad_all[idx] = self._vmin_req_grad
+        if self.b_use_data_scl:
+            self.xvec_rescaling_all[idx] = self.DataScl.xvec_scale
         if surr_optz_info is not None:
             for key in ('hp_optz_success', 'hp_optz_iter_mean', 'hp_optz_iter_max', 'hp_optz_con_good'):
                 if key in surr_optz_info:
@@ -421,10 +427,12 @@ class HparaOptz:
                           'hp_optz_iter_max': np.max(all_total_fun_iter), 'hp_optz_con_good': np.mean(all_con_good),
                           'optz_n_cho_fail': n_cho_fail, 'optz_n_cond2big': n_cond2big, 'optz_max_init_cond': max_init_cond}
         self.optz_obj_all_last, self.optz_sol_all_last = optz_obj_all, optz_sol_all
-        cond_val = np.nan
-        if self.b_use_cond_cstr:                                                 # final condition number, OptzLkd.py:324-331
-            cond_val = self.calc_lkd_all(self.hp_vec2dataclass(self.hp_info_optz_lkd, best_hp), calc_cond=True)[0].cond
-        return best_hp, cond_val, surr_optz_info
+        return best_hp, self._final_cond(best_hp), surr_optz_info
+
+    def _final_cond(self, best_hp):
+        """Condition number of the matrix the selected hyperparameters give, for every well-conditioning method
+        (OptzLkd.py:324-331)."""
+        return self.calc_lkd_all(self.hp_vec2dataclass(self.hp_info_optz_lkd, best_hp), calc_cond=True)[0].cond
 
     def _run_starts_lockstep(self, hp_x0_all, lo, hi, optz_bound, optz_opt, sol, obj, success, nit):
         """Starts [lo, hi) as concurrent SLSQP runs served by batched value + gradient calls (_LockstepObjective).
@@ -465,23 +473,58 @@ class HparaOptz:
         theta = self.hp_theta_init * np.ones(self.dim)
         beta = np.zeros(self.n_beta_coeff)
         if self.n_beta_coeff > 0:
-            beta[0] = np.mean(self._fval_in)
+            beta[0] = np.mean(self.get_scl_eval_data()[0])                    # GpHparaOptz.py:201,206
         hp_var_fval = None if self.known_eps_fval else self.hp_var_fval_init
         hp_var_fgrad = None if (self.use_grad is False) or self.known_eps_fgrad else self.hp_var_fgrad_init
         return self.make_hp_class(beta, theta, self.hp_kernel_default, self.hp_varK_init, hp_var_fval, hp_var_fgrad)
 
+    def optz_hp_max_lkd_mtd_rescale(self, i_optz, hp_x0, optz_bound):
+        """OptzLkd.py:114-185: the rescale methods' outer loop.  After the multi-start optimisation, up to cond_vreq_max_iter
+        proposals of an anisotropic scaling are made from the optimised theta (rescaling_data_w_theta_sol); each but the last
+        is followed by a re-optimisation from the isotropic theta it predicts.  The proposal closest to the line
+        theta_1 = ... = theta_d wins: its scale vector goes into DataScl (the device data are re-sent) and its isotropic theta
+        replaces the optimised one.  As in the reference, the scaled data stay as they are while the loop runs."""
+        assert 'rescale' in self.wellcond_mtd, \
+            f'Method should only be called for the rescale methods, but it is wellcond_mtd = {self.wellcond_mtd}'
+        best_hp, cond_val, surr_optz_info = self.optz_hp_max_lkd(hp_x0, optz_bound)
+        if self.n_eval <= 1:
+            return best_hp, cond_val, surr_optz_info
+        max_iter = self.cond_vreq_max_iter
+        idx_theta = self.hp_info_optz_lkd.idx_theta
+        theta_all = np.full((max_iter, self.dim), np.nan)
+        dist2line_all = np.full(max_iter, np.nan)
+        scale_vec_all = np.full((max_iter, self.dim), np.nan)
+        theta_x0 = best_hp[idx_theta]
+        for cnt in range(max_iter):
+            theta_x0, dist2line, scale_new = self.rescaling_data_w_theta_sol(self.DataScl.x_scl, self.DataScl.xvec_scale, theta_x0)
+            theta_all[cnt], dist2line_all[cnt], scale_vec_all[cnt] = theta_x0, dist2line, scale_new
+            if cnt == max_iter - 1 or dist2line < self.cond_vreq_iter_tol:
+                break
+            x0 = np.copy(best_hp)
+            x0[idx_theta] = theta_x0
+            best_hp, cond_val = self.optz_hp_max_lkd(x0, optz_bound)[:2]
+        pick = int(np.nanargmin(dist2line_all))
+        self.DataScl.set_xscale_data(xvec_scale_in=scale_vec_all[pick])
+        best_hp_final = np.copy(best_hp)
+        best_hp_final[idx_theta] = theta_all[pick]
+        return best_hp_final, cond_val, surr_optz_info
+
     def optz_hp(self, i_optz):
-        if 'rescale' in self.wellcond_mtd:
-            raise NotImplementedError('rescale well-conditioning methods are outside the accelerated path')
         if self.n_eval <= self.hp_const_n_eval:
             hp_vals = self.get_init_hp_vals()
-            surr_optz_info, cond_val = None, np.nan
+            surr_optz_info = None
+            # GpHparaOptz.py:155-156: the condition number of the matrix these fixed hyperparameters give (the device needs the
+            # factor for it, which the reference's dense SVD does not)
+            cond_val = self.calc_all_K_w_chofac(None, hp_vals, calc_chofac=True, calc_cond=True)[4]
             time_hp_optz = time_chofac = time_pick_hp0 = 0
         else:
             self._time_chofac = 0
             hp_x0, optz_bound, time_pick_hp0 = self.select_hp_optz_x0(i_optz, self.hp_info_optz_lkd)
             start_time = time.time()
-            hp_optz, cond_val, surr_optz_info = self.optz_hp_max_lkd(hp_x0, optz_bound)
+            if ('rescale' in self.wellcond_mtd) and (self.cond_vreq_max_iter > 1):                    # GpHparaOptz.py:169-172
+                hp_optz, cond_val, surr_optz_info = self.optz_hp_max_lkd_mtd_rescale(i_optz, hp_x0, optz_bound)
+            else:
+                hp_optz, cond_val, surr_optz_info = self.optz_hp_max_lkd(hp_x0, optz_bound)
             time_hp_optz = time.time() - start_time
             time_chofac = self._time_chofac
             hp_vals = self.hp_vec2dataclass(self.hp_info_optz_lkd, hp_optz)

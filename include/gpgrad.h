@@ -103,7 +103,7 @@ int gpg_lkd_grad(gpg_ctx* ctx, const gpg_hp* hp, gpg_lkd_out* out, double* g_aa,
 /* Replaces the serial restart loop of GpHparaX0.select_hp_optz_x0 (GpHparaX0.py:33-59) on ONE
  * device: m hyperparameter rows, hp_rows [m, row_len] with row = [theta(d), varK_mat, var_fval,
  * var_fgrad (, hp_kernel if row_len >= d + 4: alpha of GPG_KERNEL_RATQU)] already decoded from log10
- * (GpHpara.py:56-103); eta / wellcond / closed_form_varK are shared.  out [m].  Rows whose factorisation fails get info > 0 and NaN ln_lkd (GpHparaX0.py:34,
+ * (GpHpara.py:56-103); eta / wellcond / closed_form_varK are shared (row_len > dim + 4: column dim + 4 carries a nugget per row instead).  out [m].  Rows whose factorisation fails get info > 0 and NaN ln_lkd (GpHparaX0.py:34,
  * 43-45).  Returns 0 unless an argument / runtime error occurred.  All m evaluations are queued on
  * the stream back-to-back and synchronised once. */
 int gpg_lkd_batch(gpg_ctx* ctx, int m, const double* hp_rows, int row_len, double eta, int wellcond,
@@ -204,6 +204,17 @@ int gpg_kern_rtensor(int device, int kernel, int dim, int n1, int n2, const doub
  * The host side runs a Lanczos iteration on these two operators to get lambda_max and 1 / lambda_min
  * (gpgradpy_amd/cond_number.py; replaces np.linalg.cond of an N x N matrix). */
 int gpg_factor_apply(gpg_ctx* ctx, int op, const double* v, double* out);
+
+/* The reference's matrix-dependent nugget (cond_eta_is_const = False, i.e. wellcond_mtd 'rescale_eta_vary'; Kernel.py:229-236,
+ * 269-276): rowsum[i] = sum_j |M_ij| over the N rows of M = Kcor = P^-1 (K + diag(noise / varK)) P^-1 (wellcond PRECON) or of the
+ * kernel matrix K itself (BASE), host [N]; hp->eta is ignored.  The caller takes argmax / max and sets
+ * eta = rowsum[argmax] / (cond_max_target - 1) in the gpg_hp of the evaluation that follows. */
+int gpg_abs_rowsum(gpg_ctx* ctx, const gpg_hp* hp, double* rowsum);
+
+/* eta >= 0: the derivatives d Kcov / d hp_k (gpg_lkd_grad, gpg_lkd_grad_batch, gpg_dcov_quadform, gpg_cond_fro) are formed with
+ * this nugget instead of gpg_hp.eta -- the reference differentiates with self._etaK even when the matrix was built with the
+ * row-sum nugget above (GpHparaGrad.py:43,107,126).  eta < 0 (default): use gpg_hp.eta. */
+int gpg_set_gradient_nugget(gpg_ctx* ctx, double eta);
 
 /* out[k] = v^T (d Kcov / d hp_k) v for the dim + 4 hyperparameter slots of gpg_lkd_grad (theta, varK, var_fval,
  * var_fgrad, hp_kernel), v host [N]; call after a successful gpg_lkd / gpg_setup_eval with the same hp (it uses that

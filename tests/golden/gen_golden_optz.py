@@ -79,6 +79,12 @@ def run_case(GaussianProcess, name, n, d, kernel, noise, seed, n_hist=2, start_m
         GP.set_data(x[:ni], f[:ni], None if std_f is None else std_f[:ni], g[:ni], None if std_g is None else std_g[:ni])
         hp_x0_all, bounds = GP.get_hp_x0_lhs_median(it, GP.hp_info_optz_lkd, n_best if start_mtd == 'hp_best' else 3)
         hp_x0_sel, _, _ = GP.select_hp_optz_x0(it, GP.hp_info_optz_lkd)
+        if GP.b_use_data_scl:                                  # objective, constraint and their gradients at the start rows
+            vals = [GP.calc_store_likelihood(np.copy(r)) for r in hp_x0_sel]
+            out[f'it{it}_x0_obj'] = np.array([v[0] for v in vals], dtype=float)
+            out[f'it{it}_x0_grad'] = np.array([v[1] for v in vals], dtype=float)
+            out[f'it{it}_x0_cond'] = np.array([v[2] for v in vals], dtype=float)
+            out[f'it{it}_x0_cond_grad'] = np.array([np.real(v[3]) for v in vals], dtype=float)
         GP.set_hpara('optz', it)
         hv = GP.hp_vals
         vec = GP.hp_theta_all[it]
@@ -98,6 +104,8 @@ def run_case(GaussianProcess, name, n, d, kernel, noise, seed, n_hist=2, start_m
         out[f'it{it}_ln_lkd'] = GP.calc_lkd_all(hp_final)[0].ln_lkd
         out[f'it{it}_iter_max'] = GP.hp_optz_iter_max[it]
         out[f'it{it}_success'] = GP.hp_optz_success[it]
+        if GP.b_use_data_scl:                                  # rescale methods: the scaling the outer loop ended with (OptzLkd.py:176)
+            out[f'it{it}_xvec_scale'] = np.array(GP.DataScl.xvec_scale, dtype=float)
         print(f"{name} it{it}: n={ni} theta={hv.theta} varK={hv.varK:.6e} ln_lkd={out[f'it{it}_ln_lkd']:.10e} nit={GP.hp_optz_iter_max[it]}")
     out.update(wellcond=wellcond, cond_hist=GP.Kcov_cond_all[:n_hist + 1], con_good_hist=GP.hp_optz_con_good[:n_hist + 1])
     out.update(name=name, n=n, d=d, kernel=kernel, noise=noise, x=x, f=f, g=g, n_hist=n_hist, start_mtd=start_mtd, n_best=n_best,
@@ -111,6 +119,12 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == 'base':       # 'base' well-conditioning: SLSQP with the condition-number constraint
         run_case(GaussianProcess, 'optz_SqExp_none_n12_d2_base', 12, 2, 'SqExp', 'none', seed=37, wellcond='base')
         run_case(GaussianProcess, 'optz_Ma5f2_known_n10_d2_base_lhs', 10, 2, 'Ma5f2', 'known', seed=38, wellcond='base', start_mtd='lhs')
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == 'rescale':    # data-rescaling methods: constraint + the outer rescale loop (OptzLkd.py:114-185)
+        run_case(GaussianProcess, 'optz_SqExp_none_n12_d2_rescale_origin', 12, 2, 'SqExp', 'none', seed=41, wellcond='rescale_origin', start_mtd='lhs')
+        run_case(GaussianProcess, 'optz_Ma5f2_known_n10_d2_rescale_eta_vary', 10, 2, 'Ma5f2', 'known', seed=42, wellcond='rescale_eta_vary', start_mtd='lhs')
+        run_case(GaussianProcess, 'optz_SqExp_none_n10_d3_dflt_vmin', 10, 3, 'SqExp', 'none', seed=43, wellcond='dflt_vmin', start_mtd='lhs')
+        run_case(GaussianProcess, 'optz_SqExp_none_n12_d2_rescale_eta_vary', 12, 2, 'SqExp', 'none', seed=44, wellcond='rescale_eta_vary', start_mtd='lhs')
         return
     if len(sys.argv) > 1 and sys.argv[1] == 'ratqu':      # only the rational quadratic case (kernel with its own hyperparameter)
         run_case(GaussianProcess, 'optz_RatQu_none_n12_d2', 12, 2, 'RatQu', 'none', seed=36)

@@ -113,8 +113,6 @@ def test_out_of_scope_features_raise():
     assert GPr.kernel_has_hp and GPr.hp_kernel_default == 2 and GPr.hp_kernel_range == [1e-3, 10]   # KernelRatQuad.py:849-850
     with pytest.raises(Exception):
         gpgradpy_amd.GaussianProcess(2, True, 'Cubic')                  # Kernel.py:108-109
-    with pytest.raises(NotImplementedError):
-        gpgradpy_amd.GaussianProcess(2, True, 'SqExp', 'rescale_origin')
     with pytest.raises(AssertionError):
         gpgradpy_amd.GaussianProcess(2, True, 'SqExp', 'req_vmin')      # rejected like GaussianProcess.py:194
     GP = _gp_host_only(2, 'SqExp', 4, 'none')

@@ -84,10 +84,56 @@ def test_lhs_sample_is_a_latin_hypercube():
     np.testing.assert_array_equal(s, lhs_sample(lim, 8, seed=1))
 
 
+# 'rescale_eta_vary': the nugget follows the largest absolute row sum of the matrix (Kernel.py:272-274) while the reference's
+# gradient is formed with the constant one and without d eta / d theta (GpHparaGrad.py:43,107,126): value and gradient of the
+# objective are inconsistent by construction, SLSQP ends where its line search gives up (the reference itself stops at
+# maxiter = 250 on these fixtures), and where that is depends on the last digits.  Same optimum, loosely:
+LOOSE = dict(ln=2e-5, log_theta=5e-2, varK=0.3, beta=0.05)
+TIGHT = dict(ln=1e-6, log_theta=2e-3, varK=5e-3, beta=1e-3)
+# One start row of this fixture sits on a knife edge of SciPy's SLSQP itself (test_slsqp_knife_edge_start below): with the
+# device's value / gradient / constraint -- equal to the reference's to 1e-9 -- it returns the start row after five internal
+# resets, with the reference's it walks away.  Only the objective, the constraint and their gradients at the start rows are
+# compared there, not the end point.
+KNIFE_EDGE = {"optz_Ma5f2_known_n10_d2_rescale_eta_vary"}
+
+
+def test_slsqp_knife_edge_start():
+    """SciPy's SLSQP on a quadratic model with the value, gradient, constraint value and normal the device returns at the
+    first start row of optz_Ma5f2_known_n10_d2_rescale_eta_vary (constraint cond <= 1e10 with cond = 4.4e3: a row of size
+    1e10 next to rows of size 1e4 in its least-squares subproblem).  With those doubles it gives up at the start (exit mode 0
+    after five resets of its BFGS matrix, one function evaluation); under relative perturbations of 1e-9 -- the distance
+    between the device's numbers and the reference's -- it sometimes does that and sometimes optimises.  The end point of
+    that run is therefore not a parity quantity."""
+    from scipy.optimize import Bounds, NonlinearConstraint, minimize
+    x0 = np.array([-2.0236432494005134, -0.9009273926518704, 0.7116807745607323])
+    g0 = np.array([-588094.1471715198, -25838.366936885934, -391453.5925336131])
+    a0 = np.array([1893.8772371252585, 14391.164314234225, -4228.991981818278])        # minus the constraint gradient
+    c0 = 1e10 - 9.999995635674828e+09
+    f0 = 223203.32543576293
+
+    def run(g, a, c):
+        res = minimize(lambda z: f0 + g @ (z - x0) + 0.5e5 * np.sum((z - x0) ** 2), x0, jac=lambda z: g + 1e5 * (z - x0),
+                       method='SLSQP', bounds=Bounds([-7, -7, -5], [3, 3, 5], keep_feasible=True),
+                       constraints=NonlinearConstraint(lambda z: c - a @ (z - x0), -np.inf, 1e10, jac=lambda z: -a),
+                       options={'ftol': 1e-12, 'eps': 1e-12, 'maxiter': 250, 'disp': False})
+        return res.nfev == 1 and float(np.abs(res.x - x0).max()) == 0.0
+
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert run(g0, a0, c0)                                    # the device's numbers: stalls
+        rng = np.random.default_rng(0)
+        stalls = sum(run(g0 * (1 + 1e-9 * rng.standard_normal(3)), a0 * (1 + 1e-9 * rng.standard_normal(3)),
+                         c0 * (1 + 1e-9 * rng.standard_normal())) for _ in range(60))
+    assert 5 <= stalls <= 55, stalls                              # both outcomes, neither rare
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("path", OPTZ_CASES, ids=lambda p: os.path.basename(p)[:-4])
 def test_optz_hp_flow_matches_reference(path):
     c = _load(path)
+    T = LOOSE if str(c.get("wellcond", "precon")) == "rescale_eta_vary" else TIGHT
+    knife = os.path.basename(path)[:-4] in KNIFE_EDGE
     GP = _new_gp(c)
     sf, sg = _noise_args(c, 1)
     GP.set_data(c["x"][:1], c["f"][:1], sf, c["g"][:1], sg)
@@ -99,7 +145,18 @@ def test_optz_hp_flow_matches_reference(path):
         GP.set_data(c["x"][:ni], c["f"][:ni], sf, c["g"][:ni], sg)
         hp_x0_sel, bounds, _ = GP.select_hp_optz_x0(it, GP.hp_info_optz_lkd)
         # iteration 1 starts from the shared initial history; later rows descend from this run's own optimum
-        np.testing.assert_allclose(hp_x0_sel, c[f"it{it}_hp_x0_sel"], rtol=1e-12 if it == 1 else 1e-5, atol=1e-13 if it == 1 else 1e-5)
+        if knife and it > 1:
+            break                                                # later start rows descend from this run's own (different) optimum
+        np.testing.assert_allclose(hp_x0_sel, c[f"it{it}_hp_x0_sel"], rtol=1e-12 if it == 1 else 1e-5,
+                                   atol=1e-13 if it == 1 else (1e-5 if T is TIGHT else T["log_theta"]))
+        if f"it{it}_x0_obj" in c and it == 1:                    # rescale fixtures: objective / constraint and gradients at the start rows
+            for r, o, g, cv, cg in zip(hp_x0_sel, c[f"it{it}_x0_obj"], c[f"it{it}_x0_grad"], c[f"it{it}_x0_cond"], c[f"it{it}_x0_cond_grad"]):
+                GP._last_hp_vec = None
+                got = GP.calc_store_likelihood(np.copy(r))
+                assert np.isclose(got[0], o, rtol=1e-7), (got[0], o)
+                np.testing.assert_allclose(got[1], g, rtol=1e-5, atol=1e-6 * np.abs(g).max())
+                assert np.isclose(got[2], cv, rtol=1e-5), (got[2], cv)
+                np.testing.assert_allclose(got[3], cg, rtol=1e-3, atol=1e-4 * np.abs(cg).max())
         GP.set_hpara('optz', it)
         hv = GP.hp_vals
         # the posterior is set up from the optimum (GaussianProcess.py:394-395)
@@ -109,19 +166,28 @@ def test_optz_hp_flow_matches_reference(path):
         hp_final = GP.make_hp_class(theta=hv.theta, kernel=hv.kernel, varK=hv.varK if GP.b_has_noisy_data else None,
                                     var_fval=hv.var_fval, var_fgrad=hv.var_fgrad)
         ln_here = GP.calc_lkd_all(hp_final)[0].ln_lkd
+        if knife:
+            assert np.isfinite(ln_here) and GP.Kcov_cond_all[it] <= 1.01 * GP.cond_max
+            continue
         # the same local optimum: objective equal to 1e-6 relative, log10(theta) to 1e-3
-        assert abs(ln_here - ln_ref) <= 1e-6 * abs(ln_ref) + 1e-6, (it, ln_here, ln_ref)
-        np.testing.assert_allclose(np.log10(hv.theta), np.log10(c[f"it{it}_theta"]), atol=2e-3)
+        assert abs(ln_here - ln_ref) <= T["ln"] * abs(ln_ref) + 1e-6, (it, ln_here, ln_ref)
+        np.testing.assert_allclose(np.log10(hv.theta), np.log10(c[f"it{it}_theta"]), atol=T["log_theta"])
         if GP.kernel_has_hp:      # RatQu: alpha is optimised too (here with central differences of the device likelihood)
             np.testing.assert_allclose(np.log10(hv.kernel), np.log10(c[f"it{it}_kernel"]), atol=2e-3)
-        assert np.isclose(hv.varK, c[f"it{it}_varK"], rtol=5e-3)
-        assert np.isclose(hv.beta[0], c[f"it{it}_beta"][0], rtol=1e-3, atol=1e-6 * max(1.0, abs(c[f"it{it}_beta"][0])))
+        assert np.isclose(hv.varK, c[f"it{it}_varK"], rtol=T["varK"])
+        assert np.isclose(hv.beta[0], c[f"it{it}_beta"][0], rtol=T["beta"], atol=1e-6 * max(1.0, abs(c[f"it{it}_beta"][0])))
+        if f"it{it}_xvec_scale" in c:                              # the scaling the rescale loop ended with (OptzLkd.py:176)
+            np.testing.assert_allclose(GP.DataScl.xvec_scale, c[f"it{it}_xvec_scale"], rtol=1e-3 if T is TIGHT else 0.1)
+            np.testing.assert_allclose(GP.xvec_rescaling_all[it], GP.DataScl.xvec_scale)
+        if T is LOOSE:
+            continue
         assert GP.hp_optz_success[it] == c[f"it{it}_success"]
         if str(c.get("wellcond", "precon")) != "precon":       # SLSQP ran with the condition-number constraint
             assert GP.hp_optz_con_good[it] == c["con_good_hist"][it]
             assert np.isclose(GP.Kcov_cond_all[it], c["cond_hist"][it], rtol=1e-3) and GP.Kcov_cond_all[it] <= 1.01 * GP.cond_max
-    GP.set_hpara('stored', 1)
-    np.testing.assert_allclose(GP.hp_vals.theta, GP.hp_theta_all[1])
+    if not GP.b_use_data_scl:      # 'stored' on rescaled data would pair old hyperparameters with the current scaling
+        GP.set_hpara('stored', 1)
+        np.testing.assert_allclose(GP.hp_vals.theta, GP.hp_theta_all[1])
 
 
 @pytest.mark.gpu
