@@ -293,6 +293,12 @@ __global__ void __launch_bounds__(256, 2) tile_chol_kernel(TileCholArgs) {
 // potrf64 is still running), L21 (flag_c, after its 64-row solve), L22 in four pieces (pb[0..3]): every column block of
 // this tile is substituted piece by piece, and the MFMA update of block 1 runs while the diagonal tile is still in its
 // second potrf64.
+#ifdef GPG_STAMP
+__shared__ unsigned long long* t128_fo;      // finalisation record of the running task (thread 0 writes and reads it)
+#define GPG_FS2(k) if (threadIdx.x == 0 && t128_fo) t128_fo[k] = __builtin_amdgcn_s_memrealtime();
+#else
+#define GPG_FS2(k)
+#endif
 __device__ __forceinline__ int tile_solve_rows128(const double* L, int ldl, const double* dinv, double* X, int ldx, double* U,
                                                   double (*Ls)[4][18], double* sdinv, int* pa, int* flag_c, int* pb,
                                                   int* abort_word, int* info, int* sh) {
@@ -328,6 +334,7 @@ __device__ __forceinline__ int tile_solve_rows128(const double* L, int ldl, cons
   GPG_T128_PIECE(pa, L, 0, 1)
   GPG_T128_PIECE(pa, L, 0, 2)
   GPG_T128_PIECE(pa, L, 0, 3)
+  GPG_FS2(5)
   {
     double* Xr = X + rr + (size_t)q * ldx;
 #pragma unroll
@@ -337,6 +344,7 @@ __device__ __forceinline__ int tile_solve_rows128(const double* L, int ldl, cons
     }
   }
   if (!wg_wait_flag(flag_c, abort_word, info, sh)) return 0;   // barrier inside: X1 visible to the workgroup, Ls free
+  GPG_FS2(6)
   // ---- column block 1: T2 -= X1 L21^T for the two row halves, each transposed through the LDS tile ---------------
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
@@ -364,6 +372,7 @@ __device__ __forceinline__ int tile_solve_rows128(const double* L, int ldl, cons
     }
     __syncthreads();   // tile consumed before the next pass stages into U again
   }
+  GPG_FS2(7)
   {   // L22 in four pieces (pb[0..3]) while the diagonal tile is in its second potrf64
     const double* L22 = L + 64 + (size_t)64 * ldl;
     GPG_T128_PIECE(pb, L22, 64, 0)
@@ -406,6 +415,9 @@ __device__ __noinline__ int tile128_finalize(double* A, int ld, size_t r0, size_
 #define GPG_FS(k)
 #endif
   GPG_FS(0)
+#ifdef GPG_STAMP
+  if (tid == 0) t128_fo = is_diag ? nullptr : fo;
+#endif
   if (is_diag) {
     double* blk = A + cj + cj * (size_t)ld;
     double (*St)[64] = reinterpret_cast<double(*)[64]>(&Ls[0][0][0]);   // potrf scratch over the Ls region
@@ -687,6 +699,9 @@ tile128_trinv_task(int tix, const double* __restrict__ A, int ld, const double* 
       }
   __syncthreads();
   GPG_PRIO(2);
+#ifdef GPG_STAMP
+  if (tid == 0) t128_fo = nullptr;
+#endif
   // the diagonal tile of L is final: its piece flags are a constant array of ones
   if (!tile_solve_rows128(A + ci + ci * (size_t)ld, ld, dinv + ci, W + r0 + ci * (size_t)ldw, ldw, t128_U, t128_Ls, t128_sdinv, ones,
                           ones + 4, ones, abort_word, info, &sh_ok))
@@ -1230,14 +1245,38 @@ __global__ void __launch_bounds__(256) vec_solve_kernel(VecSolveArgs) {
   }
 }
 
-// Column-major task list of the dataflow factorisation (Mt tile columns, Rt >= Mt tile rows), cached per shape.
+// Ticket order of the factorisation's tasks (Mt tile columns, Rt >= Mt tile rows; B matrices interleaved).  Any order in which a
+// task comes after the tasks it reads is valid (progress argument at tile_chol_kernel); two are offered:
+//   order 0  tile column by tile column, rows top to bottom, the matrices of a batch interleaved column by column;
+//   order 1  the same with the critical path pulled forward: in tile column j the tile (j+1, j) comes first and the NEXT diagonal
+//            tile (j+1, j+1) right after it -- it only reads tile row j+1, which (j+1, j) completes -- then the rest of column j.
+//            The diagonal tile's potrf / L21 / syrk / potrf chain (~100 us under contention) then runs while column j is still in its
+//            MFMA loops, instead of after them with the whole column j+1 waiting for its pieces.
+template <typename F>
+static void for_each_chol_task(int Mt, int Rt, int B, int order, F emit /* (b, i, j) */) {
+  if (order == 0) {
+    for (int j = 0; j < Mt; ++j)
+      for (int b = 0; b < B; ++b)
+        for (int i = j; i < Rt; ++i) emit(b, i, j);
+    return;
+  }
+  for (int b = 0; b < B; ++b) emit(b, 0, 0);
+  for (int j = 0; j < Mt; ++j) {
+    const bool next_diag = j + 1 < Mt;
+    if (next_diag)
+      for (int b = 0; b < B; ++b) { emit(b, j + 1, j); emit(b, j + 1, j + 1); }
+    for (int b = 0; b < B; ++b)
+      for (int i = j + (next_diag ? 2 : 1); i < Rt; ++i) emit(b, i, j);
+  }
+}
+
+// Task list of the dataflow factorisation of one matrix, cached per shape and order.
 const TileMap& get_tile_tasks(gpg_ctx* c, int Mt, int Rt) {
-  const unsigned long long key = (1ull << 63) | ((unsigned long long)Mt << 20) | (unsigned)Rt;
+  const unsigned long long key = (1ull << 63) | ((unsigned long long)(c->task_order & 1) << 60) | ((unsigned long long)Mt << 20) | (unsigned)Rt;
   auto it = c->tilemaps.find(key);
   if (it != c->tilemaps.end()) return it->second;
   std::vector<int> list;
-  for (int j = 0; j < Mt; ++j)
-    for (int i = j; i < Rt; ++i) list.push_back(i | (j << 16));
+  for_each_chol_task(Mt, Rt, 1, c->task_order, [&](int, int i, int j) { list.push_back(i | (j << 16)); });
   TileMap tm;
   tm.n = (int)list.size();
   tm.dev = nullptr;
@@ -1305,13 +1344,11 @@ static void launch_tile_chol(gpg_ctx* c, int c0) {
 static void launch_tile_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a_stride, double* dinv_base, int d_stride,
                                    int* info_base) {
   const int Mt = c->Npad / 64, Rt = c->ld / 64;
-  const unsigned long long key = (2ull << 62) | ((unsigned long long)B << 40) | ((unsigned long long)Mt << 20) | (unsigned)Rt;
+  const unsigned long long key = (2ull << 62) | ((unsigned long long)(c->task_order & 1) << 60) | ((unsigned long long)B << 40) | ((unsigned long long)Mt << 20) | (unsigned)Rt;
   auto it = c->tilemaps.find(key);
   if (it == c->tilemaps.end()) {
     std::vector<int> list, bof;
-    for (int j = 0; j < Mt; ++j)
-      for (int b = 0; b < B; ++b)
-        for (int i = j; i < Rt; ++i) { list.push_back(i | (j << 16)); bof.push_back(b); }
+    for_each_chol_task(Mt, Rt, B, c->task_order, [&](int b, int i, int j) { list.push_back(i | (j << 16)); bof.push_back(b); });
     TileMap tm;
     tm.n = (int)list.size();
     if (!gpg_dev_alloc(c, &tm.dev, sizeof(int) * 2 * list.size())) return;
@@ -1354,13 +1391,11 @@ static void launch_tile128_chol(gpg_ctx* c) {
 static void launch_tile128_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a_stride, double* dinv_base, int d_stride,
                                       int* info_base) {
   const int Mt = c->Npad / 128, Rt = c->ld / 128;
-  const unsigned long long key = (2ull << 62) | (1ull << 61) | ((unsigned long long)B << 40) | ((unsigned long long)Mt << 20) | (unsigned)Rt;
+  const unsigned long long key = (2ull << 62) | (1ull << 61) | ((unsigned long long)(c->task_order & 1) << 60) | ((unsigned long long)B << 40) | ((unsigned long long)Mt << 20) | (unsigned)Rt;
   auto it = c->tilemaps.find(key);
   if (it == c->tilemaps.end()) {
     std::vector<int> list, bof;
-    for (int j = 0; j < Mt; ++j)
-      for (int b = 0; b < B; ++b)
-        for (int i = j; i < Rt; ++i) { list.push_back(i | (j << 16)); bof.push_back(b); }
+    for_each_chol_task(Mt, Rt, B, c->task_order, [&](int b, int i, int j) { list.push_back(i | (j << 16)); bof.push_back(b); });
     TileMap tm;
     tm.n = (int)list.size();
     if (!gpg_dev_alloc(c, &tm.dev, sizeof(int) * 2 * list.size())) return;
