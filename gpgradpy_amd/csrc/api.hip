@@ -114,6 +114,7 @@ static int ensure_scal(gpg_ctx* c, int slots) {
 // queue one likelihood evaluation; results land in scal[slot], info[slot]
 static void enqueue_lkd(gpg_ctx* c, const gpg_hp* hp, int slot) {
   AsmParams p = make_params(c, hp, 0);
+  c->alpha_valid = false;
   c->last_precon = p.precon;
   c->prep_valid = true;
   c->last_factor_ws = c->ws_cur;
@@ -371,6 +372,7 @@ static int gpg_lkd_grad_once(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out, dou
   if (solve_failure(c)) return -4;
   g_aa[c->d + 3] = g_inv[c->d + 3] = 0.0;                  // hp_kernel slot: RatQu only
   for (int k = 0; k < ns; ++k) { g_aa[k] = h[k]; g_inv[k] = h[ns + k]; }
+  c->alpha_valid = true;
   return 0;
 }
 
@@ -981,6 +983,19 @@ int gpg_abs_rowsum(gpg_ctx* c, const gpg_hp* hp, double* rowsum) {
   GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
   GPG_HIP_OK(c, hipGetLastError());
   GPG_LAUNCH_OK(c);
+  return 0;
+}
+
+int gpg_lkd_alpha(gpg_ctx* c, double* alpha) {
+  if (!c) return -1;
+  if (!alpha) { c->err = "alpha is NULL"; return -1; }
+  GPG_HIP_OK(c, hipSetDevice(c->device));
+  GPG_WS(c, 0);
+  if (!c->alpha_valid) { c->err = "gpg_lkd_alpha follows a successful gpg_lkd_grad (no other call on the context in between)"; return -1; }
+  gpg_launch_alpha(c, c->tmpv);
+  GPG_HIP_OK(c, hipMemcpyAsync(alpha, c->tmpv, sizeof(double) * c->N, hipMemcpyDeviceToHost, c->stream));
+  GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
+  GPG_HIP_OK(c, hipGetLastError());
   return 0;
 }
 

@@ -379,6 +379,7 @@ void launch_cross_d(gpg_ctx* c, const AsmParams& p, int nx, int nxp) {
 
 void gpg_launch_prep(gpg_ctx* c, const AsmParams& p, double var_fval, double var_fgrad, double s0, double t0,
                      double s1, double t1) {
+  if (c->ws_cur == 0) c->alpha_valid = false;   // invp of set 0 is rewritten
   hipLaunchKernelGGL(prep_diag_kernel, dim3((p.Npad + 255) / 256), dim3(256), 0, c->stream, p, c->noise, var_fval,
                      var_fgrad, c->dvec, c->invp, (const gpg_batch_item*)nullptr, (size_t)0);
   hipLaunchKernelGGL(prep_rows_kernel, dim3(p.Npad), dim3(256), 0, c->stream, p, c->y, c->invp, s0, t0, s1, t1, c->A,
@@ -399,6 +400,7 @@ void gpg_launch_assembly(gpg_ctx* c, const AsmParams& p) {
 // of them (shape only).  rhs rows as for a likelihood evaluation: row 0 = V P^-1, row 1 = y P^-1.
 void gpg_launch_prep_assembly_batch(gpg_ctx* c, const AsmParams& p, int B, const gpg_batch_item* items, size_t v_stride,
                                     size_t a_stride) {
+  c->alpha_valid = false;
   hipLaunchKernelGGL(prep_diag_kernel, dim3((p.Npad + 255) / 256, B), dim3(256), 0, c->stream, p, c->noise, 0.0, 0.0, c->dvec,
                      c->invp, items, v_stride);
   hipLaunchKernelGGL(prep_rows_kernel, dim3(p.Npad, B), dim3(256), 0, c->stream, p, c->y, c->invp, 1.0, 0.0, 0.0, 1.0, c->A,

@@ -68,6 +68,7 @@ struct gpg_ctx {
   int inv_tile64_cols = 4096;   // explicit inverse: W = L^-T on 64 x 64 tiles up to this many padded columns (0: always 128-tiles)
   int* tile_flags = nullptr;   // device: completion flags of the dataflow kernel + abort word + ticket counter
   int num_cus = 0;             // compute units of the device (grid of the persistent launches)
+  bool alpha_valid = false;    // zvec of workspace set 0 holds p * alpha of the last gpg_lkd_grad (gpg_lkd_alpha)
   int task_order = 0;          // ticket order of the dataflow factorisation (for_each_chol_task in cholesky_dataflow.hip)
   double grad_eta = -1.0;      // >= 0: nugget the hyperparameter derivatives are formed with instead of hp->eta (gpg_set_gradient_nugget)
   int max_workgroups = 0;      // > 0: cap on the grid of every persistent launch (gpg_set_max_workgroups; 0 = co-resident capacity)

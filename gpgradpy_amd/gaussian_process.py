@@ -192,6 +192,32 @@ class GaussianProcess(HparaOptz):
             return eta_Kbase, eta_Kbase * (self.dim + 1)
         raise Exception(f'Uknown method for cond_eta_set_mtd = {self.cond_eta_set_mtd}')
 
+    @staticmethod
+    def calc_grad_precon_matrix(n_eval, n_grad, gamma_grad_theta, b_return_vec):
+        """d pvec / d theta (KernelCommon.py:13-49): [n_data, dim] vectors or [dim, n_data, n_data] diagonal matrices; entry
+        (n_eval + i n_grad + a, i) = d gamma_i / d theta_i."""
+        dim = gamma_grad_theta.size
+        n_data = n_eval + n_grad * dim
+        cols = np.zeros((n_data, dim))
+        for i in range(dim):
+            cols[n_eval + i * n_grad:n_eval + (i + 1) * n_grad, i] = gamma_grad_theta[i]
+        if b_return_vec:
+            return cols
+        return np.stack([np.diag(cols[:, i]) for i in range(dim)])
+
+    def calc_Kern_precon(self, n_eval, n_grad, theta, calc_grad=False, b_return_vec=False):
+        """The preconditioner of the noise-free kernel matrix and its derivative with respect to theta -- sq_exp_Kern_precon
+        (KernelSqExp.py:590-605), matern_5f2_Kern_precon (KernelMatern5f2.py:664-679), rat_quad_Kern_precon
+        (KernelRatQuad.py:862-877): pvec = [1_n, gamma_1 1_ng, ..., gamma_d 1_ng].  Host arithmetic on O(N) numbers; the
+        device builds the same vector (with the noise of the data) inside its assembly."""
+        gamma = self.theta2gamma(np.asarray(theta, dtype=float))
+        pvec = np.hstack((np.ones(n_eval), np.kron(gamma, np.ones(n_grad))))
+        gamma_grad_theta = 5.0 / (6.0 * gamma) if self.kernel_type == 'Ma5f2' else 1 / gamma
+        grad_precon = self.calc_grad_precon_matrix(n_eval, n_grad, gamma_grad_theta, b_return_vec)
+        if b_return_vec:
+            return pvec, 1 / pvec, grad_precon
+        return np.diag(pvec), np.diag(1 / pvec), grad_precon
+
     # ---- rescaling method (GpWellCond.py:18-100; "A Non-intrusive Solution to the Ill-Conditioning Problem of the
     #      Gradient-Enhanced Gaussian Covariance Matrix for Gaussian Processes") ---------------------------------------
     calc_dist_min = staticmethod(calc_dist_min)                                   # CommonFun.py:16-34
@@ -692,8 +718,8 @@ class GaussianProcess(HparaOptz):
         if calc_grad and self.bvec_use_grad is not None and not np.all(self.bvec_use_grad):
             # the reference itself fails here (shape bug KernelSqExp.py:552-554): nothing to pin against
             raise NotImplementedError('likelihood gradient with a bvec_use_grad mask is not supported')
-        if calc_grad and not (lkd_use_adj_mtd is None or lkd_use_adj_mtd) and not self.lkd_use_adj_mtd:
-            raise NotImplementedError('only the adjoint gradient method is on the accelerated path')
+        if lkd_use_adj_mtd is None:
+            lkd_use_adj_mtd = self.lkd_use_adj_mtd                              # CalcLkd.py:292-293
         if calc_cond and self.cond_norm not in (2, 'fro'):
             raise Exception(f'cond_norm must be either 2 or "fro" but it is {self.cond_norm}')          # GpHparaCon.py:159
         noisy = self.b_has_noisy_data
@@ -729,6 +755,11 @@ class GaussianProcess(HparaOptz):
                         ev, evec = np.linalg.eigh(Kc)
                         cond_grad_fail = self._cond_grad_from_vectors(hp, cond_fail, ev[0], evec[:, -1], evec[:, 0])
             return LkdInfo(cond=cond_fail, cond_grad=cond_grad_fail), False
+        hp_beta_grad = None
+        if calc_grad and (noisy or not lkd_use_adj_mtd) and not self._skip_beta_grad:
+            # GpMeanFun.py:109-120 (the noisy path always passes K_grad_hp: CalcLkd.py:216-217); needs the state the gradient call
+            # left on the device, so before anything else runs there
+            hp_beta_grad = self._beta_grad_device(hp, hp_vals, varK_mat)
         cond = cond_grad = None
         if calc_cond and self.cond_norm == 'fro':                    # calc_cond_fronorm_w_grad (GpHparaCon.py:209-236)
             assert not (calc_grad and self.wellcond_mtd == 'precon'), \
@@ -754,30 +785,74 @@ class GaussianProcess(HparaOptz):
         ln_lkd = out.ln_lkd
         if not noisy:
             ln_lkd -= self.calc_lkd_varK_pnlt(out.varK, self._fval_scl)[0]        # CalcLkd.py:162,168
-        ln_lkd_grad = None
-        if calc_grad and calc_lkd:
-            # adjoint weights: CalcLkd.py:173-177 (noise-free), :233-235 (noisy)
+        ln_lkd_grad = hp_varK_grad = ln_det_grad = None
+        if calc_grad:
+            # adjoint weights: CalcLkd.py:173-177 (noise-free), :233-235 (noisy).  The direct method (lkd_use_adj_mtd = False,
+            # CalcLkd.py:69-86, 237-242) combines the same two contractions, alpha' G_k alpha and tr(Kcov^-1 G_k):
+            # hp_varK_grad = -alpha' G alpha / N (V' alpha = 0), ln_det_Kmat_grad = tr(Kcov^-1 G), and its ln_lkd_grad is the
+            # adjoint one term by term.
             if noisy:
                 s_aa = 0.5
             else:
                 s_aa = self.calc_lkd_varK_pnlt(out.varK, self._fval_scl)[1] / self.n_data + 1.0 / (2.0 * out.varK)
-            g_all = s_aa * g_aa + g_inv
-            hi, d = self.hp_info_optz_lkd, self.dim
-            ln_lkd_grad = np.zeros(hi.n_hp)
-            ln_lkd_grad[hi.idx_theta] = g_all[:d]
-            if hi.has_kernel:
-                ln_lkd_grad[hi.idx_kernel] = g_all[d + 3]
-            if hi.has_varK:
-                ln_lkd_grad[hi.idx_varK] = g_all[d]
-            if hi.has_var_fval:
-                ln_lkd_grad[hi.idx_var_fval] = g_all[d + 1]
-            if hi.has_var_fgrad:
-                ln_lkd_grad[hi.idx_var_fgrad] = g_all[d + 2]
-        info = LkdInfo(hp_beta=np.array([out.beta]), hp_varK=None if noisy else out.varK,
-                       ln_det_Kmat=out.ln_det if calc_lkd or not noisy else None,
-                       ln_lkd=ln_lkd if calc_lkd else None, ln_lkd_grad=ln_lkd_grad,
+            if calc_lkd:
+                ln_lkd_grad = self._slots_to_hp(s_aa * g_aa + g_inv)
+            if not lkd_use_adj_mtd:
+                ln_det_grad = self._slots_to_hp(-2.0 * g_inv) if calc_lkd else None
+                if not noisy:
+                    hp_varK_grad = self._slots_to_hp(-g_aa / self.n_data)
+        info = LkdInfo(hp_beta=np.array([out.beta]), hp_beta_grad=hp_beta_grad, hp_varK=None if noisy else out.varK,
+                       hp_varK_grad=hp_varK_grad, ln_det_Kmat=out.ln_det if calc_lkd or not noisy else None,
+                       ln_det_Kmat_grad=ln_det_grad, ln_lkd=ln_lkd if calc_lkd else None, ln_lkd_grad=ln_lkd_grad,
                        data_vec=self._data_vec if noisy else None, cond=cond, cond_grad=cond_grad)
         return info, True
+
+    _skip_beta_grad = False       # the optimiser's objective sets it: OptzLkd.py reads ln_lkd_grad / cond_grad only
+
+    def _slots_to_hp(self, g_all):
+        """The C ABI's gradient slots [theta(d), varK, var_fval, var_fgrad, hp_kernel] in hp_info_optz_lkd order."""
+        hi, d = self.hp_info_optz_lkd, self.dim
+        out = np.zeros(hi.n_hp)
+        out[hi.idx_theta] = g_all[:d]
+        if hi.has_kernel:
+            out[hi.idx_kernel] = g_all[d + 3]
+        if hi.has_varK:
+            out[hi.idx_varK] = g_all[d]
+        if hi.has_var_fval:
+            out[hi.idx_var_fval] = g_all[d + 1]
+        if hi.has_var_fgrad:
+            out[hi.idx_var_fgrad] = g_all[d + 2]
+        return out
+
+    def _beta_grad_device(self, hp, hp_vals, varK_mat):
+        """hp_beta_grad [1, n_hp] of calc_model_max_lkd_poly (GpMeanFun.py:109-120): beta_grad_k = term1 G_k term2 with
+        term1 = (V' K^-1 V)^-1 (K^-1 V)' =: u' and term2 = K^-1 V beta - K^-1 y = -alpha, i.e. -u' G_k alpha -- the polarisation of
+        the device's quadratic form v' G_k v (gpg_dcov_quadform) at u + alpha and u - alpha; K^-1 V through the factor on the
+        device (gpg_factor_apply), alpha from gpg_lkd_alpha.  Right after the gpg_lkd_grad call of calc_lkd_all."""
+        N, n = self.n_data, self.n_eval
+        alpha = np.empty(N)
+        rc = self._lib.gpg_lkd_alpha(self._ctx, _lib.as_dp(alpha))
+        if rc != 0:
+            raise _lib.GpgError(f'gpg_lkd_alpha failed ({rc}): {self._err()}')
+        pvec = np.ones(N)
+        if self.wellcond_mtd == 'precon':                                        # Kernel.py:224: sqrt(diag(K + noise / varK))
+            kd = np.ones(N)
+            kd[n:] = np.kron(self.theta2gamma(np.asarray(hp_vals.theta, dtype=float)) ** 2, np.ones(self.n_grad))
+            pvec = np.sqrt(kd + self.calc_noise_vec(hp_vals) / varK_mat)
+        V = np.zeros(N)
+        V[:n] = 1.0
+        w = np.empty(N)
+        rc = self._lib.gpg_factor_apply(self._ctx, 1, _lib.as_dp(np.ascontiguousarray(V / pvec)), _lib.as_dp(w))
+        if rc != 0:
+            raise _lib.GpgError(f'gpg_factor_apply failed ({rc}): {self._err()}')
+        KinvV = w / pvec
+        u = KinvV / (V @ KinvV)
+        q = np.zeros((2, self.dim + 4))
+        for i, v in enumerate((u + alpha, u - alpha)):
+            rc = self._lib.gpg_dcov_quadform(self._ctx, C.byref(hp), _lib.as_dp(np.ascontiguousarray(v)), _lib.as_dp(q[i]))
+            if rc != 0:
+                raise _lib.GpgError(f'gpg_dcov_quadform failed ({rc}): {self._err()}')
+        return -self._slots_to_hp((q[0] - q[1]) / 4.0)[None, :]
 
     def calc_lkd_varK_pnlt(self, varK, fval_vec):
         # CalcLkd.py:118-133 (noise-free path only, as in the reference: CalcLkd.py:204 leaves the noisy path out)

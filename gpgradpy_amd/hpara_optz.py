@@ -284,7 +284,11 @@ class HparaOptz:
         calc_store_likelihood (OptzLkd.py:47-83), without the memo."""
         hp_vals = self.hp_vec2dataclass(self.hp_info_optz_lkd, hp_vec)
         calc_cond = self.b_use_cond_cstr or always_calc_cond                   # OptzLkd.py:51
-        lkd_info, b_chofac_good = self.calc_lkd_all(hp_vals, calc_lkd=True, calc_cond=calc_cond, calc_grad=calc_grad)
+        self._skip_beta_grad = True                                            # hp_beta_grad is not read here
+        try:
+            lkd_info, b_chofac_good = self.calc_lkd_all(hp_vals, calc_lkd=True, calc_cond=calc_cond, calc_grad=calc_grad)
+        finally:
+            self._skip_beta_grad = False
         cond_val, cond_grad = lkd_info.cond, lkd_info.cond_grad
         if b_chofac_good:
             ln_lkd_val = lkd_info.ln_lkd

@@ -211,6 +211,13 @@ int gpg_factor_apply(gpg_ctx* ctx, int op, const double* v, double* out);
  * eta = rowsum[argmax] / (cond_max_target - 1) in the gpg_hp of the evaluation that follows. */
 int gpg_abs_rowsum(gpg_ctx* ctx, const gpg_hp* hp, double* rowsum);
 
+/* alpha = Kcov^-1 (y - V beta), host [N], of the most recent successful gpg_lkd_grad on this context (no likelihood call in between):
+ * with gpg_factor_apply and gpg_dcov_quadform it gives the remaining outputs of the reference's gradient code without the
+ * [n_hp, N, N] tensors -- hp_beta_grad_k = -u' G_k alpha with u = Kcov^-1 V / (V' Kcov^-1 V) (GpMeanFun.py:114-117, as the polarisation
+ * (q_k(u + alpha) - q_k(u - alpha)) / 4 of the quadratic form), hp_varK_grad_k = -alpha' G_k alpha / N (CalcLkd.py:112-113; V' alpha = 0),
+ * ln_det_Kmat_grad_k = tr(Kcov^-1 G_k) = -2 g_inv[k] (CalcLkd.py:361-365). */
+int gpg_lkd_alpha(gpg_ctx* ctx, double* alpha);
+
 /* eta >= 0: the derivatives d Kcov / d hp_k (gpg_lkd_grad, gpg_lkd_grad_batch, gpg_dcov_quadform, gpg_cond_fro) are formed with
  * this nugget instead of gpg_hp.eta -- the reference differentiates with self._etaK even when the matrix was built with the
  * row-sum nugget above (GpHparaGrad.py:43,107,126).  eta < 0 (default): use gpg_hp.eta. */
