@@ -960,6 +960,40 @@ int gpg_kern_rtensor(int device, int kernel, int dim, int n1, int n2, const doub
   return rc;
 }
 
+int gpg_kern_rtensor_grad_hp(int device, int kernel, int dim, int n, const double* rtensor, const double* theta, double hp_kernel, int use_grad,
+                             double* out_theta, double* out_alpha) {
+  if (!rtensor || !theta || (!out_theta && !out_alpha) || dim < 1 || dim > GPG_MAX_DIM || n < 1) { g_create_err = "bad gpg_kern_rtensor_grad_hp arguments (1 <= dim <= 16)"; return -1; }
+  if (kernel != GPG_KERNEL_SQEXP && kernel != GPG_KERNEL_MA5F2 && kernel != GPG_KERNEL_RATQU) { g_create_err = "unknown kernel id"; return -1; }
+  if (kernel == GPG_KERNEL_RATQU && !(hp_kernel > 0.0)) { g_create_err = "hp_kernel (alpha of RatQu) must be positive"; return -1; }
+  if (out_alpha && kernel != GPG_KERNEL_RATQU) { g_create_err = "There are no kernel hyperparameters for this kernel"; return -1; }   // KernelSqExp.py:125-127
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_create_err = "no HIP device visible"; return -2; }
+  if (device < 0 || device >= ndev) { g_create_err = "device index out of range"; return -1; }
+  const size_t N = use_grad ? (size_t)n * (dim + 1) : (size_t)n, nrt = (size_t)dim * n * n;
+  double *d_rt = nullptr, *d_th = nullptr, *d_al = nullptr;
+  hipStream_t st = nullptr;
+  int rc = 0;
+  auto fail = [&](const char* what, hipError_t e) { g_create_err = std::string(what) + ": " + hipGetErrorString(e); rc = -2; };
+  hipError_t e;
+  if ((e = hipSetDevice(device)) != hipSuccess) fail("hipSetDevice", e);
+  if (!rc && (e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) fail("hipStreamCreate", e);
+  if (!rc && (e = hipMalloc(&d_rt, sizeof(double) * nrt)) != hipSuccess) fail("hipMalloc(rtensor)", e);
+  if (!rc && out_theta && (e = hipMalloc(&d_th, sizeof(double) * dim * N * N)) != hipSuccess) fail("hipMalloc(out_theta)", e);
+  if (!rc && out_alpha && (e = hipMalloc(&d_al, sizeof(double) * N * N)) != hipSuccess) fail("hipMalloc(out_alpha)", e);
+  if (!rc && (e = hipMemcpyAsync(d_rt, rtensor, sizeof(double) * nrt, hipMemcpyHostToDevice, st)) != hipSuccess) fail("copy rtensor", e);
+  if (!rc && gpg_kern_rtensor_dhp_run(kernel, dim, n, use_grad ? 1 : 0, theta, hp_kernel, d_rt, d_th, d_al, st) != 0) {
+    g_create_err = "rtensor derivative kernel launch failed"; rc = -2;
+  }
+  if (!rc && out_theta && (e = hipMemcpyAsync(out_theta, d_th, sizeof(double) * dim * N * N, hipMemcpyDeviceToHost, st)) != hipSuccess) fail("copy out_theta", e);
+  if (!rc && out_alpha && (e = hipMemcpyAsync(out_alpha, d_al, sizeof(double) * N * N, hipMemcpyDeviceToHost, st)) != hipSuccess) fail("copy out_alpha", e);
+  if (!rc && (e = hipStreamSynchronize(st)) != hipSuccess) fail("hipStreamSynchronize", e);
+  if (d_rt) (void)hipFree(d_rt);
+  if (d_th) (void)hipFree(d_th);
+  if (d_al) (void)hipFree(d_al);
+  if (st) (void)hipStreamDestroy(st);
+  return rc;
+}
+
 int gpg_abs_rowsum(gpg_ctx* c, const gpg_hp* hp, double* rowsum) {
   int rc = check_hp(c, hp);
   if (rc) return rc;

@@ -441,6 +441,122 @@ void gpg_launch_cross(gpg_ctx* c, const AsmParams& p, int nx, int nxp) {
   else launch_cross_d<GPG_KERNEL_MA5F2>(c, p, nx, nxp);
 }
 
+// d K / d theta_k (and d K / d alpha for the rational quadratic kernel) of the kernel matrix of ONE point set with itself, from
+// its difference tensor -- calc_KernBase_grad_th / calc_KernGrad_grad_th / calc_Kern*_grad_alpha of the reference's kernel table
+// (KernelSqExp.py:91-123, 470-568; KernelMatern5f2.py:100-135, 532-642; KernelRatQuad.py:96-163, 640-840), materialised:
+// out_th [d, N, N], out_al [N, N], row-major, N = n (d + 1) with gradients.  One thread per point pair (a, b), R = x_a - x_b:
+// block (0, 0) is even in R, blocks (i+1, 0) odd -- block (0, i+1) at (a, b) is minus block (i+1, 0) at (a, b) -- blocks
+// (i+1, j+1) even and symmetric in (i, j).  The formulas are those of grad_contract_kernel (gradient.hip), which contracts the
+// same derivatives without storing them; the Matern-5/2 value block uses the exact derivative -(1/2) R_k^2 (5/3)(1 + sqrt5 nu) e^(-sqrt5 nu)
+// (the reference's gradient-free variant differentiates the exponential only, KernelMatern5f2.py:100-135: see tests/tolerances.py).
+template <int KERN>
+__global__ void __launch_bounds__(256) rtensor_kern_dhp_kernel(RtParams P, const double* __restrict__ Rt, double* __restrict__ out_th,
+                                                               double* __restrict__ out_al) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int n = P.n1, d = P.d;
+  const long long np = (long long)n * n;
+  if (t >= np) return;
+  const int a = (int)(t / n), b = (int)(t - (long long)a * n);
+  const size_t N = P.use_grad ? (size_t)n * (d + 1) : (size_t)n, NN = N * N;
+  double R[GPG_MAX_DIM], th[GPG_MAX_DIM];
+  double s = 0.0;
+  for (int k = 0; k < d; ++k) { R[k] = Rt[(size_t)k * np + t]; th[k] = P.theta[k]; s += th[k] * (R[k] * R[k]); }
+  const double sqrt5 = sqrt(5.0), al = P.hp_kernel;
+  // f0 = value, f1 / f2 / f3: the factors the first / second / third derivative levels multiply (E, M1, ... of gradient.hip)
+  double f0, f1 = 0.0, f2, f3 = 0.0, inu = 0.0, G0 = 0.0, G1 = 0.0, G2 = 0.0;
+  const double s1 = 1.0 + 1.0 / al, s2 = s1 * (1.0 + 2.0 / al), cq = 4.0 * s1, dcq = 4.0 / (al * al);
+  if (KERN == GPG_KERNEL_SQEXP) {
+    f2 = exp(-s); f0 = f2;
+  } else if (KERN == GPG_KERNEL_RATQU) {
+    const double Bq = 1.0 + s / al;
+    f0 = pow(Bq, -al); f1 = pow(Bq, -al - 1.0); f2 = pow(Bq, -al - 2.0); f3 = pow(Bq, -al - 3.0);
+    const double lnB = log(Bq), om = 1.0 - 1.0 / Bq;
+    G0 = -lnB + om; G1 = -lnB + s1 * om; G2 = -lnB + (1.0 + 2.0 / al) * om;
+  } else {
+    const double nu = sqrt(s);
+    f2 = exp(-sqrt5 * nu);
+    f1 = ((5.0 / 3.0) * (1.0 + sqrt5 * nu)) * f2;
+    f0 = (1.0 + sqrt5 * nu + (5.0 / 3.0) * (nu * nu)) * f2;
+    inu = 1.0 / fmax(nu, 1e-16);
+  }
+  auto put = [&](size_t r, size_t c, int k, double v) { out_th[(size_t)k * NN + r * N + c] = v; };
+  // ---- block (0, 0)
+  for (int k = 0; k < d; ++k) {
+    const double rk2 = R[k] * R[k];
+    if (out_th) put(a, b, k, KERN == GPG_KERNEL_SQEXP ? -rk2 * f2 : KERN == GPG_KERNEL_RATQU ? -rk2 * f1 : -0.5 * (rk2 * f1));
+  }
+  if (out_al) out_al[(size_t)a * N + b] = KERN == GPG_KERNEL_RATQU ? f0 * G0 : 0.0;
+  if (!P.use_grad) return;
+  for (int i = 0; i < d; ++i) {
+    const size_t ri = (size_t)(i + 1) * n + a, ci = (size_t)(i + 1) * n + b;
+    // ---- blocks (i+1, 0) and (0, i+1)
+    const double v = KERN == GPG_KERNEL_SQEXP ? ((-2.0 * th[i]) * R[i]) * f2 : KERN == GPG_KERNEL_RATQU ? ((-2.0 * th[i]) * R[i]) * f1 : ((-th[i]) * R[i]) * f1;
+    if (out_th)
+      for (int k = 0; k < d; ++k) {
+        const double rk2 = R[k] * R[k];
+        double dv;
+        if (KERN == GPG_KERNEL_SQEXP) dv = -rk2 * v + (k == i ? -2.0 * R[i] * f2 : 0.0);
+        else if (KERN == GPG_KERNEL_RATQU) dv = (2.0 * s1) * th[i] * R[i] * rk2 * f2 + (k == i ? -2.0 * R[i] * f1 : 0.0);
+        else dv = (25.0 / 6.0) * th[i] * R[i] * rk2 * f2 + (k == i ? -R[i] * f1 : 0.0);
+        put(ri, b, k, dv);
+        put(a, ci, k, -dv);
+      }
+    if (out_al) {
+      const double da = KERN == GPG_KERNEL_RATQU ? v * G1 : 0.0;
+      out_al[ri * N + b] = da;
+      out_al[(size_t)a * N + ci] = -da;
+    }
+    // ---- blocks (i+1, j+1) and (j+1, i+1), j <= i
+    for (int j = 0; j <= i; ++j) {
+      const size_t rj = (size_t)(j + 1) * n + a, cj = (size_t)(j + 1) * n + b;
+      const double rij = R[i] * R[j];
+      double w, daw = 0.0;
+      if (KERN == GPG_KERNEL_SQEXP) w = i == j ? (2.0 * th[i] - (4.0 * (th[i] * th[i])) * rij) * f2 : ((-4.0 * th[j]) * th[i]) * (rij * f2);
+      else if (KERN == GPG_KERNEL_RATQU) {
+        w = i == j ? (2.0 * th[i]) * f1 - ((cq * (th[i] * th[i])) * rij) * f2 : (((-cq) * th[j]) * th[i]) * rij * f2;
+        daw = (i == j ? (2.0 * th[i]) * f1 * G1 : 0.0) + (dcq - cq * G2) * th[i] * th[j] * rij * f2;
+      } else w = i == j ? th[i] * f1 - (((25.0 / 3.0) * (th[i] * th[i])) * rij) * f2 : ((((-(25.0 / 3.0)) * th[j]) * th[i]) * rij) * f2;
+      if (out_th)
+        for (int k = 0; k < d; ++k) {
+          const double rk2 = R[k] * R[k];
+          double dw;
+          if (KERN == GPG_KERNEL_SQEXP) {
+            dw = -rk2 * w;
+            if (i == j) dw += k == i ? (2.0 - 8.0 * th[i] * rij) * f2 : 0.0;
+            else dw += (k == i ? -4.0 * th[j] * rij * f2 : 0.0) + (k == j ? -4.0 * th[i] * rij * f2 : 0.0);
+          } else if (KERN == GPG_KERNEL_RATQU) {
+            dw = (4.0 * s2) * th[i] * th[j] * rij * rk2 * f3;
+            if (i == j) dw += -(2.0 * s1) * th[i] * rk2 * f2 + (k == i ? 2.0 * f1 - (8.0 * s1) * th[i] * rij * f2 : 0.0);
+            else dw += (k == i ? -(4.0 * s1) * th[j] * rij * f2 : 0.0) + (k == j ? -(4.0 * s1) * th[i] * rij * f2 : 0.0);
+          } else {
+            dw = ((25.0 * sqrt5 / 6.0) * th[i] * th[j]) * rij * rk2 * inu * f2;
+            if (i == j) dw += -((25.0 / 6.0) * th[i]) * rk2 * f2 + (k == i ? f1 - ((50.0 / 3.0) * th[i]) * rij * f2 : 0.0);
+            else dw += (k == i ? -((25.0 / 3.0) * th[j]) * rij * f2 : 0.0) + (k == j ? -((25.0 / 3.0) * th[i]) * rij * f2 : 0.0);
+          }
+          put(ri, cj, k, dw);
+          if (i != j) put(rj, ci, k, dw);
+        }
+      if (out_al) {
+        out_al[ri * N + cj] = daw;
+        if (i != j) out_al[rj * N + ci] = daw;
+      }
+    }
+  }
+}
+
+int gpg_kern_rtensor_dhp_run(int kernel, int d, int n, int use_grad, const double* theta, double hp_kernel, const double* rt_dev,
+                             double* out_th_dev, double* out_al_dev, hipStream_t stream) {
+  RtParams P;
+  memset(&P, 0, sizeof(P));
+  P.d = d; P.n1 = n; P.n2 = n; P.n1g = n; P.n2g = n; P.use_grad = use_grad; P.hp_kernel = hp_kernel > 0.0 ? hp_kernel : 1.0;
+  for (int k = 0; k < d; ++k) P.theta[k] = theta[k];
+  const dim3 grid((unsigned)(((long long)n * n + 255) / 256));
+  if (kernel == GPG_KERNEL_SQEXP) hipLaunchKernelGGL(rtensor_kern_dhp_kernel<GPG_KERNEL_SQEXP>, grid, dim3(256), 0, stream, P, rt_dev, out_th_dev, out_al_dev);
+  else if (kernel == GPG_KERNEL_RATQU) hipLaunchKernelGGL(rtensor_kern_dhp_kernel<GPG_KERNEL_RATQU>, grid, dim3(256), 0, stream, P, rt_dev, out_th_dev, out_al_dev);
+  else hipLaunchKernelGGL(rtensor_kern_dhp_kernel<GPG_KERNEL_MA5F2>, grid, dim3(256), 0, stream, P, rt_dev, out_th_dev, out_al_dev);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 // Host side of gpg_kern_rtensor (api.hip): device buffers are temporaries of the call.
 int gpg_kern_rtensor_run(int kernel, int d, int n1, int n2, int n1g, int n2g, int use_grad, const double* theta, double hp_kernel,
                          const double* rt_dev, const int* gpos1_dev, const int* gpos2_dev, double* out_dev, hipStream_t stream) {

@@ -653,6 +653,135 @@ class GaussianProcess(HparaOptz):
         """Kernel.py:116,122: calc_KernGrad when the model uses gradients, calc_KernBase otherwise."""
         return self.calc_KernGrad(Rtensor, theta, hp_kernel, *masks) if self.use_grad else self.calc_KernBase(Rtensor, theta, hp_kernel)
 
+    # ---- derivative tensors of the kernel table (Kernel.py:43-48, 69-75, 96-102, 119-125) and their compositions
+    #      (optz/GpHparaGrad.py): materialised for callers that want them; the likelihood gradient never forms them -----------
+    def _kern_grad_hp_tensors(self, Rtensor, theta, hp_kernel, use_grad, want_theta, want_alpha):
+        Rtensor = np.ascontiguousarray(Rtensor, dtype=np.float64)
+        assert Rtensor.ndim == 3, 'Rtensor must have the shape [dim, n1, n2]'
+        dim, n1, n2 = Rtensor.shape
+        assert n1 == n2, 'Incompatible shapes'                                   # KernelSqExp.py:500
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        assert theta.size == dim, 'theta must have dim entries'
+        N = n1 * (dim + 1) if use_grad else n1
+        out_th = np.empty((dim, N, N)) if want_theta else None
+        out_al = np.empty((1, N, N)) if want_alpha else None
+        alpha = 0.0
+        if self.kernel_has_hp:
+            assert hp_kernel is not None and not np.isnan(hp_kernel), 'this kernel needs its hyperparameter hp_kernel'
+            alpha = float(np.asarray(hp_kernel).reshape(-1)[0])
+        rc = self._lib.gpg_kern_rtensor_grad_hp(self.device, _lib.GPG_KERNEL[self.kernel_type], dim, n1, _lib.as_dp(Rtensor),
+                                                _lib.as_dp(theta), alpha, int(use_grad),
+                                                None if out_th is None else _lib.as_dp(out_th),
+                                                None if out_al is None else _lib.as_dp(out_al))
+        if rc != 0:
+            raise _lib.GpgError(f'gpg_kern_rtensor_grad_hp failed ({rc}): {self._lib.gpg_last_error(None).decode()}')
+        return out_th, out_al
+
+    def _no_kernel_hp(self):
+        name = {'SqExp': 'squared exponential', 'Ma5f2': 'Matern 5/2'}[self.kernel_type]
+        raise Exception(f'There are no kernel hyperparameters for the {name} kernel')        # KernelSqExp.py:126-127, KernelMatern5f2.py:138-139
+
+    @staticmethod
+    def _full_mask_only(bvec_use_grad):
+        if bvec_use_grad is not None and not np.all(bvec_use_grad):
+            # the reference's own arrays do not fit together with a mask (KernelSqExp.py:552-554): nothing to reproduce
+            raise NotImplementedError('hyperparameter derivatives of the kernel matrix with a bvec_use_grad mask are not supported')
+
+    def calc_KernBase_grad_th(self, Rtensor, theta, hp_kernel=None, *args):
+        """d KernBase / d theta_k, [dim, n, n] (sq_exp / matern_5f2 / rat_quad _calc_KernBase_grad_th), on the device.  Matern-5/2:
+        the exact derivative (the reference's differentiates the exponential factor only, see tests/tolerances.py)."""
+        return self._kern_grad_hp_tensors(Rtensor, theta, hp_kernel, False, True, False)[0]
+
+    def calc_KernGrad_grad_th(self, Rtensor, theta, hp_kernel=None, bvec_use_grad=None):
+        """d KernGrad / d theta_k, [dim, n (dim + 1), n (dim + 1)] (KernelSqExp.py:470-568, KernelMatern5f2.py:532-642,
+        KernelRatQuad.py:640-750), on the device."""
+        self._full_mask_only(bvec_use_grad)
+        return self._kern_grad_hp_tensors(Rtensor, theta, hp_kernel, True, True, False)[0]
+
+    def calc_KernBase_grad_alpha(self, Rtensor, theta, hp_kernel=None, *args):
+        """d KernBase / d alpha, [1, n, n], for the rational quadratic kernel (KernelRatQuad.py:133-163); the others have none."""
+        if not self.kernel_has_hp:
+            self._no_kernel_hp()
+        return self._kern_grad_hp_tensors(Rtensor, theta, hp_kernel, False, False, True)[1]
+
+    def calc_KernGrad_grad_alpha(self, Rtensor, theta, hp_kernel=None, bvec_use_grad=None):
+        """d KernGrad / d alpha, [1, N, N], for the rational quadratic kernel (KernelRatQuad.py:752-840)."""
+        if not self.kernel_has_hp:
+            self._no_kernel_hp()
+        self._full_mask_only(bvec_use_grad)
+        return self._kern_grad_hp_tensors(Rtensor, theta, hp_kernel, True, False, True)[1]
+
+    def calc_Kern_grad_theta(self, Rtensor, theta, hp_kernel=None, *args):
+        """Kernel.py:119-125: the gradient-enhanced or the gradient-free variant, as the model uses gradients or not."""
+        return self.calc_KernGrad_grad_th(Rtensor, theta, hp_kernel, *args) if self.use_grad else self.calc_KernBase_grad_th(Rtensor, theta, hp_kernel)
+
+    def calc_Kern_grad_alpha(self, Rtensor, theta, hp_kernel=None, *args):
+        return self.calc_KernGrad_grad_alpha(Rtensor, theta, hp_kernel, *args) if self.use_grad else self.calc_KernBase_grad_alpha(Rtensor, theta, hp_kernel)
+
+    def calc_KernGrad_hp(self, hp_optz_info, hp_vals, Rtensor, etaK=None):
+        """GpHparaGrad.py:13-68: derivative of the regularised kernel matrix of the noise-free path with respect to the optimised
+        hyperparameters, [n_hp, N, N]; 'precon' adds 2 eta gamma_i d gamma_i / d theta_i on the diagonal of the gradient blocks."""
+        assert hp_optz_info.has_varK is False, 'If has_varK is True, use, calc_Kcov_grad_hp()'
+        assert hp_optz_info.has_var_fval is False, 'If has_var_fval is True, use, calc_Kcov_grad_hp()'
+        assert hp_optz_info.has_var_fgrad is False, 'If has_var_fgrad is True, use, calc_Kcov_grad_hp()'
+        out = np.zeros((hp_optz_info.n_hp, self.n_data, self.n_data))
+        if hp_optz_info.has_theta:
+            out[hp_optz_info.idx_theta] = self.calc_Kern_grad_theta(Rtensor, hp_vals.theta, hp_vals.kernel, self.bvec_use_grad)
+            if self.wellcond_mtd == 'precon':
+                if etaK is None:
+                    etaK = self._etaK
+                pvec, _, grad_precon = self.calc_Kern_precon(self.n_eval, self.n_grad, hp_vals.theta, calc_grad=True, b_return_vec=True)
+                add = (2 * etaK) * pvec[self.n_eval:, None] * grad_precon[self.n_eval:, :]
+                idx = np.arange(self.n_eval, self.n_data)
+                for i in range(self.dim):
+                    out[hp_optz_info.idx_theta[i], idx, idx] += add[:, i]
+        if hp_optz_info.has_kernel:
+            out[hp_optz_info.idx_kernel] = self.calc_Kern_grad_alpha(Rtensor, hp_vals.theta, hp_vals.kernel, self.bvec_use_grad)
+        return out
+
+    def _plus_eta_diag(self, T):
+        """'precon': K -> K + eta diag(diag(K)) for every slice of a [m, N, N] derivative (GpHparaGrad.py:105-110, 119-126)."""
+        if self.wellcond_mtd == 'precon':
+            idx = np.arange(T.shape[1])
+            T[:, idx, idx] *= 1.0 + self._etaK
+        return T
+
+    def calc_Kcov_grad_theta(self, hp_vals, Rtensor):
+        varK = self.hp_varK if hp_vals.varK is None else hp_vals.varK                    # GpHparaGrad.py:100-111
+        return self._plus_eta_diag(varK * self.calc_Kern_grad_theta(Rtensor, hp_vals.theta, hp_vals.kernel, self.bvec_use_grad))
+
+    def calc_Kcov_grad_alpha(self, hp_vals, Rtensor):
+        varK = self.hp_varK if hp_vals.varK is None else hp_vals.varK                    # GpHparaGrad.py:113-126
+        return self._plus_eta_diag(varK * self.calc_Kern_grad_alpha(Rtensor, hp_vals.theta, hp_vals.kernel, self.bvec_use_grad))
+
+    def calc_Kcov_grad_varK(self, hp_vals, Kern):
+        eta = self._etaK                                                                 # GpHparaGrad.py:128-137
+        return Kern + eta * (np.diag(np.diag(Kern)) if self.wellcond_mtd == 'precon' else np.eye(Kern.shape[0]))
+
+    def calc_Kcov_grad_var_fval(self, hp_vals):
+        scalar = 1 + self._etaK if self.wellcond_mtd == 'precon' else 1                  # GpHparaGrad.py:139-146
+        return scalar * np.diag(np.hstack((np.ones(self.n_eval), np.zeros(self.n_grad * self.dim))))
+
+    def calc_Kcov_grad_var_fgrad(self, hp_vals):
+        scalar = 1 + self._etaK if self.wellcond_mtd == 'precon' else 1                  # GpHparaGrad.py:148-155
+        return scalar * np.diag(np.hstack((np.zeros(self.n_eval), np.ones(self.n_grad * self.dim))))
+
+    def calc_Kcov_grad_hp(self, hp_optz_info, hp_vals, Kern, Rtensor):
+        """GpHparaGrad.py:70-98: derivative of the covariance matrix of the noisy path, [n_hp, N, N]."""
+        assert hp_vals.varK is not None, 'The method calc_Kcov_grad_hp() only needs to be called if varK is a hyperparameter'
+        out = np.zeros((hp_optz_info.n_hp, self.n_data, self.n_data))
+        if hp_optz_info.has_theta:
+            out[hp_optz_info.idx_theta] = self.calc_Kcov_grad_theta(hp_vals, Rtensor)
+        if hp_optz_info.has_kernel:
+            out[hp_optz_info.idx_kernel] = self.calc_Kcov_grad_alpha(hp_vals, Rtensor)
+        if hp_optz_info.has_varK:
+            out[hp_optz_info.idx_varK] = self.calc_Kcov_grad_varK(hp_vals, Kern)
+        if hp_optz_info.has_var_fval:
+            out[hp_optz_info.idx_var_fval] = self.calc_Kcov_grad_var_fval(hp_vals)
+        if hp_optz_info.has_var_fgrad:
+            out[hp_optz_info.idx_var_fgrad] = self.calc_Kcov_grad_var_fgrad(hp_vals)
+        return out
+
     # ---- kernel + factorisation (compat entry points; the hot path does not materialise N x N arrays) ----
     def calc_Kern_w_chofac(self, Rtensor, hp_vals, noise_vec=None, calc_chofac=True, calc_cond=False,
                            materialize=False):

@@ -205,6 +205,15 @@ int gpg_kern_rtensor(int device, int kernel, int dim, int n1, int n2, const doub
  * (gpgradpy_amd/cond_number.py; replaces np.linalg.cond of an N x N matrix). */
 int gpg_factor_apply(gpg_ctx* ctx, int op, const double* v, double* out);
 
+/* d K / d theta_k [dim, N, N] and, for GPG_KERNEL_RATQU, d K / d alpha [N, N] (either may be NULL) of the kernel matrix of ONE point
+ * set with itself from its difference tensor rtensor [dim, n, n] (R[k, a, b] = x[a, k] - x[b, k]); N = n (dim + 1) with use_grad, n
+ * without; host arrays, row-major.  Replaces the kernel-table entries calc_KernBase_grad_th / calc_KernGrad_grad_th /
+ * calc_Kern*_grad_alpha (Kernel.py:43-48, 69-75, 96-102; KernelSqExp.py:91-123, 470-568, KernelMatern5f2.py:100-135, 532-642,
+ * KernelRatQuad.py:133-163, 640-840) for callers that want the tensors themselves (the reference's unit_test/test_grad_Kmat.py,
+ * calc_KernGrad_hp / calc_Kcov_grad_hp); the likelihood gradient never forms them (gpg_lkd_grad). */
+int gpg_kern_rtensor_grad_hp(int device, int kernel, int dim, int n, const double* rtensor, const double* theta, double hp_kernel,
+                             int use_grad, double* out_theta, double* out_alpha);
+
 /* The reference's matrix-dependent nugget (cond_eta_is_const = False, i.e. wellcond_mtd 'rescale_eta_vary'; Kernel.py:229-236,
  * 269-276): rowsum[i] = sum_j |M_ij| over the N rows of M = Kcor = P^-1 (K + diag(noise / varK)) P^-1 (wellcond PRECON) or of the
  * kernel matrix K itself (BASE), host [N]; hp->eta is ignored.  The caller takes argmax / max and sets

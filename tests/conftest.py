@@ -42,7 +42,7 @@ def load_case(path):
 
 def golden_case_paths():
     paths = sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
-    return [p for p in paths if not os.path.basename(p).startswith(("multistart_", "nugget_", "optz_", "hess_", "cond_", "evar_", "failobj_", "rescale_", "direct_", "precon_"))]
+    return [p for p in paths if not os.path.basename(p).startswith(("multistart_", "nugget_", "optz_", "hess_", "cond_", "evar_", "failobj_", "rescale_", "direct_", "precon_", "kgrad_"))]
 
 
 def case_id(path):
