@@ -9,6 +9,7 @@ NumPy/SciPy fallback for any part of the computation.
 import copy
 import ctypes as C
 import time
+import weakref
 
 import numpy as np
 
@@ -25,13 +26,13 @@ class DeviceChoFactor:
     (`eval_model`, `eval_model_var`) never triggers the download."""
 
     def __init__(self, gp):
-        self._gp = gp
+        self._gp = weakref.ref(gp)       # no reference cycle: a dropped GaussianProcess frees its device memory at once
         self._fac = None
 
     def _array(self):
         if self._fac is None:
-            gp = self._gp
-            if gp.KernEta_chofac is not self:
+            gp = self._gp()
+            if gp is None or gp.KernEta_chofac is not self:
                 raise RuntimeError('this KernEta_chofac belongs to an earlier setup_eval_model(): its device factor has been replaced')
             fac = np.empty((gp.n_data, gp.n_data))
             rc = gp._lib.gpg_get_matrix(gp._ctx, None, 4, _lib.as_dp(fac))
@@ -129,11 +130,20 @@ class GaussianProcess(HparaOptz):
         self.KernEta_chofac = None
         self.invKernEta_fdiff = None
 
+    def close(self):
+        """Free the device context (every workspace, factor and buffer of this model) now; the object can take new data
+        afterwards (set_data creates a fresh context)."""
+        if getattr(self, '_ctx', None):
+            self._lib.gpg_destroy(self._ctx)
+            self._ctx = None
+            self._ctx_shape = None
+            self.KernEta_chofac = None
+            self.invKernEta_fdiff = None
+            self._eval_ready = False
+
     def __del__(self):
         try:
-            if getattr(self, '_ctx', None):
-                self._lib.gpg_destroy(self._ctx)
-                self._ctx = None
+            self.close()
         except Exception:
             pass
 
@@ -435,7 +445,8 @@ class GaussianProcess(HparaOptz):
                 raise Exception(f'Unknown method wellcond_mtd = {self.wellcond_mtd}')
             self.DataScl = Rescaling(x_eval, x_scl_method=x_scl_method, dist_set=dist_set)
             self.DataScl.set_obj_data(fval, std_fval, grad, std_grad)
-            self.DataScl.on_change = self._on_rescale          # a later set_xscale_data() re-sends the scaled data to the device
+            me = weakref.ref(self)                              # (weak: DataScl must not keep the model and its device memory alive)
+            self.DataScl.on_change = lambda: me() is not None and me()._on_rescale()   # a later set_xscale_data() re-sends the scaled data
         self._Rtensor_init = None       # the [d, n, n] tensor (GaussianProcess.py:363): not built by the hot path, see Rtensor_init
         self.KernEta_chofac = None
         self.invKernEta_fdiff = None

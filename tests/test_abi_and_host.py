@@ -169,3 +169,30 @@ def test_rtensor_init_is_built_on_demand():
     Y = np.arange(6.0).reshape(2, 3)
     R2 = GP.calc_Rtensor(x, Y, 1)
     assert R2.shape == (3, 5, 2) and R2[1, 4, 1] == x[4, 1] - Y[1, 1]
+
+
+def test_dropped_model_is_collected_without_the_cycle_collector():
+    """A GaussianProcess owns GBs of device memory: dropping the last reference must free it at once (no reference cycle through
+    KernEta_chofac or the rescaling callback), and close() frees it explicitly."""
+    import gc
+    import weakref
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        for wellcond in ('precon', 'rescale_origin'):
+            GP = _gp_host_only(2, 'SqExp', 5, 'none') if wellcond == 'precon' else gpgradpy_amd.GaussianProcess(2, True, 'SqExp', wellcond)
+            if wellcond != 'precon':
+                x = np.random.default_rng(0).uniform(-1, 1, (5, 2))
+                try:
+                    GP.set_data(x, x[:, 0], np.zeros(5), x, np.zeros((5, 2)))
+                except _lib.GpgError:
+                    pass
+                assert GP.DataScl.on_change is not None
+            GP.KernEta_chofac = gpgradpy_amd.gaussian_process.DeviceChoFactor(GP)
+            r = weakref.ref(GP)
+            GP.close()                                   # idempotent, also without a context
+            del GP
+            assert r() is None
+    finally:
+        if was:
+            gc.enable()

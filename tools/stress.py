@@ -8,13 +8,14 @@ import gpgradpy_amd
 from oracle import gp_oracle as orc
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+LARGE = os.environ.get('STRESS_LARGE') == '1'        # N = 3000 .. 20000: self-consistency only (the oracle would take minutes per case)
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 t_end = time.time() + budget
 n_cases = n_checks = 0
 while time.time() < t_end:
     d = int(rng.integers(1, 13))
-    N_target = int(10 ** rng.uniform(1.3, 3.7))
-    n = max(2, min(N_target // (d + 1), 700))
+    N_target = int(10 ** (rng.uniform(3.5, 4.3) if LARGE else rng.uniform(1.3, 3.7)))
+    n = max(2, min(N_target // (d + 1), 4000 if LARGE else 700))
     kernel = ('SqExp', 'Ma5f2', 'RatQu')[int(rng.integers(0, 3))]
     noise = ('none', 'known', 'unknown')[int(rng.integers(0, 3))]
     mode = ('auto', 'tile64', 'tile128', 'blocked')[int(rng.integers(0, 4))]
@@ -30,7 +31,7 @@ while time.time() < t_end:
     if rng.random() < 0.3:
         GP.set_max_workgroups(int(rng.integers(1, 600)))
     hi = GP.hp_info_optz_lkd
-    m = int(rng.integers(1, 12))
+    m = int(rng.integers(1, 5 if LARGE else 12))
     rows = np.zeros((m, hi.n_hp))
     rows[:, hi.idx_theta] = rng.uniform(-2.3, -0.5, (m, d))
     if hi.has_kernel:
@@ -50,6 +51,7 @@ while time.time() < t_end:
     hp_m = GP.optz_closed_form_hp(GP.hp_vec2dataclass(hi, rows[i]))
     GP.set_hpara('set', 0, hp_vals=hp_m)
     xq = rng.uniform(-2, 2, (int(rng.integers(1, 80)), d))
+    print(f'case {n_cases}: {kernel} {noise} n={n} d={d} N={n * (d + 1)} mode={mode} rows={m}', flush=True)
     mu0, sig0 = GP.eval_model(xq)[:2]
     info, good = GP.calc_lkd_all(hp, calc_grad=True)
     assert good and abs(info.ln_lkd - ln_b[i]) <= 1e-11 * abs(ln_b[i])
