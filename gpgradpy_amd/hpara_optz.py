@@ -140,6 +140,38 @@ class HparaOptz:
         for name in self._HIST_1D + ('Kcov_cond_at_max_all',):
             setattr(self, name, getattr(self, name)[:idx])
 
+    def _history_names(self):
+        return ('hp_beta_all', 'hp_theta_all', 'xvec_rescaling_all', 'Kcov_cond_at_max_all') + self._HIST_1D
+
+    def export_data_surr(self, save2file=True, file2save=None, file2save_old=None):
+        """GpParaDef.py:171-217: the stored history as a dict keyed `surr_name + array name`; written as an .npz file when
+        save2file (default file: path_data_surr + '.npz'; an existing file is kept as file2save_old, default '..._old.npz')."""
+        import os
+        assert self._save_data, 'If the method init_optz_surr has not been called, then export_data_surr cannot be used'
+        data2save = {self.surr_name + k: getattr(self, k) for k in self._history_names()}
+        if save2file:
+            file2save = file2save or self.path_data_surr + '.npz'
+            file2save_old = file2save_old or self.path_data_surr + '_old.npz'
+            if os.path.isfile(file2save):
+                os.replace(file2save, file2save_old)
+            np.savez(file2save, **data2save)
+        return data2save
+
+    def load_data_surr(self, all_data=None):
+        """GpParaDef.py:115-169: fill the first rows of the history arrays from a dict / NpzFile made by export_data_surr
+        (default: path_data_surr + '.npz', nothing happens if it does not exist; numpy.load without pickle)."""
+        import os
+        assert self._save_data, 'If the method init_optz_surr has not been called, then load_data_surr cannot be used'
+        if all_data is None:
+            file2load = self.path_data_surr + '.npz'
+            if not os.path.isfile(file2load):
+                return
+            all_data = np.load(file2load, allow_pickle=False)
+        name = self.surr_name
+        idx = all_data[name + 'hp_beta_all'].size                                # n_beta_coeff = 1: one entry per iteration
+        for k in self._history_names():
+            getattr(self, k)[:idx] = all_data[name + k]
+
     def store_new_para_surr(self, i_optz, hp_vals, surr_optz_info=None, cond_val=np.nan, time_hp_optz=np.nan,
                             time_chofac=np.nan, time_pick_hp0=np.nan):
         self.hp_vals = hp_vals

@@ -196,3 +196,28 @@ def test_dropped_model_is_collected_without_the_cycle_collector():
     finally:
         if was:
             gc.enable()
+
+
+def test_history_export_and_load_round_trip(tmp_path):
+    """export_data_surr / load_data_surr (GpParaDef.py:115-217): keys `surr_name + array name`, npz without pickle."""
+    GP = _gp_host_only(2, 'SqExp', 4, 'none')
+    GP.path_data_surr = str(tmp_path / 'hist')
+    GP.init_optz_surr(5)
+    hp = GP.make_hp_class(beta=np.array([0.5]), theta=np.array([0.1, 0.2]), varK=2.0)
+    GP.store_new_para_surr(0, hp, None, 123.0, 0.1, 0.05, 0.01)
+    GP.store_new_para_surr(1, GP.make_hp_class(beta=np.array([0.7]), theta=np.array([0.3, 0.4]), varK=3.0), None, 456.0)
+    GP.finish_optz_surr(2)
+    d = GP.export_data_surr()
+    assert set(d) >= {'obj_hp_theta_all', 'obj_hp_varK_all', 'obj_Kcov_cond_all', 'obj_xvec_rescaling_all', 'obj_vmin_init_all'}
+    assert os.path.isfile(str(tmp_path / 'hist.npz'))
+    GP.export_data_surr()                                       # the previous file is kept as ..._old.npz
+    assert os.path.isfile(str(tmp_path / 'hist_old.npz'))
+    G2 = _gp_host_only(2, 'SqExp', 4, 'none')
+    G2.path_data_surr = GP.path_data_surr
+    G2.init_optz_surr(5)
+    G2.load_data_surr()
+    np.testing.assert_array_equal(G2.hp_theta_all[:2], [[0.1, 0.2], [0.3, 0.4]])
+    np.testing.assert_array_equal(G2.Kcov_cond_all[:2], [123.0, 456.0])
+    assert np.isnan(G2.hp_theta_all[2]).all()
+    G2.set_hp_from_idx(1)
+    np.testing.assert_array_equal(G2.hp_vals.theta, [0.3, 0.4])
