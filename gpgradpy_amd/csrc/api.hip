@@ -292,6 +292,22 @@ int gpg_set_data(gpg_ctx* c, const double* x, const double* data_vec, const doub
 
 // A dependency wait of the dataflow factorisation timed out (never expected: it would mean a lost flag or a
 // dispatch-order assumption broken).  The kernel drains and marks info with GPG_INFO_INTERNAL.
+int gpg_set_noise(gpg_ctx* c, const double* noise_var) {
+  if (!c) return -1;
+  if (!c->have_data) { c->err = "gpg_set_data has not been called"; return -1; }
+  GPG_HIP_OK(c, hipSetDevice(c->device));
+  GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
+  if (noise_var) GPG_HIP_OK(c, hipMemcpy(c->noise, noise_var, sizeof(double) * c->N, hipMemcpyHostToDevice));
+  else {
+    GPG_HIP_OK(c, hipMemsetAsync(c->noise, 0, sizeof(double) * c->N, c->stream));
+    GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
+  }
+  c->ws[0].factor_valid = c->ws[0].prep_valid = false;      // likelihood-side state only: the posterior keeps its own factor
+  if (c->ws_cur == 0) c->factor_valid = c->prep_valid = false;
+  c->alpha_valid = false;
+  return 0;
+}
+
 static int internal_failure(gpg_ctx* c, const int* infos, int m) {
   for (int i = 0; i < m; ++i)
     if (infos[i] == GPG_INFO_INTERNAL) {

@@ -572,6 +572,8 @@ class GaussianProcess(HparaOptz):
             hp.var_fgrad = -1.0
         else:
             hp.var_fgrad = -1.0 if (self.known_eps_fgrad or not self.b_has_noisy_data) else float(hp_vals.var_fgrad)
+        if self._noise_override:                                 # per-row vector on the device (calc_all_K_w_chofac(noise_vec=...))
+            hp.var_fval = hp.var_fgrad = -1.0
         hp.eta = float(self._etaK)
         hp.wellcond = self._wellcond_code
         hp.closed_form_varK = int(closed_form)
@@ -808,7 +810,18 @@ class GaussianProcess(HparaOptz):
         (lower factor for both well-conditioning methods).  Kern / Kcov are downloaded only when
         materialize=True; Kcor is never formed (None)."""
         if noise_vec is not None:
-            raise NotImplementedError('a caller-supplied noise_vec is outside the accelerated path')
+            # Kernel.py:207-208, 218: the caller's per-row noise variances instead of the model's -- sent to the device for this
+            # call, the model's own vector is put back afterwards
+            noise_vec = np.ascontiguousarray(noise_vec, dtype=np.float64)
+            assert noise_vec.size == self.n_data, 'noise_vec must have n_data entries'
+            if self._lib.gpg_set_noise(self._ctx, _lib.as_dp(noise_vec)) != 0:
+                raise _lib.GpgError(f'gpg_set_noise failed: {self._err()}')
+            try:
+                self._noise_override = True
+                return self.calc_all_K_w_chofac(Rtensor, hp_vals, None, calc_chofac, calc_cond, varK, b_normlz_w_varK, materialize)
+            finally:
+                self._noise_override = False
+                self._lib.gpg_set_noise(self._ctx, _lib.as_dp(self._noise_known))
         if varK is None:
             assert hp_vals.varK is not None, f'varK is not provided and hp_vals.varK is None, hp_vals = {hp_vals}'
             varK = hp_vals.varK
@@ -947,6 +960,7 @@ class GaussianProcess(HparaOptz):
                        data_vec=self._data_vec if noisy else None, cond=cond, cond_grad=cond_grad)
         return info, True
 
+    _noise_override = False
     _skip_beta_grad = False       # the optimiser's objective sets it: OptzLkd.py reads ln_lkd_grad / cond_grad only
 
     def _slots_to_hp(self, g_all):

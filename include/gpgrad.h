@@ -81,6 +81,10 @@ int gpg_set_grad_mask(gpg_ctx* ctx, const unsigned char* use_grad_pt);
  * The [d, n, n] Rtensor of the reference is never materialised. */
 int gpg_set_data(gpg_ctx* ctx, const double* x, const double* data_vec, const double* noise_var);
 
+/* Replace the per-row noise variances only (host [N], NULL = zeros): what calc_all_K_w_chofac(..., noise_vec = ...) passes in
+ * (Kernel.py:140-143, 207-208, 218).  Likelihood-side state is invalidated; a posterior set up by gpg_setup_eval keeps its factor. */
+int gpg_set_noise(gpg_ctx* ctx, const double* noise_var);
+
 /* Likelihood ------------------------------------------------------------------------------------- */
 
 /* Replaces CalcLkd.calc_lkd_all(hp, calc_lkd=True, calc_cond=False, calc_grad=False)

@@ -427,3 +427,39 @@ def test_frobenius_condition_number_against_reference(name):
     elif GP.wellcond_mtd == "precon":
         with pytest.raises(AssertionError):                        # as the reference: no gradient with the preconditioner
             GP.calc_lkd_all(hp, calc_cond=True, calc_grad=True)
+
+
+def test_caller_supplied_noise_vector():
+    """calc_all_K_w_chofac(..., noise_vec=...) (Kernel.py:140-143, 207-208, 218): the caller's per-row noise variances are used for that
+    call only; the model's own noise and a posterior that was set up before are untouched."""
+    import scipy.linalg
+    import gpgradpy_amd
+    from oracle import gp_oracle as orc
+    n, d = 14, 2
+    X, f, g = orc.synthetic_design(n, d, seed=9)
+    std_f, std_g = np.full(n, 1e-2), np.full((n, d), 1e-1)
+    GP = gpgradpy_amd.GaussianProcess(d, True, 'SqExp', 'precon')
+    GP.set_data(X, f, std_f, g, std_g)
+    hp = GP.make_hp_class(theta=np.array([0.3, 0.6]), varK=1.5)
+    ln0 = GP.calc_lkd_all(hp)[0].ln_lkd
+    hp_m = GP.optz_closed_form_hp(GP.make_hp_class(theta=np.array([0.3, 0.6]), varK=1.5))
+    GP.set_hpara('set', 0, hp_vals=hp_m)
+    xq = np.array([[0.1, -0.2], [1.0, 0.5]])
+    mu0, sig0 = GP.eval_model(xq)[:2]
+    nv = np.linspace(1e-3, 5e-2, n * (d + 1))
+    Kern, _, Kcov, chofac, _, eta, _ = GP.calc_all_K_w_chofac(None, hp, noise_vec=nv, materialize=True)
+    Kref = orc.kern_grad(X, X, hp.theta, 'SqExp')
+    np.testing.assert_allclose(Kern, Kref, rtol=1e-13, atol=1e-15)
+    Kw = Kref + np.diag(nv / hp.varK)
+    p = np.sqrt(np.diag(Kw))
+    Kcov_ref = hp.varK * (Kw + eta * np.diag(p ** 2))              # P (Kcor + eta I) P
+    np.testing.assert_allclose(Kcov, Kcov_ref, rtol=1e-12, atol=1e-14)
+    L = np.tril(chofac[0])
+    np.testing.assert_allclose(L @ L.T, Kcov_ref, rtol=1e-10, atol=1e-12)
+    b = np.arange(1.0, n * (d + 1) + 1)
+    np.testing.assert_allclose(scipy.linalg.cho_solve(chofac, b), np.linalg.solve(Kcov_ref, b), rtol=1e-7)
+    # back to the model's own noise, posterior untouched
+    assert GP.calc_lkd_all(hp)[0].ln_lkd == ln0
+    mu1, sig1 = GP.eval_model(xq)[:2]
+    np.testing.assert_array_equal(mu1, mu0)
+    np.testing.assert_array_equal(sig1, sig0)
