@@ -18,7 +18,7 @@ PROF_NCAT = len(PROF_CATS)
 # every symbol include/gpgrad.h declares
 ABI_SYMBOLS = (
     "gpg_create", "gpg_destroy", "gpg_last_error", "gpg_set_grad_mask", "gpg_set_data", "gpg_lkd", "gpg_lkd_grad", "gpg_lkd_batch", "gpg_lkd_grad_batch",
-    "gpg_setup_eval", "gpg_predict", "gpg_predict_grad", "gpg_predict_var", "gpg_predict_hess", "gpg_get_matrix", "gpg_kern_rtensor", "gpg_kern_rtensor_grad_hp", "gpg_factor_apply", "gpg_dcov_quadform", "gpg_cond_fro", "gpg_set_noise", "gpg_abs_rowsum", "gpg_set_gradient_nugget", "gpg_lkd_alpha", "gpg_prof_enable", "gpg_prof_read", "gpg_set_panel", "gpg_set_lookahead", "gpg_set_factor_mode", "gpg_factor_fallbacks", "gpg_last_factor", "gpg_set_batch", "gpg_reserve_batch", "gpg_set_max_workgroups",
+    "gpg_setup_eval", "gpg_predict", "gpg_predict_grad", "gpg_predict_var", "gpg_predict_hess", "gpg_get_matrix", "gpg_kern_rtensor", "gpg_kern_rtensor_grad_hp", "gpg_kern_rtensor_hess_x", "gpg_factor_apply", "gpg_dcov_quadform", "gpg_cond_fro", "gpg_set_noise", "gpg_abs_rowsum", "gpg_set_gradient_nugget", "gpg_lkd_alpha", "gpg_prof_enable", "gpg_prof_read", "gpg_set_panel", "gpg_set_lookahead", "gpg_set_factor_mode", "gpg_factor_fallbacks", "gpg_last_factor", "gpg_set_batch", "gpg_reserve_batch", "gpg_set_max_workgroups",
     "gpg_device_info", "gpg_multi_create", "gpg_multi_destroy", "gpg_multi_last_error", "gpg_multi_count", "gpg_multi_set_data",
     "gpg_multi_lkd_batch",
 )
@@ -111,6 +111,8 @@ def load():
     lib.gpg_abs_rowsum.restype = C.c_int
     lib.gpg_kern_rtensor_grad_hp.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, C.c_double, C.c_int, dp, dp]
     lib.gpg_kern_rtensor_grad_hp.restype = C.c_int
+    lib.gpg_kern_rtensor_hess_x.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, dp, dp, C.c_double, C.c_int, C.POINTER(C.c_ubyte), dp]
+    lib.gpg_kern_rtensor_hess_x.restype = C.c_int
     lib.gpg_set_noise.argtypes = [vp, dp]
     lib.gpg_set_noise.restype = C.c_int
     lib.gpg_lkd_alpha.argtypes = [vp, dp]

@@ -1010,6 +1010,45 @@ int gpg_kern_rtensor_grad_hp(int device, int kernel, int dim, int n, const doubl
   return rc;
 }
 
+int gpg_kern_rtensor_hess_x(int device, int kernel, int dim, int n1, int n2, const double* rtensor, const double* theta, double hp_kernel,
+                            int use_grad, const unsigned char* use_grad2, double* out) {
+  if (!rtensor || !theta || !out || dim < 1 || dim > GPG_MAX_DIM || n1 < 1 || n2 < 1) { g_create_err = "bad gpg_kern_rtensor_hess_x arguments (1 <= dim <= 16)"; return -1; }
+  if (kernel != GPG_KERNEL_SQEXP && kernel != GPG_KERNEL_MA5F2 && kernel != GPG_KERNEL_RATQU) { g_create_err = "unknown kernel id"; return -1; }
+  if (kernel == GPG_KERNEL_RATQU && !(hp_kernel > 0.0)) { g_create_err = "hp_kernel (alpha of RatQu) must be positive"; return -1; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_create_err = "no HIP device visible"; return -2; }
+  if (device < 0 || device >= ndev) { g_create_err = "device index out of range"; return -1; }
+  std::vector<int> gp2(n2, -1);
+  int n2g = 0;
+  if (use_grad)
+    for (int b = 0; b < n2; ++b) if (!use_grad2 || use_grad2[b]) gp2[b] = n2g++;
+  const size_t Ccols = (size_t)n2 + (size_t)n2g * dim, nout = (size_t)dim * n1 * dim * Ccols, nrt = (size_t)dim * n1 * n2;
+  double *d_rt = nullptr, *d_out = nullptr;
+  int* d_g2 = nullptr;
+  hipStream_t st = nullptr;
+  int rc = 0;
+  auto fail = [&](const char* what, hipError_t e) { g_create_err = std::string(what) + ": " + hipGetErrorString(e); rc = -2; };
+  hipError_t e;
+  if ((e = hipSetDevice(device)) != hipSuccess) fail("hipSetDevice", e);
+  if (!rc && (e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking)) != hipSuccess) fail("hipStreamCreate", e);
+  if (!rc && (e = hipMalloc(&d_rt, sizeof(double) * nrt)) != hipSuccess) fail("hipMalloc(rtensor)", e);
+  if (!rc && (e = hipMalloc(&d_out, sizeof(double) * nout)) != hipSuccess) fail("hipMalloc(out)", e);
+  if (!rc && (e = hipMalloc(&d_g2, sizeof(int) * n2)) != hipSuccess) fail("hipMalloc(gpos2)", e);
+  if (!rc && (e = hipMemcpyAsync(d_rt, rtensor, sizeof(double) * nrt, hipMemcpyHostToDevice, st)) != hipSuccess) fail("copy rtensor", e);
+  if (!rc && (e = hipMemcpyAsync(d_g2, gp2.data(), sizeof(int) * n2, hipMemcpyHostToDevice, st)) != hipSuccess) fail("copy gpos2", e);
+  if (!rc && (e = hipMemsetAsync(d_out, 0, sizeof(double) * nout, st)) != hipSuccess) fail("memset out", e);
+  if (!rc && gpg_kern_rtensor_hess_x_run(kernel, dim, n1, n2, n2g, use_grad ? 1 : 0, theta, hp_kernel, d_rt, d_g2, d_out, st) != 0) {
+    g_create_err = "rtensor x-derivative kernel launch failed"; rc = -2;
+  }
+  if (!rc && (e = hipMemcpyAsync(out, d_out, sizeof(double) * nout, hipMemcpyDeviceToHost, st)) != hipSuccess) fail("copy out", e);
+  if (!rc && (e = hipStreamSynchronize(st)) != hipSuccess) fail("hipStreamSynchronize", e);
+  if (d_rt) (void)hipFree(d_rt);
+  if (d_out) (void)hipFree(d_out);
+  if (d_g2) (void)hipFree(d_g2);
+  if (st) (void)hipStreamDestroy(st);
+  return rc;
+}
+
 int gpg_abs_rowsum(gpg_ctx* c, const gpg_hp* hp, double* rowsum) {
   int rc = check_hp(c, hp);
   if (rc) return rc;

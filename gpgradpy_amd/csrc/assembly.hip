@@ -544,6 +544,63 @@ __global__ void __launch_bounds__(256) rtensor_kern_dhp_kernel(RtParams P, const
   }
 }
 
+// d (d K / d x1) / d x1: the x-derivative entries of the kernel table -- calc_KernBase_hess_x [d, n1 d, n2] and calc_KernGrad_grad_x
+// [d, n1 d, n2 + n2g d] (KernelSqExp.py:48-88, 412-468; KernelMatern5f2.py:53-97, 452-530; KernelRatQuad.py:51-131, 556-638) from the
+// difference tensor R = X1 - X2 of two point sets: out[k][i n1 + a][b] = d2 K(a, b) / d x1_i d x1_k and, in the gradient columns
+// (j, b), d3 K / d x1_i d x1_k d x2_j.  The formulas are those of hess_contract_kernel (solve.hip), which contracts them for the
+// posterior Hessian without storing them (there R = x_train - x_query, hence the opposite sign of the odd, third-order entries).
+template <int KERN>
+__global__ void __launch_bounds__(256) rtensor_kern_hess_x_kernel(RtParams P, const double* __restrict__ Rt, const int* __restrict__ gpos2,
+                                                                  double* __restrict__ out) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long np = (long long)P.n1 * P.n2;
+  if (t >= np) return;
+  const int a = (int)(t / P.n2), b = (int)(t - (long long)a * P.n2);
+  const int d = P.d, n1 = P.n1, n2 = P.n2;
+  const size_t C = P.use_grad ? (size_t)n2 + (size_t)P.n2g * d : (size_t)n2, Rw = (size_t)n1 * d;
+  double tR[GPG_MAX_DIM], th[GPG_MAX_DIM];
+  double s = 0.0;
+  for (int k = 0; k < d; ++k) { const double r = Rt[(size_t)k * np + t]; th[k] = P.theta[k]; tR[k] = th[k] * r; s += tR[k] * r; }
+  const double sqrt5 = sqrt(5.0), al = P.hp_kernel, s1 = 1.0 + 1.0 / al, s2 = s1 * (1.0 + 2.0 / al);
+  double E, M1 = 0.0, F3 = 0.0, c3 = 0.0;
+  if (KERN == GPG_KERNEL_SQEXP) E = exp(-s);
+  else if (KERN == GPG_KERNEL_RATQU) { const double Bq = 1.0 + s / al; M1 = pow(Bq, -al - 1.0); E = pow(Bq, -al - 2.0); F3 = pow(Bq, -al - 3.0); }
+  else { const double nu = sqrt(s); E = exp(-sqrt5 * nu); M1 = ((5.0 / 3.0) * (1.0 + sqrt5 * nu)) * E; c3 = sqrt5 / fmax(nu, 1e-16); }
+  const int gb = P.use_grad ? gpos2[b] : -1;
+  for (int k = 0; k < d; ++k)
+    for (int i = 0; i < d; ++i) {
+      double* row = out + ((size_t)k * Rw + (size_t)i * n1 + a) * C;
+      double v;
+      if (KERN == GPG_KERNEL_SQEXP) v = (4.0 * tR[i] * tR[k] - (i == k ? 2.0 * th[i] : 0.0)) * E;
+      else if (KERN == GPG_KERNEL_RATQU) v = (4.0 * s1) * tR[i] * tR[k] * E - (i == k ? 2.0 * th[i] * M1 : 0.0);
+      else v = (25.0 / 3.0) * tR[i] * tR[k] * E - (i == k ? th[k] * M1 : 0.0);
+      row[b] = v;
+      if (gb < 0) continue;
+      for (int j = 0; j < d; ++j) {
+        const double lin = (i == k ? th[i] * tR[j] : 0.0) + (j == k ? th[j] * tR[i] : 0.0) + (i == j ? th[i] * tR[k] : 0.0);
+        const double cub = tR[i] * tR[j] * tR[k];
+        double w;
+        if (KERN == GPG_KERNEL_SQEXP) w = (-4.0 * lin + 8.0 * cub) * E;
+        else if (KERN == GPG_KERNEL_RATQU) w = -(4.0 * s1) * lin * E + (8.0 * s2) * cub * F3;
+        else w = -(25.0 / 3.0) * E * (lin - c3 * cub);
+        row[(size_t)n2 + (size_t)j * P.n2g + gb] = w;
+      }
+    }
+}
+
+int gpg_kern_rtensor_hess_x_run(int kernel, int d, int n1, int n2, int n2g, int use_grad, const double* theta, double hp_kernel,
+                                const double* rt_dev, const int* gpos2_dev, double* out_dev, hipStream_t stream) {
+  RtParams P;
+  memset(&P, 0, sizeof(P));
+  P.d = d; P.n1 = n1; P.n2 = n2; P.n1g = n1; P.n2g = n2g; P.use_grad = use_grad; P.hp_kernel = hp_kernel > 0.0 ? hp_kernel : 1.0;
+  for (int k = 0; k < d; ++k) P.theta[k] = theta[k];
+  const dim3 grid((unsigned)(((long long)n1 * n2 + 255) / 256));
+  if (kernel == GPG_KERNEL_SQEXP) hipLaunchKernelGGL(rtensor_kern_hess_x_kernel<GPG_KERNEL_SQEXP>, grid, dim3(256), 0, stream, P, rt_dev, gpos2_dev, out_dev);
+  else if (kernel == GPG_KERNEL_RATQU) hipLaunchKernelGGL(rtensor_kern_hess_x_kernel<GPG_KERNEL_RATQU>, grid, dim3(256), 0, stream, P, rt_dev, gpos2_dev, out_dev);
+  else hipLaunchKernelGGL(rtensor_kern_hess_x_kernel<GPG_KERNEL_MA5F2>, grid, dim3(256), 0, stream, P, rt_dev, gpos2_dev, out_dev);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 int gpg_kern_rtensor_dhp_run(int kernel, int d, int n, int use_grad, const double* theta, double hp_kernel, const double* rt_dev,
                              double* out_th_dev, double* out_al_dev, hipStream_t stream) {
   RtParams P;

@@ -189,6 +189,8 @@ int gpg_kern_rtensor_run(int kernel, int d, int n1, int n2, int n1g, int n2g, in
                          const double* rt_dev, const int* gpos1_dev, const int* gpos2_dev, double* out_dev, hipStream_t stream);
 int gpg_kern_rtensor_dhp_run(int kernel, int d, int n, int use_grad, const double* theta, double hp_kernel, const double* rt_dev,
                              double* out_th_dev, double* out_al_dev, hipStream_t stream);
+int gpg_kern_rtensor_hess_x_run(int kernel, int d, int n1, int n2, int n2g, int use_grad, const double* theta, double hp_kernel,
+                                const double* rt_dev, const int* gpos2_dev, double* out_dev, hipStream_t stream);
 int gpg_ws_activate(gpg_ctx* c, int which);                              // make workspace set `which` the active one (allocates set 1 on first use)
 
 // Device allocation inside a launch helper (task lists, flags, carrier tiles): on failure the pointer stays null, the

@@ -731,6 +731,42 @@ class GaussianProcess(HparaOptz):
     def calc_Kern_grad_alpha(self, Rtensor, theta, hp_kernel=None, *args):
         return self.calc_KernGrad_grad_alpha(Rtensor, theta, hp_kernel, *args) if self.use_grad else self.calc_KernBase_grad_alpha(Rtensor, theta, hp_kernel)
 
+    def _kern_hess_x(self, Rtensor, theta, hp_kernel, use_grad, bvec_use_grad2=None):
+        Rtensor = np.ascontiguousarray(Rtensor, dtype=np.float64)
+        assert Rtensor.ndim == 3, 'Rtensor must have the shape [dim, n1, n2]'
+        dim, n1, n2 = Rtensor.shape
+        theta = np.ascontiguousarray(theta, dtype=np.float64)
+        assert theta.size == dim, 'theta must have dim entries'
+        m2, n2g = None, n2
+        if use_grad and bvec_use_grad2 is not None:
+            m2 = np.ascontiguousarray(bvec_use_grad2, dtype=np.uint8)
+            assert m2.size == n2
+            n2g = int(m2.sum())
+        out = np.empty((dim, n1 * dim, n2 + n2g * dim if use_grad else n2))
+        alpha = 0.0
+        if self.kernel_has_hp:
+            assert hp_kernel is not None and not np.isnan(hp_kernel), 'this kernel needs its hyperparameter hp_kernel'
+            alpha = float(np.asarray(hp_kernel).reshape(-1)[0])
+        rc = self._lib.gpg_kern_rtensor_hess_x(self.device, _lib.GPG_KERNEL[self.kernel_type], dim, n1, n2, _lib.as_dp(Rtensor),
+                                               _lib.as_dp(theta), alpha, int(use_grad),
+                                               None if m2 is None else m2.ctypes.data_as(C.POINTER(C.c_ubyte)), _lib.as_dp(out))
+        if rc != 0:
+            raise _lib.GpgError(f'gpg_kern_rtensor_hess_x failed ({rc}): {self._lib.gpg_last_error(None).decode()}')
+        return out
+
+    def calc_KernBase_hess_x(self, Rtensor, theta, hp_kernel=None, *args):
+        """d2 KernBase / d x1 d x1, [dim, n1 dim, n2] (KernelSqExp.py:48-88, KernelMatern5f2.py:53-97, KernelRatQuad.py:51-131)."""
+        return self._kern_hess_x(Rtensor, theta, hp_kernel, False)
+
+    def calc_KernGrad_grad_x(self, Rtensor, theta, hp_kernel=None, bvec_use_grad2=None):
+        """Derivative of the gradient-enhanced cross kernel with respect to the first point set, [dim, n1 dim, n2 + n2g dim]
+        (KernelSqExp.py:412-468, KernelMatern5f2.py:452-530, KernelRatQuad.py:556-638)."""
+        return self._kern_hess_x(Rtensor, theta, hp_kernel, True, bvec_use_grad2)
+
+    def calc_Kern_hess_x(self, Rtensor, theta, hp_kernel=None, *args):
+        """Kernel.py:117,123: what eval_model's Hessians are made of (GpEvalModel.py:148-150)."""
+        return self.calc_KernGrad_grad_x(Rtensor, theta, hp_kernel, *args) if self.use_grad else self.calc_KernBase_hess_x(Rtensor, theta, hp_kernel)
+
     def calc_KernGrad_hp(self, hp_optz_info, hp_vals, Rtensor, etaK=None):
         """GpHparaGrad.py:13-68: derivative of the regularised kernel matrix of the noise-free path with respect to the optimised
         hyperparameters, [n_hp, N, N]; 'precon' adds 2 eta gamma_i d gamma_i / d theta_i on the diagonal of the gradient blocks."""

@@ -218,6 +218,14 @@ int gpg_factor_apply(gpg_ctx* ctx, int op, const double* v, double* out);
 int gpg_kern_rtensor_grad_hp(int device, int kernel, int dim, int n, const double* rtensor, const double* theta, double hp_kernel,
                              int use_grad, double* out_theta, double* out_alpha);
 
+/* The x-derivative entries of the kernel table, from the difference tensor rtensor [dim, n1, n2] of two point sets (R = X1 - X2):
+ * out [dim, n1 dim, n2 (+ n2g dim with use_grad)], out[k][i n1 + a][b] = d2 K(a, b) / d x1_i d x1_k and, in gradient column (j, b),
+ * d3 K / d x1_i d x1_k d x2_j; use_grad2 [n2] masks the gradient columns (NULL = all).  Replaces calc_KernBase_hess_x (use_grad = 0) /
+ * calc_KernGrad_grad_x (use_grad = 1) (Kernel.py:56-57, 82-83, 109-110; KernelSqExp.py:48-88, 412-468); the posterior Hessian itself
+ * (gpg_predict_hess) never forms the tensor. */
+int gpg_kern_rtensor_hess_x(int device, int kernel, int dim, int n1, int n2, const double* rtensor, const double* theta, double hp_kernel,
+                            int use_grad, const unsigned char* use_grad2, double* out);
+
 /* The reference's matrix-dependent nugget (cond_eta_is_const = False, i.e. wellcond_mtd 'rescale_eta_vary'; Kernel.py:229-236,
  * 269-276): rowsum[i] = sum_j |M_ij| over the N rows of M = Kcor = P^-1 (K + diag(noise / varK)) P^-1 (wellcond PRECON) or of the
  * kernel matrix K itself (BASE), host [N]; hp->eta is ignored.  The caller takes argmax / max and sets

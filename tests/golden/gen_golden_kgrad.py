@@ -49,8 +49,25 @@ def case(GaussianProcess, name, n, d, kernel, noise, wellcond, seed):
     print(name, {k: np.shape(v) for k, v in out.items() if isinstance(v, np.ndarray) and v.ndim == 3})
 
 
+def hessx_case(GaussianProcess, name, n1, n2, d, kernel, seed):
+    """x-derivative entries: calc_KernBase_hess_x / calc_KernGrad_grad_x of two different point sets."""
+    rng = np.random.default_rng(seed)
+    x1, x2 = rng.uniform(-1.5, 1.5, (n1, d)), rng.uniform(-1.5, 1.5, (n2, d))
+    theta = 10.0 ** rng.uniform(-0.8, 0.3, d)
+    GP = GaussianProcess(d, True, kernel, 'precon')
+    a = GP.hp_kernel_default
+    Rt = GP.calc_Rtensor(x1, x2, 1)
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), name=name, kernel=kernel, x1=x1, x2=x2, theta=theta,
+                        hp_kernel=np.nan if a is None else float(a), base_hess_x=GP.calc_KernBase_hess_x(Rt, theta, a),
+                        grad_grad_x=GP.calc_KernGrad_grad_x(Rt, theta, a))
+    print(name, GP.calc_KernBase_hess_x(Rt, theta, a).shape, GP.calc_KernGrad_grad_x(Rt, theta, a).shape)
+
+
 def main():
     GaussianProcess = gg._import_reference()
+    hessx_case(GaussianProcess, 'kgrad_hessx_SqExp_d3', 4, 5, 3, 'SqExp', 81)
+    hessx_case(GaussianProcess, 'kgrad_hessx_Ma5f2_d2', 5, 3, 2, 'Ma5f2', 82)
+    hessx_case(GaussianProcess, 'kgrad_hessx_RatQu_d2', 3, 6, 2, 'RatQu', 83)
     case(GaussianProcess, 'kgrad_SqExp_none_n5_d2_precon', 5, 2, 'SqExp', 'none', 'precon', 71)
     case(GaussianProcess, 'kgrad_Ma5f2_none_n4_d3_base', 4, 3, 'Ma5f2', 'none', 'base', 72)
     case(GaussianProcess, 'kgrad_RatQu_none_n5_d2_precon', 5, 2, 'RatQu', 'none', 'precon', 73)

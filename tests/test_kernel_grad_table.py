@@ -10,7 +10,8 @@ import pytest
 from conftest import GOLDEN_DIR
 
 pytestmark = pytest.mark.gpu
-CASES = sorted(glob.glob(os.path.join(GOLDEN_DIR, "kgrad_*.npz")))
+CASES = sorted(p for p in glob.glob(os.path.join(GOLDEN_DIR, "kgrad_*.npz")) if "hessx" not in p)
+HESSX = sorted(glob.glob(os.path.join(GOLDEN_DIR, "kgrad_hessx_*.npz")))
 
 
 def _load(path):
@@ -82,3 +83,41 @@ def test_derivative_tensors_against_finite_differences(kernel, use_grad):
         an_a = GP.calc_Kern_grad_alpha(Rt, theta, a)
         fd = (GP.calc_Kern(Rt, theta, a + eps) - GP.calc_Kern(Rt, theta, a - eps)) / (2 * eps)
         np.testing.assert_allclose(an_a[0], fd, rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.parametrize("path", HESSX, ids=lambda p: os.path.basename(p)[:-4])
+def test_x_derivative_entries_match_reference(path):
+    import gpgradpy_amd
+    c = _load(path)
+    d = c["x1"].shape[1]
+    GP = gpgradpy_amd.GaussianProcess(d, True, str(c["kernel"]), 'precon')
+    a = None if np.isnan(c["hp_kernel"]) else float(c["hp_kernel"])
+    Rt = GP.calc_Rtensor(c["x1"], c["x2"], 1)
+    _close(GP.calc_KernBase_hess_x(Rt, c["theta"], a), c["base_hess_x"])
+    _close(GP.calc_KernGrad_grad_x(Rt, c["theta"], a), c["grad_grad_x"])
+    _close(GP.calc_Kern_hess_x(Rt, c["theta"], a), c["grad_grad_x"])
+
+
+@pytest.mark.parametrize("kernel", ["SqExp", "Ma5f2", "RatQu"])
+def test_x_derivative_entries_against_finite_differences(kernel):
+    """d (d K / d x1_i) / d x1_k by central differences of the device's own gradient-enhanced cross kernel (rows of the x1-gradient
+    blocks of calc_KernGrad), with a gradient mask on the second point set."""
+    import gpgradpy_amd
+    rng = np.random.default_rng(11)
+    n1, n2, d = 4, 6, 3
+    x1, x2 = rng.uniform(-1.5, 1.5, (n1, d)), rng.uniform(-1.5, 1.5, (n2, d))
+    theta = 10.0 ** rng.uniform(-0.8, 0.3, d)
+    a = 1.7 if kernel == "RatQu" else None
+    mask2 = np.array([True, False, True, True, False, True])
+    GP = gpgradpy_amd.GaussianProcess(d, True, kernel, 'precon')
+    an = GP.calc_KernGrad_grad_x(GP.calc_Rtensor(x1, x2, 1), theta, a, mask2)
+    assert an.shape == (d, n1 * d, n2 + int(mask2.sum()) * d)
+    eps = 1e-6
+    for k in range(d):
+        xp, xm = x1.copy(), x1.copy()
+        xp[:, k] += eps
+        xm[:, k] -= eps
+        Kp = GP.calc_KernGrad(GP.calc_Rtensor(xp, x2, 1), theta, a, None, mask2)
+        Km = GP.calc_KernGrad(GP.calc_Rtensor(xm, x2, 1), theta, a, None, mask2)
+        fd = (Kp[n1:] - Km[n1:]) / (2 * eps)                  # rows (i, a) of the x1-gradient blocks: shifting every x1 point at once is
+        np.testing.assert_allclose(an[k], fd, rtol=2e-6, atol=2e-8)   # fine, entry (a, b) only depends on x1[a]
