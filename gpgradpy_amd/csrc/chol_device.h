@@ -562,7 +562,9 @@ __device__ __forceinline__ double2 gpg_nt_load2(const double* p) {
   const gpg_d2v v = __builtin_nontemporal_load(reinterpret_cast<const gpg_d2v*>(p));
   double2 r; r.x = v.x; r.y = v.y; return r;
 }
-template <int PF>
+// MI = 4: all 64 rows of the wave tile; MI = 2: only its first 32-row group (acc[.][0], acc[.][1]) -- the right-hand-side tile row of
+// the factorisation carries two real rows.
+template <int PF, int MI = 4>
 __device__ __forceinline__ void direct_tile_gemm_x2(d4 (&acc)[4][4], const double* pa, int lda, const double* pb, int ldb,
                                                     int nstep) {
   const size_t sa = (size_t)4 * lda, sb = (size_t)4 * ldb;
@@ -575,7 +577,7 @@ __device__ __forceinline__ void direct_tile_gemm_x2(d4 (&acc)[4][4], const doubl
 #define GPG_DX_LOAD(set)                                                              \
   {                                                                                   \
     fa0[set] = GPG_DX_LD(pa);                                                         \
-    fa1[set] = GPG_DX_LD(pa + 32);                                                    \
+    if (MI == 4) fa1[set] = GPG_DX_LD(pa + 32);                                       \
     fb0[set] = GPG_DX_LD(pb);                                                         \
     fb1[set] = GPG_DX_LD(pb + 32);                                                    \
     pa += sa;                                                                         \
@@ -583,10 +585,10 @@ __device__ __forceinline__ void direct_tile_gemm_x2(d4 (&acc)[4][4], const doubl
   }
 #define GPG_DX_MFMA(set)                                                              \
   {                                                                                   \
-    const double fm[4] = {-fa0[set].x, -fa0[set].y, -fa1[set].x, -fa1[set].y};        \
+    const double fm[4] = {-fa0[set].x, -fa0[set].y, MI == 4 ? -fa1[set].x : 0.0, MI == 4 ? -fa1[set].y : 0.0}; \
     const double fn[4] = {fb0[set].x, fb0[set].y, fb1[set].x, fb1[set].y};            \
     _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                   \
-      _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                 \
+      _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                \
         acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fn[ni], fm[mi], acc[ni][mi], 0, 0, 0); \
   }
 #pragma unroll
