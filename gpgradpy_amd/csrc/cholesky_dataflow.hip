@@ -535,10 +535,11 @@ tile128_chol_task(int tix, double* A, int ld, int Mt, const int* __restrict__ ta
     GPG_ACQUIRE();
     GPG_TR(q1)
     const size_t ck = 128 * (size_t)kdone;
-    if (ti < Mt)
-      direct_tile_gemm_x2<GPG_MFMA_PF>(acc, A + r0 + wm * 64 + 2 * l15 + (ck + l4) * (size_t)ld, ld,
-                             A + cj + wn * 64 + 2 * l15 + (ck + l4) * (size_t)ld, ld, 32 * (kr - kdone));
-    else if (wm == 0)   // right-hand-side tile row (prep_rows_kernel): rows 0 and 1 are real, the other 126 zero -- an eighth of the MFMAs
+    if (ti < Mt) {
+      if (!(ti == tj && wm == 0 && wn == 1))   // diagonal tile: the block above the diagonal is never stored
+        direct_tile_gemm_x2<GPG_MFMA_PF>(acc, A + r0 + wm * 64 + 2 * l15 + (ck + l4) * (size_t)ld, ld,
+                               A + cj + wn * 64 + 2 * l15 + (ck + l4) * (size_t)ld, ld, 32 * (kr - kdone));
+    } else if (wm == 0)   // right-hand-side tile row (prep_rows_kernel): rows 0 and 1 are real, the other 126 zero -- an eighth of the MFMAs
       direct_tile_gemm_x2<GPG_MFMA_PF, 2>(acc, A + r0 + 2 * l15 + (ck + l4) * (size_t)ld, ld,
                                 A + cj + wn * 64 + 2 * l15 + (ck + l4) * (size_t)ld, ld, 32 * (kr - kdone));
     __syncthreads();   // sh_kr may be rewritten
