@@ -17,6 +17,15 @@ class LanczosNotConverged(RuntimeWarning):
     """The Ritz value returned by lanczos_largest did not meet its residual bound within k_max steps."""
 
 
+def _tridiag_eigh(alpha, beta):
+    """Eigenpairs of the Lanczos tridiagonal matrix.  LAPACK's stemr (SciPy's default driver) occasionally gives up on matrices
+    with a very wide spectrum -- the operator here may be K^-1 with cond(K) ~ 1e10 and beyond -- ; the QR iteration (stev) does not."""
+    try:
+        return eigh_tridiagonal(alpha, beta)
+    except np.linalg.LinAlgError:
+        return eigh_tridiagonal(alpha, beta, lapack_driver='stev')
+
+
 def lanczos_largest(apply, n, k_max=120, rtol=1e-9, seed=0, want_vector=False):
     """Largest eigenvalue (and, on request, its unit eigenvector) of the symmetric positive definite operator
     `apply` (n -> n)."""
@@ -42,15 +51,15 @@ def lanczos_largest(apply, n, k_max=120, rtol=1e-9, seed=0, want_vector=False):
             w -= Q[:j + 1].T @ (Q[:j + 1] @ w)
         b = float(np.linalg.norm(w))
         if j >= 1:
-            ev, evec = eigh_tridiagonal(np.array(alpha), np.array(beta))
+            ev, evec = _tridiag_eigh(np.array(alpha), np.array(beta))
             theta = ev[-1]
             ritz = evec[:, -1]
             if b * abs(evec[-1, -1]) <= rtol * abs(theta):   # residual bound of the largest Ritz pair
                 return done(theta, ritz, j)
         else:
             theta = a
-        if b <= 1e-300:                                      # invariant subspace: the Ritz values are exact
-            return done(theta, ritz, j)
+        if b <= 1e-300 or b <= 4e-16 * abs(theta) or not np.isfinite(b):   # invariant subspace (what is left of w is rounding): the Ritz
+            return done(theta, ritz, j)                                      # values are exact; nothing to normalise a next vector from
         if j + 1 >= k_max:
             if k_max < n:                                    # (k_max = n is the full Krylov space: exact up to rounding)
                 res = b * abs(evec[-1, -1]) / abs(theta) if j >= 1 else np.inf

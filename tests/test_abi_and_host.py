@@ -221,3 +221,21 @@ def test_history_export_and_load_round_trip(tmp_path):
     assert np.isnan(G2.hp_theta_all[2]).all()
     G2.set_hp_from_idx(1)
     np.testing.assert_array_equal(G2.hp_vals.theta, [0.3, 0.4])
+
+
+def test_lanczos_survives_exhausted_krylov_space_and_wide_spectra():
+    """Small operators exhaust the Krylov space (what is left of the next vector is rounding noise), and K^-1 of an ill-conditioned K
+    gives a tridiagonal matrix LAPACK's stemr can fail on: both must end in the exact answer, not in an exception."""
+    from gpgradpy_amd.cond_number import cond_from_factor, _tridiag_eigh
+    rng = np.random.default_rng(1)
+    for n, cond in ((3, 1e3), (6, 1e12), (12, 1e16), (40, 1e14)):
+        Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        lam = np.logspace(0, -np.log10(cond), n)
+        K, Ki = (Q * lam) @ Q.T, (Q / lam) @ Q.T
+        c = cond_from_factor(lambda v: K @ v, lambda v: Ki @ v, n)
+        assert np.isclose(c, cond, rtol=1e-5), (n, c, cond)
+        c2, lam_min, v_max, v_min = cond_from_factor(lambda v: K @ v, lambda v: Ki @ v, n, want_vectors=True)
+        assert np.isclose(c2, cond, rtol=1e-5) and np.isclose(lam_min, lam[-1], rtol=1e-5)
+        assert abs(abs(v_max @ Q[:, 0]) - 1) < 1e-6 and abs(abs(v_min @ Q[:, -1]) - 1) < 1e-4
+    ev, _ = _tridiag_eigh(np.array([1.0, 2.0, 3.0]), np.array([0.1, 0.2]))
+    assert np.all(np.diff(ev) > 0)
