@@ -8,7 +8,8 @@ Parameter space:   x_scl = (x_init - x_shift) * xvec_scale, where xvec_scale = x
                    to `dist_set` (Rescaling.py:72-125).
 Objective:         obj_scl = (obj - obj_shift) * obj_scale, gradients * obj_scale / xvec_scale, Hessians * obj_scale / xvec_scale^2
                    (Rescaling.py:134-183); obj_scale maps the range of the data on `rangeobj_max_dflt` ('dflt_max', :199-216).
-Constraint data (nlc_*), box and linear constraints: carried along for callers that keep them next to the surrogate (:223-393).
+Only what the Gaussian process itself uses is here; the reference class also carries constraint data, box and linear constraints
+(:223-393) for the Bayesian optimiser that sits above the package -- host bookkeeping outside this path.
 
 The Hessian factors broadcast over the LAST axis only -- entry (i, j) is scaled by xvec_scale[j]^2, not xvec_scale[i] *
 xvec_scale[j] -- exactly as the reference's arrays of shape [1, dim] do (Rescaling.py:147,173); the two agree whenever the
@@ -47,17 +48,16 @@ class Rescaling:
 
     x_scl_method_avail = ['set_vmin', 'set_vmax', None]
     obj_scl_method_avail = ['dflt_max', None]
-    nlc_scl_method_avail = ['obj_scl', None]
 
     vmin_dflt = 1
     vmax_dflt = 1
     rangeobj_max_dflt = 100
 
-    _xdata_set = _obj_data_set = _nlc_data_set = _boxcon_set = _lincon_set = False
-    use_x_shift = use_obj_shift = use_nlc_shift = True
-    x_scl_method = obj_scl_method = nlc_scl_method = None
+    _xdata_set = _obj_data_set = False
+    use_x_shift = use_obj_shift = True
+    x_scl_method = obj_scl_method = None
     dist_set = None
-    x_shift = xvec_scale = obj_shift = obj_scale = nlc_shift = nlc_scale = np.nan
+    x_shift = xvec_scale = obj_shift = obj_scale = np.nan
     on_change = None              # callable run after the scaled data changed (the GaussianProcess re-sends them to the device)
 
     def __init__(self, x_init, idx_xbest=None, use_x_shift=True, x_scl_method=None, dist_set=None):
@@ -122,12 +122,6 @@ class Rescaling:
         self._Rtensor_scl = None
         if self._obj_data_set:
             self._calc_n_set_scl_obj()
-        if self._nlc_data_set:
-            self._calc_n_set_scl_nlc()
-        if self._boxcon_set:
-            self._calc_n_set_scl_boxcon()
-        if self._lincon_set:
-            self._calc_n_set_scl_lincon()
         if self.on_change is not None:
             self.on_change()
 
@@ -209,112 +203,3 @@ class Rescaling:
     def get_scl_obj_data(self):
         assert self._obj_data_set, 'Must call the method set_obj_data prior to this method'
         return self.obj_scl, self.std_obj_scl, self.grad_scl, self.std_grad_scl
-
-    # ---- nonlinear-constraint data ([n_eval, nlc_n] values, [n_eval, nlc_n, dim] gradients) -------------------------
-    def nlc_init_2_scl(self, mu_in, sig_in, dmudx_in=None, dsigdx_in=None, d2mudx2_in=None, d2sigdx2_in=None):
-        assert self._nlc_data_set, 'Must call set_nlc_data prior to this method'
-        assert mu_in.ndim == 2, f'Unexpected shape for mu_in of {mu_in.shape}'
-        if dmudx_in is not None:
-            assert dmudx_in.ndim == 3, f'Unexpected shape for dmudx_in of {dmudx_in.shape}'
-        fg, fh = self._derivative_factors(True, self.nlc_scale)
-        fg, fh = fg[None], fh[None]
-        return ((mu_in - self.nlc_shift[None, :]) * self.nlc_scale, sig_in * self.nlc_scale, _opt(dmudx_in, fg),
-                _opt(dsigdx_in, fg), _opt(d2mudx2_in, fh), _opt(d2sigdx2_in, fh))
-
-    def nlc_scl_2_init(self, mu_scl=None, sig_scl=None, dmudx_scl=None, dsigdx_scl=None, d2mudx2_scl=None, d2sigdx2_scl=None):
-        assert self._nlc_data_set, 'Must call set_nlc_data prior to this method'
-        assert mu_scl.ndim == 2, f'Unexpected shape for mu_scl of {mu_scl.shape}'
-        if dmudx_scl is not None:
-            assert dmudx_scl.ndim == 3, f'Unexpected shape for dmudx_scl of {dmudx_scl.shape}'
-        fg, fh = self._derivative_factors(False, self.nlc_scale)
-        fg, fh = fg[None], fh[None]
-        return (mu_scl / self.nlc_scale + self.nlc_shift[None, :], None if sig_scl is None else sig_scl / self.nlc_scale,
-                _opt(dmudx_scl, fg), _opt(dsigdx_scl, fg), _opt(d2mudx2_scl, fh), _opt(d2sigdx2_scl, fh))
-
-    def _calc_nlc_scaling(self, nlc_init):
-        nlc_shift = nlc_init[self.idx_xbest, :] if self.use_nlc_shift else np.zeros(self.nlc_n)
-        if self.x_init.shape[0] == 1 or self.nlc_scl_method is None:
-            return nlc_shift, 1
-        if self.nlc_scl_method == 'obj_scl':
-            assert self._obj_data_set, 'Must call set_obj_data prior to this method'
-            return nlc_shift, self.obj_scale
-        raise Exception(f'Unavailable method of nlc_scl_method = {self.nlc_scl_method}')
-
-    def _calc_n_set_scl_nlc(self):
-        self.nlc_val_scl, self.nlc_std_val_scl, self.nlc_grad_scl, self.nlc_std_grad_scl = \
-            self.nlc_init_2_scl(self.nlc_val_init, self.nlc_std_val_init, self.nlc_grad_init, self.nlc_std_grad_init)[:4]
-
-    def set_nlc_scaling(self, nlc_shift=None, nlc_scale=None):
-        assert self._nlc_data_set, 'Must call set_nlc_data prior to this method'
-        if nlc_shift is not None:
-            self.nlc_shift = nlc_shift
-        if nlc_scale is not None:
-            self.nlc_scale = nlc_scale
-        self._calc_n_set_scl_nlc()
-
-    def set_nlc_data(self, nlc_val_init, nlc_std_val_init, nlc_grad_init, nlc_std_grad_init, use_nlc_shift=False,
-                     nlc_scl_method='obj_scl'):
-        """The reference's default nlc_scl_method='dflt_max' fails its own availability assert (Rescaling.py:518,523): the
-        only scaling it implements for constraint data is 'obj_scl' (or None), which is the default here."""
-        n_eval, self.nlc_n = nlc_val_init.shape
-        assert self._xdata_set, 'Must call the method set_xdata prior to set_obj_data'
-        assert n_eval == self.n_eval, f'Unecpected shape for nlc_val_init of {nlc_val_init.shape} when n_eval = {n_eval}'
-        assert nlc_scl_method in self.nlc_scl_method_avail, f'Requested nlc_scl_method = {nlc_scl_method} is not available'
-        self._nlc_data_set = True
-        self.nlc_val_init, self.nlc_std_val_init = nlc_val_init, nlc_std_val_init
-        self.nlc_grad_init, self.nlc_std_grad_init = nlc_grad_init, nlc_std_grad_init
-        self.nlc_scl_method, self.use_nlc_shift = nlc_scl_method, use_nlc_shift
-        self.set_nlc_scaling(*self._calc_nlc_scaling(nlc_val_init))
-
-    def get_init_nlc_data(self):
-        assert self._nlc_data_set, 'Must call the method set_nlc_data prior to this method'
-        return self.nlc_val_init, self.nlc_std_val_init, self.nlc_grad_init, self.nlc_std_grad_init
-
-    def get_scl_nlc_data(self):
-        assert self._nlc_data_set, 'Must call the method set_nlc_data prior to this method'
-        return self.nlc_val_scl, self.nlc_std_val_scl, self.nlc_grad_scl, self.nlc_std_grad_scl
-
-    # ---- box and linear constraints -------------------------------------------------------------------------------
-    def boxcon_init_2_scl(self, lb_init, ub_init):
-        assert self._xdata_set, 'Must call the method set_xdata prior to this method'
-        return self.xvec_scale * (lb_init - self.x_shift), self.xvec_scale * (ub_init - self.x_shift)
-
-    def _calc_n_set_scl_boxcon(self):
-        self.boxcon_lb_scl, self.boxcon_ub_scl = self.boxcon_init_2_scl(self.boxcon_lb_init, self.boxcon_ub_init)
-
-    def set_boxcon(self, lb_init, ub_init):
-        assert self._xdata_set, 'Must call set_xdata before this method'
-        self._boxcon_set = True
-        self.boxcon_lb_init, self.boxcon_ub_init = lb_init, ub_init
-        self._calc_n_set_scl_boxcon()
-
-    def get_init_boxcon(self):
-        assert self._boxcon_set, 'Must call set_boxcon before this method'
-        return self.boxcon_lb_init, self.boxcon_ub_init
-
-    def get_scl_boxcon(self):
-        assert self._boxcon_set, 'Must call set_boxcon before this method'
-        return self.boxcon_lb_scl, self.boxcon_ub_scl
-
-    def lincon_init_2_scl(self, A_init, lb_init, ub_init):
-        assert self._xdata_set, 'Must call the method set_xdata prior to this method'
-        off = np.dot(A_init, self.x_shift)
-        return A_init * (1 / self.xvec_scale[None, :]), lb_init - off, ub_init - off
-
-    def _calc_n_set_scl_lincon(self):
-        self.lincon_A_scl, self.lincon_lb_scl, self.lincon_ub_scl = \
-            self.lincon_init_2_scl(self.lincon_A_init, self.lincon_lb_init, self.lincon_ub_init)
-
-    def set_lincon(self, A_init, lb_init, ub_init):
-        assert self._xdata_set, 'Must call set_xdata before this method'
-        self._lincon_set = True
-        self.lincon_A_init, self.lincon_lb_init, self.lincon_ub_init = A_init, lb_init, ub_init
-        self._calc_n_set_scl_lincon()
-
-    def get_init_lincon(self):
-        assert self._lincon_set, 'Must call set_lincon before this method'
-        return self.lincon_A_init, self.lincon_lb_init, self.lincon_ub_init
-
-    def get_scl_lincon(self):
-        assert self._lincon_set, 'Must call set_lincon before this method'
-        return self.lincon_A_scl, self.lincon_lb_scl, self.lincon_ub_scl

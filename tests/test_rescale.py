@@ -88,34 +88,6 @@ def test_scaling_and_nuggets_match_reference(path):
     np.testing.assert_allclose(back[2], c["g"], rtol=1e-12, atol=1e-10)
 
 
-def test_rescaling_constraints_and_nlc_data():
-    """Box / linear constraints and constraint data follow the same affine map (Rescaling.py:223-393)."""
-    from gpgradpy_amd.rescaling import Rescaling
-    rng = np.random.default_rng(3)
-    x = rng.uniform(-1, 3, (7, 3))
-    S = Rescaling(x, x_scl_method='set_vmin', dist_set=2.0)
-    S.set_obj_data(rng.standard_normal(7), None, rng.standard_normal((7, 3)), None)
-    lb, ub = np.full(3, -1.0), np.full(3, 3.0)
-    S.set_boxcon(lb, ub)
-    np.testing.assert_allclose(S.get_scl_boxcon()[0], S.x_init_2_scl(lb), rtol=1e-14)
-    np.testing.assert_allclose(S.get_scl_boxcon()[1], S.x_init_2_scl(ub), rtol=1e-14)
-    A = rng.standard_normal((2, 3))
-    S.set_lincon(A, np.array([-1.0, -2.0]), np.array([1.0, 2.0]))
-    As, lbs, ubs = S.get_scl_lincon()
-    for pt in x:                                                   # A x - lb is invariant under the map
-        np.testing.assert_allclose(As @ S.x_init_2_scl(pt) - lbs, A @ pt - np.array([-1.0, -2.0]), rtol=1e-12, atol=1e-12)
-    nlc, dn = rng.standard_normal((7, 2)), rng.standard_normal((7, 2, 3))
-    S.set_nlc_data(nlc, 0.1 * np.ones((7, 2)), dn, 0.1 * np.ones((7, 2, 3)))
-    v, sv, gv = S.get_scl_nlc_data()[:3]
-    b = S.nlc_scl_2_init(v, sv, gv)
-    np.testing.assert_allclose(b[0], nlc, rtol=1e-12, atol=1e-12)
-    np.testing.assert_allclose(b[2], dn, rtol=1e-12, atol=1e-12)
-    S.set_xscale_data(xvec_scale_in=np.array([1.0, 2.0, 0.5]))    # everything follows a new anisotropic scale
-    np.testing.assert_allclose(S.get_scl_boxcon()[1], S.x_init_2_scl(ub), rtol=1e-14)
-    np.testing.assert_allclose(S.nlc_scl_2_init(*S.get_scl_nlc_data()[:3])[2], dn, rtol=1e-12, atol=1e-12)
-    assert S.get_scl_x_w_dist()[1].shape == (3, 7, 7)
-
-
 def _oracle_eval(c):
     """The oracle on the SCALED data with the nugget the reference used."""
     from oracle import gp_oracle as orc
