@@ -68,6 +68,12 @@ __device__ __forceinline__ double readlane_d(double v, int lane) {
 // column broadcast by v_readlane.  The reciprocal pivot comes from v_rsq_f64 plus two coupled
 // Goldschmidt steps (sqrt and 1/sqrt to ~1 ulp in 7 dependent operations; the pivot chain is the critical
 // path of every factorisation in this file).
+#ifdef GPG_POTRF_STAMP   // tools/potrf_probe.hip: cycle counter at the two phase boundaries of every 16-column sub-block
+__device__ unsigned long long* g_potrf_stamp;
+#define GPG_PS(k) if ((threadIdx.x & 63) == 0 && g_potrf_stamp) g_potrf_stamp[k] = __builtin_readcyclecounter();
+#else
+#define GPG_PS(k)
+#endif
 __device__ __forceinline__ int potrf64_wave(const double* src, int sld, double (*St)[64], double* __restrict__ blk, int ld,
                                             double* __restrict__ dinv, int* piece_flags = nullptr) {
   const int i = threadIdx.x & 63, l15 = i & 15, l4 = i >> 4;
@@ -102,6 +108,7 @@ __device__ __forceinline__ int potrf64_wave(const double* src, int sld, double (
 #pragma unroll
       for (int c = 0; c < 16; ++c) a[c] = St[16 * s + c][i];
     }
+    GPG_PS(2 * s)
     // Pivot chain, software-pipelined: the next pivot a[c+1][c+1] - L[c+1][c]^2 only needs the diagonal lane's own
     // scaled entry, so it is formed and broadcast BEFORE column c is applied to the other columns; the 15 - c
     // broadcast-FMA updates then fill the latency of the next v_rsq_f64 + Goldschmidt chain.
@@ -142,9 +149,92 @@ __device__ __forceinline__ int potrf64_wave(const double* src, int sld, double (
       GPG_RELEASE();
       if (i == 0) GPG_FLAG_UP(piece_flags + s);
     }
+    GPG_PS(2 * s + 1)
   }
   return bad;
 }
+
+// potrf64_wg: the same factorisation called by ALL FOUR waves of a 256-thread workgroup.  Wave 0 runs the pivot phases exactly as in
+// potrf64_wave; the MFMA update that precedes the pivots of sub-block s (64 x 16 panel -= L[:, :16 s] L[16 s : 16 s + 16, :16 s]^T) is
+// spread over the waves -- wave R takes the 16-row tile R of the panel, tiles above the diagonal block (R < s) are skipped -- so its
+// chain is 4 s dependent MFMAs instead of 16 s issued by one wave (potrf_probe: 2.1 / 3.2 / 4.6 k cycles of 33 k for s = 1 / 2 / 3
+// in the one-wave version).  Two workgroup barriers per sub-block; the return value is that of wave 0 (other waves return 0).
+__device__ __forceinline__ int potrf64_wg(const double* src, int sld, double (*St)[64], double* __restrict__ blk, int ld,
+                                          double* __restrict__ dinv, int* piece_flags = nullptr) {
+  const int w = threadIdx.x >> 6, i = threadIdx.x & 63, l15 = i & 15, l4 = i >> 4;
+  int bad = 0;
+  double myinv = 0.0;
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    double a[16];
+    if (s == 0) {
+      if (w == 0) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) a[c] = src[i + (size_t)c * sld];
+      }
+    } else {
+      if (w >= s) {                                        // tile R = w of the panel; R < s lies above the diagonal block
+        d4 acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = src[(16 * w + l15) + (size_t)(16 * s + 4 * r + l4) * sld];
+#pragma unroll
+        for (int kk = 0; kk < 4 * s; ++kk) {
+          const double fn = St[4 * kk + l4][16 * s + l15];
+          const double fm = -St[4 * kk + l4][16 * w + l15];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fn, fm, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) St[16 * s + 4 * r + l4][16 * w + l15] = acc[r];
+      }
+      __syncthreads();                                     // the updated panel is in St[16 s .. 16 s + 15][.]
+      if (w == 0) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) a[c] = St[16 * s + c][i];
+      }
+    }
+    GPG_PS(2 * s)
+    if (w == 0) {
+      double ajj = readlane_d(a[0], 16 * s);
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        bad = (bad == 0 && !(ajj > 0.0)) ? 16 * s + c + 1 : bad;
+        const double y0 = __builtin_amdgcn_rsq(ajj);
+        double g = ajj * y0, h = 0.5 * y0;
+        double r = __builtin_fma(-h, g, 0.5);
+        g = __builtin_fma(g, r, g);
+        h = __builtin_fma(h, r, h);
+        r = __builtin_fma(-h, g, 0.5);
+        const double dj = __builtin_fma(g, r, g);
+        const double inv = 2.0 * __builtin_fma(h, r, h);
+        const double lc = a[c] * inv;
+        if (c < 15) {
+          const double t = __builtin_fma(-lc, lc, a[c + 1]);
+          ajj = readlane_d(t, 16 * s + c + 1);
+        }
+        a[c] = (i == 16 * s + c) ? dj : lc;
+        myinv = (i == 16 * s + c) ? inv : myinv;
+#pragma unroll
+        for (int k2 = c + 1; k2 < 16; ++k2) a[k2] -= a[c] * readlane_d(a[c], 16 * s + k2);
+#pragma unroll
+        for (int k2 = c + 1; k2 < 16; ++k2) asm volatile("" : "+v"(a[k2]));
+      }
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        St[16 * s + c][i] = a[c];
+        if (i >= 16 * s + c) GPG_ST(&blk[i + (size_t)(16 * s + c) * ld], a[c]);
+      }
+      if (i >= 16 * s && i < 16 * s + 16) GPG_ST(&dinv[i], myinv);
+      if (piece_flags) {
+        GPG_RELEASE();
+        if (i == 0) GPG_FLAG_UP(piece_flags + s);
+      }
+    }
+    GPG_PS(2 * s + 1)
+    if (s < 3) __syncthreads();                            // columns 16 s .. 16 s + 15 of St are final for the next update
+  }
+  return bad;
+}
+
 
 
 // DPP quad_perm broadcast of lane Q of every lane quad (see trsm64_kernel / GPG_QUAD_SUBST)

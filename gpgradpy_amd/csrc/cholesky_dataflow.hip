@@ -163,9 +163,14 @@ tile_chol_task(int tix, double* A, int ld, int c0, int Mt, const int* __restrict
   }
 
   // ---- (1) left-looking accumulation over the finished tile columns ------------------------------------------
+#ifdef GPG_STAMP
+  const unsigned long long tk_start = __builtin_amdgcn_s_memrealtime();
+  unsigned long long tk_spin = 0, tk_gemm = 0, tk_runs = 0;
+#endif
   GPG_PRIO_ACC(ti - tj)
   int kdone = 0;
   while (kdone < tj) {
+    GPG_TR(q0)
     if (tid == 0) {
       int kr = kdone;
       const unsigned long long t_wait = __builtin_amdgcn_s_memrealtime();
@@ -188,12 +193,20 @@ tile_chol_task(int tix, double* A, int ld, int c0, int Mt, const int* __restrict
     const int kr = sh_kr;
     if (kr < 0) return false;                            // abort: drain
     GPG_ACQUIRE();   // the producers' tiles are visible from here on
+    GPG_TR(q1)
     const size_t ck = (size_t)c0 + 64 * (size_t)kdone;
     wave_tile_gemm(acc, A + r0 + 2 * sp + (ck + sk) * (size_t)ld, ld, A + cj + 2 * sp + (ck + sk) * (size_t)ld, ld,
                    4 * (kr - kdone), sA, sB, w, l15, l4, sp, sk);
     __syncthreads();                                     // staging buffers free again; sh_kr may be rewritten
+    GPG_TR(q2)
+#ifdef GPG_STAMP
+    tk_spin += q1 - q0; tk_gemm += q2 - q1; ++tk_runs;
+#endif
     kdone = kr;
   }
+#ifdef GPG_STAMP
+  const unsigned long long tk_fin0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   // ---- (2) accumulators -> LDS tile Ts[col][row] --------------------------------------------------------------
   GPG_PRIO_FIN(ti - tj)
@@ -206,10 +219,10 @@ tile_chol_task(int tix, double* A, int ld, int c0, int Mt, const int* __restrict
   }
   if (ti == tj) {
     __syncthreads();
-    if (w == 0) {   // diagonal tile: factor it (one wave; entries above the diagonal are garbage nobody reads)
+    {   // diagonal tile: factor it (pivots on wave 0, the MFMA updates on all four; entries above the diagonal are garbage nobody reads)
       double* blk = A + r0 + cj * (size_t)ld;
-      const int bad = potrf64_wave(U, SA, reinterpret_cast<double(*)[64]>(&Ls[0][0][0]), blk, ld, dinv + cj, pieces + 4 * tj);
-      if (bad && lane == 0 && (int)cj + bad - 1 < N) atomicCAS(info, 0, (int)cj + bad);
+      const int bad = potrf64_wg(U, SA, reinterpret_cast<double(*)[64]>(&Ls[0][0][0]), blk, ld, dinv + cj, pieces + 4 * tj);
+      if (w == 0 && bad && lane == 0 && (int)cj + bad - 1 < N) atomicCAS(info, 0, (int)cj + bad);
     }
   } else {
     // substitute against the diagonal tile of this column piece by piece, as its 16-column pieces are published
@@ -244,7 +257,19 @@ tile_chol_task(int tix, double* A, int ld, int c0, int Mt, const int* __restrict
     for (int m = 0; m < 16; ++m) GPG_ST(&Xr[(size_t)(4 * m) * ld], x[m]);
   }
   // ---- (3) publish (and fetch the next ticket) --------------------------------------------------------------------
+#ifdef GPG_STAMP
+  const unsigned long long tk_pub0 = __builtin_amdgcn_s_memrealtime();
+#endif
   GPG_PUBLISH_AND_NEXT(ticket, frow_i + tj)
+#ifdef GPG_STAMP
+  if (tid == 0 && g_stamp_buf != nullptr && tix < GPG_STAMP_MAX) {
+    unsigned long long* o = g_stamp_buf + (size_t)tix * 8;
+    o[0] = tk_start; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = tk_spin; o[3] = tk_gemm; o[4] = tk_runs;
+    o[5] = tk_fin0; o[6] = (unsigned long long)task; o[7] = (unsigned long long)blockIdx.x;
+    unsigned long long* fo = g_stamp_buf + (size_t)GPG_STAMP_MAX * 8 + (size_t)tix * 8;
+    fo[0] = tk_fin0; fo[1] = tk_pub0; fo[2] = fo[3] = fo[4] = fo[5] = fo[6] = fo[7] = 0;
+  }
+#endif
   return true;
 }
 
@@ -421,9 +446,10 @@ __device__ __noinline__ int tile128_finalize(double* A, int ld, size_t r0, size_
   if (is_diag) {
     double* blk = A + cj + cj * (size_t)ld;
     double (*St)[64] = reinterpret_cast<double(*)[64]>(&Ls[0][0][0]);   // potrf scratch over the Ls region
-    if (w == 0) {   // A11 was left in the LDS tile by this same wave (no barrier, no trip through memory)
-      const int bad = potrf64_wave(U, SA, St, blk, ld, dinv + cj, pa);   // L11 published in 16-column pieces pa[0..3]
-      if (bad && lane == 0 && (int)cj + bad - 1 < N) atomicCAS(info, 0, (int)cj + bad);
+    __syncthreads();   // A11 was left in the LDS tile by wave 0; the other waves' stores of A21 / A22 are drained below
+    {
+      const int bad = potrf64_wg(U, SA, St, blk, ld, dinv + cj, pa);   // L11 published in 16-column pieces pa[0..3]
+      if (w == 0 && bad && lane == 0 && (int)cj + bad - 1 < N) atomicCAS(info, 0, (int)cj + bad);
     }
     __syncthreads();   // also drains the other waves' stores of A21 / A22
     GPG_FS(1)
@@ -450,9 +476,9 @@ __device__ __noinline__ int tile128_finalize(double* A, int ld, size_t r0, size_
       for (int r = 0; r < 4; ++r) U[(ni * 16 + 4 * r + l4) * SA + 16 * w + l15] = a2[ni][r];
     __syncthreads();
     GPG_FS(3)
-    if (w == 0) {
-      const int bad = potrf64_wave(U, SA, St, blk + 64 + (size_t)64 * ld, ld, dinv + cj + 64, pb);   // L22: pb[0..3]
-      if (bad && lane == 0 && (int)cj + 64 + bad - 1 < N) atomicCAS(info, 0, (int)cj + 64 + bad);
+    {
+      const int bad = potrf64_wg(U, SA, St, blk + 64 + (size_t)64 * ld, ld, dinv + cj + 64, pb);   // L22: pb[0..3]
+      if (w == 0 && bad && lane == 0 && (int)cj + 64 + bad - 1 < N) atomicCAS(info, 0, (int)cj + 64 + bad);
     }
     GPG_FS(4)
     return 1;

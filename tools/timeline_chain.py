@@ -16,6 +16,11 @@ for v in diag:
         inc.append(e - prev)
     prev = e
 inc = np.array(inc)
+sub = sorted([v for v in R if v['ti'] == v['tj'] + 1], key=lambda v: v['tj'])
+if sub:
+    print('first sub-diagonal tile (j+1, j): mean residency %.1f us, K-loop %.1f, spin %.1f, after K-loop (wait for pieces + substitution + publish) %.1f' % (
+        np.mean([v['end'] - v['start'] for v in sub]) / 100, np.mean([v['gemm_cyc'] for v in sub]) / 100, np.mean([v['spin_cyc'] for v in sub]) / 100,
+        np.mean([v['end'] - v['fin0'] for v in sub]) / 100))
 print(f"{len(diag)} diagonal tasks, span {(max(v['end'] for v in R) - t0) / 100:.0f} us; chain increment per tile column: mean {inc.mean():.1f} us, "
       f"median {np.median(inc):.1f}, first 10 {inc[:10].mean():.1f}, last 10 {inc[-10:].mean():.1f}")
 step = max(1, len(diag) // 12)
