@@ -465,9 +465,14 @@ class HparaOptz:
         self.optz_obj_all_last, self.optz_sol_all_last = optz_obj_all, optz_sol_all
         return best_hp, self._final_cond(best_hp), surr_optz_info
 
+    optz_calc_final_cond = True   # False: skip it where nothing needs it ('precon': the value only goes into Kcov_cond_all)
+
     def _final_cond(self, best_hp):
         """Condition number of the matrix the selected hyperparameters give, for every well-conditioning method
-        (OptzLkd.py:324-331)."""
+        (OptzLkd.py:324-331).  Two Lanczos runs through the factor (~50 ms at N = 2500): with 'precon' the optimisation itself does not
+        use it, optz_calc_final_cond = False then stores NaN instead."""
+        if not self.optz_calc_final_cond and not self.b_use_cond_cstr:
+            return np.nan
         return self.calc_lkd_all(self.hp_vec2dataclass(self.hp_info_optz_lkd, best_hp), calc_cond=True)[0].cond
 
     def _run_starts_lockstep(self, hp_x0_all, lo, hi, optz_bound, optz_opt, sol, obj, success, nit):
