@@ -908,6 +908,37 @@ rows_fwd_task(int tix, const double* __restrict__ A, int ld, const double* __res
   return true;
 }
 
+// The same product on 64 x 64 tiles (wave_tile_gemm, the MFMA loop of tile_chol_kernel): for ONE small matrix the 128-tile list has fewer
+// tasks than the device has workgroup slots (210 at 2560 columns) and its longest contraction is the whole launch; four times as many
+// tiles of a quarter of the work fill the slots and halve the longest task.  tasks[t] = a | b << 16, a >= b, longest first.
+__global__ void __launch_bounds__(256, 2)
+tile64_wwt_kernel(const double* __restrict__ W, int ldw, double* __restrict__ M, int ldm, int Mt, const int* __restrict__ tasks, int ntask,
+                  int* ticket) {
+  constexpr int KB = 16, SA = 80, BUF = KB * SA;
+  __shared__ __attribute__((aligned(16))) double U[4 * BUF];
+  __shared__ int sh_tix;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, l4 = lane >> 4, sp = tid & 31, sk = tid >> 5;
+  for (int round = 0;; ++round) {
+    const int tix = next_ticket(ticket, &sh_tix, round);
+    if (tix >= ntask) return;
+    const int task = tasks[tix];
+    const int ta = task & 0xffff, tb = task >> 16;        // a >= b
+    const size_t r0 = 64 * (size_t)ta, c0 = 64 * (size_t)tb, ck = 64 * (size_t)ta;   // W is upper triangular: columns >= 64 a
+    d4 acc[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[ni][r] = 0.0;
+    wave_tile_gemm(acc, W + r0 + 2 * sp + (ck + sk) * (size_t)ldw, ldw, W + c0 + 2 * sp + (ck + sk) * (size_t)ldw, ldw, 4 * (Mt - ta), U,
+                   U + 2 * BUF, w, l15, l4, sp, sk);
+    double* Cw = M + r0 + 16 * w + l15 + (c0 + l4) * (size_t)ldm;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Cw[(size_t)(ni * 16 + 4 * r) * ldm] = acc[ni][r];
+    __syncthreads();                                      // staging buffers and sh_tix free for the next round
+  }
+}
 __global__ void __launch_bounds__(256, 2)
 rows_fwd_kernel(const double* __restrict__ A, int ld, const double* __restrict__ dinv, double* W, int ldw, int Mt, int nrt,
                 int valid, int* flags, int* abort_word, int* ticket, int* info) {
@@ -1499,6 +1530,23 @@ static bool launch_tile128_inverse_batch(gpg_ctx* c, int B, const double* Abase,
     hipLaunchKernelGGL(tile128_trinv_kernel, dim3(persistent_grid(c, tile128_trinv_kernel, tm.n)), dim3(256), 0, c->stream,
                        TrinvArgs{Abase, c->ld, dinv_base, Wbase, ldw, Mt, tasks1, tm.n, c->tile_flags, ones, ones + 9, ones + 10, info_base,
                                  B > 1 ? bof1 : nullptr, a_stride, w_stride, d_stride, (int)per});
+  if (small && B == 1) {   // one small matrix: -(W W^T) on 64-tiles too (task list cached under its own key)
+    const unsigned long long key64 = (3ull << 61) | (1ull << 59) | (unsigned long long)Mt64;
+    auto i64 = c->tilemaps.find(key64);
+    if (i64 == c->tilemaps.end()) {
+      std::vector<int> l64;
+      for (int a = 0; a < Mt64; ++a)
+        for (int bb = 0; bb <= a; ++bb) l64.push_back(a | (bb << 16));
+      TileMap t64;
+      t64.n = (int)l64.size();
+      if (!gpg_dev_alloc(c, &t64.dev, sizeof(int) * l64.size())) return false;
+      (void)hipMemcpy(t64.dev, l64.data(), sizeof(int) * l64.size(), hipMemcpyHostToDevice);
+      i64 = c->tilemaps.emplace(key64, t64).first;
+    }
+    hipLaunchKernelGGL(tile64_wwt_kernel, dim3(persistent_grid(c, tile64_wwt_kernel, i64->second.n)), dim3(256), 0, c->stream,
+                       (const double*)Wbase, ldw, Mbase, ldw, Mt64, (const int*)i64->second.dev, i64->second.n, ones + 11);
+    return true;
+  }
   hipLaunchKernelGGL(tile128_wwt_kernel, dim3(persistent_grid(c, tile128_wwt_kernel, n2)), dim3(256), 0, c->stream,
                      (const double*)Wbase, ldw, Mbase, ldw, Mt, tasks2, n2, ones + 11, B > 1 ? bof2 : (const int*)nullptr, w_stride,
                      (const double*)nullptr, 0);
