@@ -18,7 +18,9 @@
 
 namespace {
 
-constexpr int kTBg = 16;
+constexpr int kTBg = 16;          // b-points staged per workgroup (at most)
+// Small designs: fewer b-points per workgroup, so that the launch has enough workgroups for the chip (n = 500: 64 -> 250).
+static inline int grad_tb(int n) { return n <= 1024 ? 4 : kTBg; }
 
 __device__ __forceinline__ double wave_sum_g(double v) {
 #pragma unroll
@@ -51,7 +53,7 @@ __global__ void __launch_bounds__(256, 2) grad_contract_kernel(AsmParams P, cons
                                                             const double* __restrict__ invp,
                                                             const double* __restrict__ zvec,
                                                             const double* __restrict__ Minv, int ldm,
-                                                            double* __restrict__ partial) {
+                                                            double* __restrict__ partial, int tb) {
   constexpr int RQ = KERN == GPG_KERNEL_RATQU ? 1 : 0;
   constexpr int NS = D + 3 + RQ;            // theta_0..D-1, varK, var_fval, var_fgrad (, alpha of RatQu)
   __shared__ double xb[kTBg][D];
@@ -61,13 +63,13 @@ __global__ void __launch_bounds__(256, 2) grad_contract_kernel(AsmParams P, cons
   __shared__ double red[2 * NS][4];
   const int n = P.n, ng = P.ng;
   const int a = blockIdx.x * 256 + threadIdx.x;
-  const int b0 = blockIdx.y * kTBg;
+  const int b0 = blockIdx.y * tb;
   const int nblk = P.use_grad ? D + 1 : 1;
-  for (int t = threadIdx.x; t < kTBg * D; t += 256) {
+  for (int t = threadIdx.x; t < tb * D; t += 256) {
     int bb = t / D, k = t % D, b = b0 + bb;
     xb[bb][k] = b < n ? Xt[(size_t)k * n + b] : 0.0;
   }
-  for (int t = threadIdx.x; t < kTBg * (D + 1); t += 256) {
+  for (int t = threadIdx.x; t < tb * (D + 1); t += 256) {
     int bb = t / (D + 1), J = t % (D + 1), b = b0 + bb;
     double v = 0.0, al = 0.0;
     if (b < n && J < nblk) {
@@ -80,7 +82,7 @@ __global__ void __launch_bounds__(256, 2) grad_contract_kernel(AsmParams P, cons
     ipb[bb][J] = v;
     alb[bb][J] = al;
   }
-  if (threadIdx.x < kTBg) gpb[threadIdx.x] = (b0 + threadIdx.x < n) ? P.gpos[b0 + threadIdx.x] : -1;
+  if (threadIdx.x < tb) gpb[threadIdx.x] = (b0 + threadIdx.x < n) ? P.gpos[b0 + threadIdx.x] : -1;
   __syncthreads();
 
   double ga[NS], gi[NS];
@@ -103,7 +105,7 @@ __global__ void __launch_bounds__(256, 2) grad_contract_kernel(AsmParams P, cons
     }
     const double vK = P.varK, eta = P.eta;
     const int precon = P.precon;
-    const int bend = min(kTBg, n - b0);
+    const int bend = min(tb, n - b0);
     const double sqrt5 = sqrt(5.0);
     const double rq_alpha = P.hp_kernel, rq_s1 = 1.0 + 1.0 / P.hp_kernel, rq_s2 = rq_s1 * (1.0 + 2.0 / P.hp_kernel);   // scalar1, scalar2 (:704-705)
     const double rq_c = 4.0 * rq_s1, rq_dc = 4.0 / (P.hp_kernel * P.hp_kernel);          // const (:529) and -d const / d alpha
@@ -339,11 +341,11 @@ __global__ void grad_final_reduce_kernel(const double* __restrict__ partial, int
 }
 
 template <int KERN>
-void launch_contract_d(gpg_ctx* c, const AsmParams& p, double* partial, dim3 grid, const double* zvec, const double* Minv) {
+void launch_contract_d(gpg_ctx* c, const AsmParams& p, double* partial, dim3 grid, const double* zvec, const double* Minv, int tb) {
 #define CASE_D(DD)                                                                                               \
   case DD:                                                                                                       \
     hipLaunchKernelGGL((grad_contract_kernel<KERN, DD>), grid, dim3(256), 0, c->stream, p, c->Xt, c->invp, zvec,   \
-                       Minv, c->Npad, partial);                                                                  \
+                       Minv, c->Npad, partial, tb);                                                              \
     break;
   switch (p.d) {
     CASE_D(1) CASE_D(2) CASE_D(3) CASE_D(4) CASE_D(5) CASE_D(6) CASE_D(7) CASE_D(8)
@@ -371,10 +373,11 @@ void gpg_launch_grad_contract(gpg_ctx* c, const AsmParams& p_in, double* partial
                               const double* Minv) {
   AsmParams p = p_in;
   if (c->grad_eta >= 0.0) p.eta = c->grad_eta;   // the reference differentiates with self._etaK whatever nugget the matrix got
-  dim3 grid((p.n + 255) / 256, (p.n + kTBg - 1) / kTBg);
-  if (p.kernel == GPG_KERNEL_SQEXP) launch_contract_d<GPG_KERNEL_SQEXP>(c, p, partial, grid, zvec, Minv);
-  else if (p.kernel == GPG_KERNEL_RATQU) launch_contract_d<GPG_KERNEL_RATQU>(c, p, partial, grid, zvec, Minv);
-  else launch_contract_d<GPG_KERNEL_MA5F2>(c, p, partial, grid, zvec, Minv);
+  const int tb = grad_tb(p.n);
+  dim3 grid((p.n + 255) / 256, (p.n + tb - 1) / tb);
+  if (p.kernel == GPG_KERNEL_SQEXP) launch_contract_d<GPG_KERNEL_SQEXP>(c, p, partial, grid, zvec, Minv, tb);
+  else if (p.kernel == GPG_KERNEL_RATQU) launch_contract_d<GPG_KERNEL_RATQU>(c, p, partial, grid, zvec, Minv, tb);
+  else launch_contract_d<GPG_KERNEL_MA5F2>(c, p, partial, grid, zvec, Minv, tb);
   const int ns = p.d + 3 + (p.kernel == GPG_KERNEL_RATQU ? 1 : 0);
   hipLaunchKernelGGL(grad_final_reduce_kernel, dim3(2 * ns), dim3(64), 0, c->stream, partial, (int)(grid.x * grid.y),
                      2 * ns, out_dev);
@@ -384,4 +387,4 @@ void gpg_launch_unscale(gpg_ctx* c, const double* v, double* z) {
   hipLaunchKernelGGL(unscale_kernel, dim3((c->Npad + 255) / 256), dim3(256), 0, c->stream, v, c->invp, c->N, c->Npad, z);
 }
 
-int gpg_grad_partial_blocks(const gpg_ctx* c) { return ((c->n + 255) / 256) * ((c->n + kTBg - 1) / kTBg); }
+int gpg_grad_partial_blocks(const gpg_ctx* c) { const int tb = grad_tb(c->n); return ((c->n + 255) / 256) * ((c->n + tb - 1) / tb); }
