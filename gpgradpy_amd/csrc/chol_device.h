@@ -158,12 +158,17 @@ __device__ __forceinline__ int potrf64_wave(const double* src, int sld, double (
 // potrf64_wave; the MFMA update that precedes the pivots of sub-block s (64 x 16 panel -= L[:, :16 s] L[16 s : 16 s + 16, :16 s]^T) is
 // spread over the waves -- wave R takes the 16-row tile R of the panel, tiles above the diagonal block (R < s) are skipped -- so its
 // chain is 4 s dependent MFMAs instead of 16 s issued by one wave (potrf_probe: 2.1 / 3.2 / 4.6 k cycles of 33 k for s = 1 / 2 / 3
-// in the one-wave version).  Two workgroup barriers per sub-block; the return value is that of wave 0 (other waves return 0).
+// in the one-wave version) -- and all but the last four of them run AHEAD, during the pivot chain of the previous sub-block (waves
+// 1 .. 3 are idle then): what stays between two pivot phases is a rank-16 update.  Two workgroup barriers per sub-block; the return
+// value is that of wave 0 (other waves return 0).
 __device__ __forceinline__ int potrf64_wg(const double* src, int sld, double (*St)[64], double* __restrict__ blk, int ld,
                                           double* __restrict__ dinv, int* piece_flags = nullptr) {
   const int w = threadIdx.x >> 6, i = threadIdx.x & 63, l15 = i & 15, l4 = i >> 4;
   int bad = 0;
   double myinv = 0.0;
+  d4 pre;                                                  // tile R = w of the NEXT sub-block's panel, updated with every sub-block before the current one
+#pragma unroll
+  for (int r = 0; r < 4; ++r) pre[r] = 0.0;
 #pragma unroll
   for (int s = 0; s < 4; ++s) {
     double a[16];
@@ -173,18 +178,15 @@ __device__ __forceinline__ int potrf64_wg(const double* src, int sld, double (*S
         for (int c = 0; c < 16; ++c) a[c] = src[i + (size_t)c * sld];
       }
     } else {
-      if (w >= s) {                                        // tile R = w of the panel; R < s lies above the diagonal block
-        d4 acc;
+      if (w >= s) {                                        // what is left of this sub-block's update: the 16 columns just factored
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = src[(16 * w + l15) + (size_t)(16 * s + 4 * r + l4) * sld];
-#pragma unroll
-        for (int kk = 0; kk < 4 * s; ++kk) {
+        for (int kk = 4 * (s - 1); kk < 4 * s; ++kk) {
           const double fn = St[4 * kk + l4][16 * s + l15];
           const double fm = -St[4 * kk + l4][16 * w + l15];
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fn, fm, acc, 0, 0, 0);
+          pre = __builtin_amdgcn_mfma_f64_16x16x4f64(fn, fm, pre, 0, 0, 0);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) St[16 * s + 4 * r + l4][16 * w + l15] = acc[r];
+        for (int r = 0; r < 4; ++r) St[16 * s + 4 * r + l4][16 * w + l15] = pre[r];
       }
       __syncthreads();                                     // the updated panel is in St[16 s .. 16 s + 15][.]
       if (w == 0) {
@@ -227,6 +229,17 @@ __device__ __forceinline__ int potrf64_wg(const double* src, int sld, double (*S
       if (piece_flags) {
         GPG_RELEASE();
         if (i == 0) GPG_FLAG_UP(piece_flags + s);
+      }
+    } else if (s < 3 && w >= s + 1) {
+      // look-ahead, while wave 0 runs the pivot chain: the next sub-block's tile, updated with the columns that are already final
+      // (sub-blocks 0 .. s-1); only the rank-16 part of sub-block s is left for after the barrier
+#pragma unroll
+      for (int r = 0; r < 4; ++r) pre[r] = src[(16 * w + l15) + (size_t)(16 * (s + 1) + 4 * r + l4) * sld];
+#pragma unroll
+      for (int kk = 0; kk < 4 * s; ++kk) {
+        const double fn = St[4 * kk + l4][16 * (s + 1) + l15];
+        const double fm = -St[4 * kk + l4][16 * w + l15];
+        pre = __builtin_amdgcn_mfma_f64_16x16x4f64(fn, fm, pre, 0, 0, 0);
       }
     }
     GPG_PS(2 * s + 1)
