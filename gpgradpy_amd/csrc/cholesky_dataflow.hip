@@ -124,7 +124,7 @@ __shared__ int g_next_ticket;
 __device__ __forceinline__ bool
 tile_chol_task(int tix, double* A, int ld, int c0, int Mt, const int* __restrict__ tasks, int* flags, int* pieces, int* abort_word,
                int* ticket, double* __restrict__ dinv, int* __restrict__ info, int N, const int* __restrict__ batch_of, size_t a_stride,
-               int d_stride, int f_stride) {
+               int d_stride, int f_stride, int fuse) {
   constexpr int KB = 16, SA = 80, BUF = KB * SA;
   __shared__ __attribute__((aligned(16))) double U[4 * BUF];      // staging sA[2] | sB[2]; later the tile Ts[64][SA]
   __shared__ __attribute__((aligned(16))) double Ls[64][4][18];   // L_jj image (i > j) / potrf scratch St[64][64] (i == j)
@@ -149,8 +149,15 @@ tile_chol_task(int tix, double* A, int ld, int c0, int Mt, const int* __restrict
   const size_t cj = (size_t)c0 + 64 * (size_t)tj;        // first matrix column of the tile
   const int q = tid & 3;
   const int sp = tid & 31, sk = tid >> 5;
+  // Fused diagonal task (fuse != 0, tj > 0): this workgroup ALSO owns the sub-diagonal tile (tj, tj-1) -- the task list has no task of
+  // its own for it.  It carries that tile's accumulators (acc1) next to its own, substitutes them against the pieces of the previous
+  // diagonal tile as they are published, and applies the result to its own accumulators from LDS: the chain diagonal tile -> tile
+  // (j+1, j) -> store / flag / poll / reload -> diagonal tile (j+1, j+1) loses its two trips through memory (~20.7 -> ~17 us per column).
+  const bool fused = fuse != 0 && ti == tj && tj > 0;
+  const int kend = fused ? tj - 1 : tj;                  // tile columns the MFMA loop covers (the fused task's last one comes from LDS)
+  const size_t cjm = cj - 64;                            // first matrix column of tile column tj - 1 (fused only)
   int* const frow_i = flags + (size_t)ti * Mt;           // flags of tile row i
-  int* const frow_j = flags + (size_t)tj * Mt;
+  int* const frow_j = flags + (size_t)(fused ? tj - 1 : tj) * Mt;
 
   // accumulators start as A_ij
   d4 acc[4];
@@ -161,6 +168,14 @@ tile_chol_task(int tix, double* A, int ld, int c0, int Mt, const int* __restrict
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[ni][r] = Cw[(size_t)(ni * 16 + 4 * r) * ld];
   }
+  d4 acc1[4];                                            // fused: A(tj, tj-1), nobody else writes that tile
+  if (fused) {
+    const double* Cw = A + r0 + 16 * w + l15 + (cjm + l4) * (size_t)ld;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc1[ni][r] = Cw[(size_t)(ni * 16 + 4 * r) * ld];
+  }
 
   // ---- (1) left-looking accumulation over the finished tile columns ------------------------------------------
 #ifdef GPG_STAMP
@@ -168,17 +183,24 @@ tile_chol_task(int tix, double* A, int ld, int c0, int Mt, const int* __restrict
   unsigned long long tk_spin = 0, tk_gemm = 0, tk_runs = 0;
 #endif
   GPG_PRIO_ACC(ti - tj)
-  int kdone = 0;
-  while (kdone < tj) {
+  __shared__ int sh_kr1;
+  int kdone = 0, kd1 = 0;                                // tile columns applied to acc / to the fused task's acc1
+  while (kdone < kend || (fused && kd1 < kend)) {
     GPG_TR(q0)
     if (tid == 0) {
-      int kr = kdone;
+      int kr = kdone, kr1 = kd1;
       const unsigned long long t_wait = __builtin_amdgcn_s_memrealtime();
       for (;;) {
-        while (kr < tj && __hip_atomic_load(frow_i + kr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 &&
-               __hip_atomic_load(frow_j + kr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
-          ++kr;
-        if (kr > kdone) break;
+        if (fused) {   // own accumulators: tile row tj only; acc1: tile rows tj and tj - 1 -- the two frontiers advance independently
+          while (kr < kend && __hip_atomic_load(frow_i + kr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ++kr;
+          while (kr1 < kr && __hip_atomic_load(frow_j + kr1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ++kr1;
+          if (kr > kdone || kr1 > kd1) break;
+        } else {
+          while (kr < kend && __hip_atomic_load(frow_i + kr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 &&
+                 __hip_atomic_load(frow_j + kr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+            ++kr;
+          if (kr > kdone) break;
+        }
         if (__builtin_amdgcn_s_memrealtime() - t_wait > GPG_TILE_WAIT_TICKS || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
           __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           atomicMax(info, GPG_INFO_INTERNAL);
@@ -188,28 +210,96 @@ tile_chol_task(int tix, double* A, int ld, int c0, int Mt, const int* __restrict
         __builtin_amdgcn_s_sleep(4);
       }
       sh_kr = kr;
+      sh_kr1 = kr1;
     }
     __syncthreads();
-    const int kr = sh_kr;
+    const int kr = sh_kr, kr1 = sh_kr1;
     if (kr < 0) return false;                            // abort: drain
     GPG_ACQUIRE();   // the producers' tiles are visible from here on
     GPG_TR(q1)
-    const size_t ck = (size_t)c0 + 64 * (size_t)kdone;
-    wave_tile_gemm(acc, A + r0 + 2 * sp + (ck + sk) * (size_t)ld, ld, A + cj + 2 * sp + (ck + sk) * (size_t)ld, ld,
-                   4 * (kr - kdone), sA, sB, w, l15, l4, sp, sk);
+    if (kr > kdone) {
+      const size_t ck = (size_t)c0 + 64 * (size_t)kdone;
+      wave_tile_gemm(acc, A + r0 + 2 * sp + (ck + sk) * (size_t)ld, ld, A + cj + 2 * sp + (ck + sk) * (size_t)ld, ld,
+                     4 * (kr - kdone), sA, sB, w, l15, l4, sp, sk);
+    }
     __syncthreads();                                     // staging buffers free again; sh_kr may be rewritten
+    if (fused && kr1 > kd1) {                            // the sub-diagonal tile's share: rows tj against rows tj - 1
+      const size_t ck = (size_t)c0 + 64 * (size_t)kd1;
+      wave_tile_gemm(acc1, A + r0 + 2 * sp + (ck + sk) * (size_t)ld, ld, A + cjm + 2 * sp + (ck + sk) * (size_t)ld, ld,
+                     4 * (kr1 - kd1), sA, sB, w, l15, l4, sp, sk);
+      __syncthreads();
+    }
     GPG_TR(q2)
 #ifdef GPG_STAMP
     tk_spin += q1 - q0; tk_gemm += q2 - q1; ++tk_runs;
 #endif
     kdone = kr;
+    kd1 = kr1;
   }
 #ifdef GPG_STAMP
   const unsigned long long tk_fin0 = __builtin_amdgcn_s_memrealtime();
 #endif
 
-  // ---- (2) accumulators -> LDS tile Ts[col][row] --------------------------------------------------------------
   GPG_PRIO_FIN(ti - tj)
+  // one 16-column piece of the diagonal tile of tile column PC (matrix column PCJ): wait, image, quad-row substitution of x
+#define GPG_TC_PIECE(S, PC, PCJ)                                                             \
+    {                                                                                       \
+      if (!wg_wait_flag(pieces + 4 * (PC) + (S), abort_word, info, &sh_kr)) return false;    \
+      _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                        \
+        const int t = tid + 256 * u, jj = 16 * (S) + (t >> 6), k = t & 63;                   \
+        Ls[jj][k & 3][k >> 2] = (A + (PCJ) + (PCJ) * (size_t)ld)[k + (size_t)jj * ld];       \
+      }                                                                                     \
+      if (tid < 16) sdinv[16 * (S) + tid] = dinv[(PCJ) + 16 * (S) + tid];                    \
+      __syncthreads();                                                                      \
+      GPG_QUAD_SUBST_PIECE(x, Ls, sdinv, q, S)                                               \
+      /* pin x: otherwise the FMAs of a piece are deferred into the next ones and everything spills */ \
+      _Pragma("unroll") for (int m = 0; m < 16; ++m) asm volatile("" : "+v"(x[m]));              \
+    }
+  if (fused) {
+    // ---- (1') the sub-diagonal tile: acc1 -> LDS -> quad rows, substitution against L(tj-1, tj-1) piece by piece, then out to memory
+    //      (asynchronously) and, through the LDS tile, into this task's own accumulators: acc -= X X^T ------------------------------
+    {
+      double* Ts = U;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ts[(ni * 16 + 4 * r + l4) * SA + 16 * w + l15] = acc1[ni][r];
+    }
+    __syncthreads();
+    double x[16];
+    {
+      const double* Tr = U + q * SA + (tid >> 2);
+#pragma unroll
+      for (int m = 0; m < 16; ++m) x[m] = Tr[(4 * m) * SA];
+    }
+    GPG_TC_PIECE(0, tj - 1, cjm)
+    GPG_TC_PIECE(1, tj - 1, cjm)
+    GPG_TC_PIECE(2, tj - 1, cjm)
+    GPG_TC_PIECE(3, tj - 1, cjm)
+    {
+      double* Xr = A + r0 + (tid >> 2) + (cjm + q) * (size_t)ld;
+      double* Tw = U + q * SA + (tid >> 2);
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        GPG_ST(&Xr[(size_t)(4 * m) * ld], x[m]);
+        Tw[(4 * m) * SA] = x[m];                          // every thread rewrites exactly the entries it read: no barrier needed before
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 64; kk += 4) {
+      const double fm = -U[(kk + l4) * SA + 16 * w + l15];
+      double fn[4];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) fn[ni] = U[(kk + l4) * SA + ni * 16 + l15];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(fn[ni], fm, acc[ni], 0, 0, 0);
+    }
+    GPG_RELEASE();                                        // the stores of X have had the whole update to complete
+    __syncthreads();                                      // ... and the LDS tile is free again
+    if (tid == 0) GPG_FLAG_UP(frow_i + (tj - 1));          // tile (tj, tj-1) is final for everybody else
+  }
+  // ---- (2) accumulators -> LDS tile Ts[col][row] --------------------------------------------------------------
   {
     double* Ts = U;
 #pragma unroll
@@ -233,24 +323,10 @@ tile_chol_task(int tix, double* A, int ld, int c0, int Mt, const int* __restrict
 #pragma unroll
       for (int m = 0; m < 16; ++m) x[m] = Tr[(4 * m) * SA];
     }
-    const double* Ljj = A + cj + cj * (size_t)ld;
-#define GPG_TC_PIECE(S)                                                                      \
-    {                                                                                       \
-      if (!wg_wait_flag(pieces + 4 * tj + (S), abort_word, info, &sh_kr)) return false;      \
-      _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                        \
-        const int t = tid + 256 * u, jj = 16 * (S) + (t >> 6), k = t & 63;                   \
-        Ls[jj][k & 3][k >> 2] = Ljj[k + (size_t)jj * ld];                                    \
-      }                                                                                     \
-      if (tid < 16) sdinv[16 * (S) + tid] = dinv[cj + 16 * (S) + tid];                       \
-      __syncthreads();                                                                      \
-      GPG_QUAD_SUBST_PIECE(x, Ls, sdinv, q, S)                                               \
-      /* pin x: otherwise the FMAs of a piece are deferred into the next ones and everything spills */ \
-      _Pragma("unroll") for (int m = 0; m < 16; ++m) asm volatile("" : "+v"(x[m]));              \
-    }
-    GPG_TC_PIECE(0)
-    GPG_TC_PIECE(1)
-    GPG_TC_PIECE(2)
-    GPG_TC_PIECE(3)
+    GPG_TC_PIECE(0, tj, cj)
+    GPG_TC_PIECE(1, tj, cj)
+    GPG_TC_PIECE(2, tj, cj)
+    GPG_TC_PIECE(3, tj, cj)
 #undef GPG_TC_PIECE
     double* Xr = A + r0 + (tid >> 2) + (cj + q) * (size_t)ld;
 #pragma unroll
@@ -275,14 +351,14 @@ tile_chol_task(int tix, double* A, int ld, int c0, int Mt, const int* __restrict
 
 struct TileCholArgs {
   double* A; int ld, c0, Mt; const int* tasks; int ntask; int* flags; int* pieces; int* abort_word; int* ticket; double* dinv;
-  int* info; int N; const int* batch_of; size_t a_stride; int d_stride, f_stride;
+  int* info; int N; const int* batch_of; size_t a_stride; int d_stride, f_stride, fuse;
 };
 
 __device__ __noinline__ int tile_chol_task_call(int tix_v, unsigned long long kernarg_bits) {
   GPG_KERNARGS_FROM(TileCholArgs, ap, kernarg_bits);
   const int tix = __builtin_amdgcn_readfirstlane(tix_v);
   return tile_chol_task(tix, ap->A, ap->ld, ap->c0, ap->Mt, ap->tasks, ap->flags, ap->pieces, ap->abort_word, ap->ticket, ap->dinv,
-                        ap->info, ap->N, ap->batch_of, ap->a_stride, ap->d_stride, ap->f_stride) ? 1 : 0;
+                        ap->info, ap->N, ap->batch_of, ap->a_stride, ap->d_stride, ap->f_stride, ap->fuse) ? 1 : 0;
 }
 
 __global__ void __launch_bounds__(256, 2) tile_chol_kernel(TileCholArgs) {
@@ -1314,31 +1390,36 @@ __global__ void __launch_bounds__(256) vec_solve_kernel(VecSolveArgs) {
 //            tile (j+1, j+1) right after it -- it only reads tile row j+1, which (j+1, j) completes -- then the rest of column j.
 //            The diagonal tile's potrf / L21 / syrk / potrf chain (~100 us under contention) then runs while column j is still in its
 //            MFMA loops, instead of after them with the whole column j+1 waiting for its pieces.
+// fuse: the sub-diagonal tiles (j+1, j) of the matrix have no task of their own -- the diagonal task (j+1, j+1) of the 64-tile kernel
+// computes and publishes them (tile_chol_task); it only reads earlier tile columns and the pieces of diagonal tile (j, j), all with
+// smaller tickets.
 template <typename F>
-static void for_each_chol_task(int Mt, int Rt, int B, int order, F emit /* (b, i, j) */) {
+static void for_each_chol_task(int Mt, int Rt, int B, int order, F emit /* (b, i, j) */, bool fuse = false) {
   if (order == 0) {
     for (int j = 0; j < Mt; ++j)
       for (int b = 0; b < B; ++b)
-        for (int i = j; i < Rt; ++i) emit(b, i, j);
+        for (int i = j; i < Rt; ++i)
+          if (!(fuse && i == j + 1 && i < Mt)) emit(b, i, j);
     return;
   }
   for (int b = 0; b < B; ++b) emit(b, 0, 0);
   for (int j = 0; j < Mt; ++j) {
     const bool next_diag = j + 1 < Mt;
     if (next_diag)
-      for (int b = 0; b < B; ++b) { emit(b, j + 1, j); emit(b, j + 1, j + 1); }
+      for (int b = 0; b < B; ++b) { if (!fuse) emit(b, j + 1, j); emit(b, j + 1, j + 1); }
     for (int b = 0; b < B; ++b)
       for (int i = j + (next_diag ? 2 : 1); i < Rt; ++i) emit(b, i, j);
   }
 }
 
 // Task list of the dataflow factorisation of one matrix, cached per shape and order.
-const TileMap& get_tile_tasks(gpg_ctx* c, int Mt, int Rt) {
-  const unsigned long long key = (1ull << 63) | ((unsigned long long)(c->task_order & 1) << 60) | ((unsigned long long)Mt << 20) | (unsigned)Rt;
+const TileMap& get_tile_tasks(gpg_ctx* c, int Mt, int Rt, bool fuse) {
+  const unsigned long long key = (1ull << 63) | ((unsigned long long)(c->task_order & 1) << 60) | ((unsigned long long)(fuse ? 1 : 0) << 59) |
+                                 ((unsigned long long)Mt << 20) | (unsigned)Rt;
   auto it = c->tilemaps.find(key);
   if (it != c->tilemaps.end()) return it->second;
   std::vector<int> list;
-  for_each_chol_task(Mt, Rt, 1, c->task_order, [&](int, int i, int j) { list.push_back(i | (j << 16)); });
+  for_each_chol_task(Mt, Rt, 1, c->task_order, [&](int, int i, int j) { list.push_back(i | (j << 16)); }, fuse);
   TileMap tm;
   tm.n = (int)list.size();
   tm.dev = nullptr;
@@ -1385,7 +1466,10 @@ static bool ensure_tile_flags(gpg_ctx* c, size_t nflag) {
 static void launch_tile_chol(gpg_ctx* c, int c0) {
   const int Mt = (c->Npad - c0) / 64, Rt = (c->ld - c0) / 64;
   if (Mt <= 0) return;
-  const TileMap& tm = get_tile_tasks(c, Mt, Rt);
+  // fused diagonal tasks pay while the launch is chain-bound; from ~4000 columns on their doubled MFMA loops are the longer chain
+  // (tools/tile_probe: -8 % at 640 / 1280 columns, -5 % at 2560, +5 % at 5120, +30 % at 9216)
+  const bool fuse = c->fuse_subdiag != 0 && Mt <= c->fuse_subdiag_max_tiles;
+  const TileMap& tm = get_tile_tasks(c, Mt, Rt, fuse);
   if (!tm.dev) return;
   const size_t nflag = (size_t)Mt * Rt + 1 + 4 * (size_t)Mt + 8;   // tile flags, abort word, four piece flags per diagonal tile, ticket words
   if (!ensure_tile_flags(c, nflag)) return;
@@ -1395,7 +1479,7 @@ static void launch_tile_chol(gpg_ctx* c, int c0) {
   int* abort_word = c->tile_flags + (size_t)Mt * Rt;
   hipLaunchKernelGGL(tile_chol_kernel, dim3(persistent_grid(c, tile_chol_kernel, tm.n)), dim3(256), 0, c->stream,
                      TileCholArgs{c->A, c->ld, c0, Mt, tm.dev, tm.n, c->tile_flags, abort_word + 1, abort_word, c->tile_flags + (nflag - 8),
-                                  c->dinv, c->info, c->N, nullptr, 0, 0, 0});
+                                  c->dinv, c->info, c->N, nullptr, 0, 0, 0, fuse ? 1 : 0});
   gpg_prof_end(c);
 }
 
@@ -1406,11 +1490,14 @@ static void launch_tile_chol(gpg_ctx* c, int c0) {
 static void launch_tile_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a_stride, double* dinv_base, int d_stride,
                                    int* info_base) {
   const int Mt = c->Npad / 64, Rt = c->ld / 64;
-  const unsigned long long key = (2ull << 62) | ((unsigned long long)(c->task_order & 1) << 60) | ((unsigned long long)B << 40) | ((unsigned long long)Mt << 20) | (unsigned)Rt;
+  // batched launches are throughput-bound, not chain-bound: the fused task's doubled loop costs +27 % there (tile_probe, 64 x 1280 columns)
+  const bool fuse = c->fuse_subdiag != 0 && B == 1 && Mt <= c->fuse_subdiag_max_tiles;
+  const unsigned long long key = (2ull << 62) | ((unsigned long long)(c->task_order & 1) << 60) | ((unsigned long long)(fuse ? 1 : 0) << 59) |
+                                 ((unsigned long long)B << 40) | ((unsigned long long)Mt << 20) | (unsigned)Rt;
   auto it = c->tilemaps.find(key);
   if (it == c->tilemaps.end()) {
     std::vector<int> list, bof;
-    for_each_chol_task(Mt, Rt, B, c->task_order, [&](int b, int i, int j) { list.push_back(i | (j << 16)); bof.push_back(b); });
+    for_each_chol_task(Mt, Rt, B, c->task_order, [&](int b, int i, int j) { list.push_back(i | (j << 16)); bof.push_back(b); }, fuse);
     TileMap tm;
     tm.n = (int)list.size();
     if (!gpg_dev_alloc(c, &tm.dev, sizeof(int) * 2 * list.size())) return;
@@ -1427,14 +1514,14 @@ static void launch_tile_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a_st
   int* abort_word = c->tile_flags + (size_t)Mt * Rt;      // the abort word of matrix 0 serves the whole launch
   hipLaunchKernelGGL(tile_chol_kernel, dim3(persistent_grid(c, tile_chol_kernel, tm.n)), dim3(256), 0, c->stream,
                      TileCholArgs{Abase, c->ld, 0, Mt, tm.dev, tm.n, c->tile_flags, abort_word + 1, abort_word, c->tile_flags + (nflag - 8),
-                                  dinv_base, info_base, c->N, tm.dev + tm.n, a_stride, d_stride, (int)per});
+                                  dinv_base, info_base, c->N, tm.dev + tm.n, a_stride, d_stride, (int)per, fuse ? 1 : 0});
   gpg_prof_end(c);
 }
 
 // The whole matrix with the 128-tile dataflow kernel, on c->stream.
 static void launch_tile128_chol(gpg_ctx* c) {
   const int Mt = c->Npad / 128, Rt = c->ld / 128;
-  const TileMap& tm = get_tile_tasks(c, Mt, Rt);
+  const TileMap& tm = get_tile_tasks(c, Mt, Rt, false);
   if (!tm.dev) return;
   const size_t nflag = (size_t)Mt * Rt + 1 + 9 * (size_t)Mt + 8;   // tile flags, abort word, 4 + 4 piece flags and the L21 flag per diagonal tile, ticket words
   if (!ensure_tile_flags(c, nflag)) return;

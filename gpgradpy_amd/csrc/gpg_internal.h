@@ -69,6 +69,8 @@ struct gpg_ctx {
   int* tile_flags = nullptr;   // device: completion flags of the dataflow kernel + abort word + ticket counter
   int num_cus = 0;             // compute units of the device (grid of the persistent launches)
   bool alpha_valid = false;    // zvec of workspace set 0 holds p * alpha of the last gpg_lkd_grad (gpg_lkd_alpha)
+  int fuse_subdiag_max_tiles = 48;   // ... up to this many 64-column tile columns (3072 matrix columns)
+  int fuse_subdiag = 1;        // 64-tile factorisation: diagonal tasks own the sub-diagonal tile below the previous diagonal tile (tile_chol_task)
   int task_order = 0;          // ticket order of the dataflow factorisation (for_each_chol_task in cholesky_dataflow.hip)
   double grad_eta = -1.0;      // >= 0: nugget the hyperparameter derivatives are formed with instead of hp->eta (gpg_set_gradient_nugget)
   int max_workgroups = 0;      // > 0: cap on the grid of every persistent launch (gpg_set_max_workgroups; 0 = co-resident capacity)

@@ -32,6 +32,7 @@ int main(int argc, char** argv) {
   if (getenv("GPG_PROBE_MAX_WG")) c.max_workgroups = atoi(getenv("GPG_PROBE_MAX_WG"));   // cap on the persistent grid (e.g. 256 = one workgroup per CU)
   c.num_cus = 256;
   if (getenv("GPG_PROBE_ORDER")) c.task_order = atoi(getenv("GPG_PROBE_ORDER"));
+  if (getenv("GPG_PROBE_FUSE")) { c.fuse_subdiag = atoi(getenv("GPG_PROBE_FUSE")); c.fuse_subdiag_max_tiles = 1 << 20; }
   hipMalloc(&c.A, sizeof(double) * (size_t)c.ld * n);
   hipMalloc(&c.dinv, sizeof(double) * n);
   hipMalloc(&c.info, sizeof(int));
