@@ -333,13 +333,13 @@ static int gpg_lkd_once(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out) {
   if (!out) { c->err = "out is NULL"; return -1; }
   GPG_HIP_OK(c, hipSetDevice(c->device));
   GPG_WS(c, 0);
-  GPG_HIP_OK(c, hipMemsetAsync(c->info, 0, sizeof(int), c->stream));
+  c->zero_info_in_prep = true;                             // one launch fewer than a memset of the info word
   enqueue_lkd(c, hp, 0);
   GPG_HIP_OK(c, hipMemcpyAsync(c->h_scal, c->scal, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
-  GPG_HIP_OK(c, hipMemcpyAsync(c->h_info, c->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
   GPG_HIP_OK(c, hipGetLastError());
   GPG_LAUNCH_OK(c);
+  c->h_info[0] = (int)c->h_scal[7];                        // lkd_reduce_kernel passes the info word along
   if (internal_failure(c, c->h_info, 1)) return -4;
   c->factor_valid = (c->h_info[0] == 0);
   finish_lkd(c, hp, c->h_scal, c->h_info[0], out);
@@ -360,13 +360,13 @@ static int gpg_lkd_grad_once(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out, dou
   const int nblk = gpg_grad_partial_blocks(c);
   const int nval = 2 * GPG_GRAD_SLOTS_MAX;
   if (!c->gpartial) GPG_HIP_OK(c, hipMalloc(&c->gpartial, sizeof(double) * (size_t)nval * (nblk + 1)));
-  GPG_HIP_OK(c, hipMemsetAsync(c->info, 0, sizeof(int), c->stream));
+  c->zero_info_in_prep = true;
   enqueue_lkd(c, hp, 0);                                   // factor + beta + r'K^-1 r + ln det (scal slot 0)
   GPG_HIP_OK(c, hipMemcpyAsync(c->h_scal, c->scal, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
-  GPG_HIP_OK(c, hipMemcpyAsync(c->h_info, c->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
   GPG_HIP_OK(c, hipGetLastError());
   GPG_LAUNCH_OK(c);
+  c->h_info[0] = (int)c->h_scal[7];
   if (internal_failure(c, c->h_info, 1)) return -4;
   c->factor_valid = (c->h_info[0] == 0);
   finish_lkd(c, hp, c->h_scal, c->h_info[0], out);
@@ -506,7 +506,7 @@ static int gpg_lkd_batch_once(gpg_ctx* c, int m, const double* hp_rows, int row_
                                      c->stream));
         gpg_launch_prep_assembly_batch(c, c->items_host[r0].p, Bg, c->items_dev + r0, 3 * (size_t)c->Npad, c->A_elems);
         gpg_launch_tile_chol_batch(c, Bg, c->batchA, c->A_elems, c->batchV + 2 * (size_t)c->Npad, 3 * c->Npad, info0 + r0);
-        gpg_launch_lkd_reduce_batch(c, r0, Bg, 3 * (size_t)c->Npad, c->A_elems);
+        gpg_launch_lkd_reduce_batch(c, r0, Bg, 3 * (size_t)c->Npad, c->A_elems, info0 + r0);
       } else {
         AsmParams p = make_params(c, &hps[r0], 0);
         c->last_precon = p.precon;
@@ -521,10 +521,10 @@ static int gpg_lkd_batch_once(gpg_ctx* c, int m, const double* hp_rows, int row_
     for (int i = 0; i < m; ++i) enqueue_lkd(c, &hps[i], i);
   }
   GPG_HIP_OK(c, hipMemcpyAsync(c->h_scal, c->scal, sizeof(double) * 8 * m, hipMemcpyDeviceToHost, c->stream));
-  GPG_HIP_OK(c, hipMemcpyAsync(c->h_info, c->info, sizeof(int) * m, hipMemcpyDeviceToHost, c->stream));
   GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
   GPG_HIP_OK(c, hipGetLastError());
   GPG_LAUNCH_OK(c);
+  for (int i = 0; i < m; ++i) c->h_info[i] = (int)c->h_scal[(size_t)8 * i + 7];
   if (internal_failure(c, c->h_info, m)) return -4;
   for (int i = 0; i < m; ++i) finish_lkd(c, &hps[i], c->h_scal + (size_t)8 * i, c->h_info[i], &out[i]);
   c->factor_valid = false;
@@ -637,7 +637,7 @@ static int gpg_lkd_grad_batch_once(gpg_ctx* c, int m, const double* hp_rows, int
       gpg_launch_prep_assembly_batch(c, c->items_host[r0].p, Bg, c->items_dev + r0, vs, c->A_elems);
       if (Bg > 1) gpg_launch_tile_chol_batch(c, Bg, c->batchA, c->A_elems, c->batchV + 2 * (size_t)c->Npad, 3 * c->Npad, info0 + r0);
       else { c->info = info0 + r0; gpg_cholesky(c); c->info = info0; }
-      gpg_launch_lkd_reduce_batch(c, r0, Bg, vs, c->A_elems);
+      gpg_launch_lkd_reduce_batch(c, r0, Bg, vs, c->A_elems, info0 + r0);
       for (int b = 0; b < Bg; ++b) {     // alpha of matrix b: RHS row 0 <- w2 - beta w1, then z = L^-T (.) by the vector solve
         c->A = c->batchA + (size_t)b * c->A_elems;
         c->dinv = c->batchV + (size_t)b * vs + 2 * (size_t)c->Npad;

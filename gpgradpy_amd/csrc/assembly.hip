@@ -29,13 +29,14 @@ __device__ __forceinline__ double kdiag_of(int kernel, int blk, const double* th
 // come from items[bz] and its buffers sit at bz * stride behind the base pointers.
 __global__ void prep_diag_kernel(AsmParams P, const double* __restrict__ noise, double var_fval, double var_fgrad,
                                  double* __restrict__ dvec, double* __restrict__ invp,
-                                 const gpg_batch_item* __restrict__ items, size_t v_stride) {
+                                 const gpg_batch_item* __restrict__ items, size_t v_stride, int* __restrict__ zero_info) {
   if (items) {
     const int bz = blockIdx.y;
     P = items[bz].p; var_fval = items[bz].var_fval; var_fgrad = items[bz].var_fgrad;
     dvec += bz * v_stride; invp += bz * v_stride;
   }
   int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (zero_info && r == 0) *zero_info = 0;               // the evaluation's info word (first launch of the evaluation)
   if (r >= P.Npad) return;
   if (r >= P.N) { dvec[r] = 1.0; invp[r] = 1.0; return; }
   int blk = (P.use_grad && r >= P.n) ? 1 + (r - P.n) / P.ng : 0;
@@ -77,7 +78,7 @@ __global__ void __launch_bounds__(256) assemble_kernel(AsmParams P, const double
                                                        const double* __restrict__ dvec,
                                                        const double* __restrict__ invp, double* __restrict__ A,
                                                        const gpg_batch_item* __restrict__ items, size_t v_stride,
-                                                       size_t a_stride) {
+                                                       size_t a_stride, int tb /* points b per workgroup, <= kTB */) {
   if (items) {
     const int bz = blockIdx.z;
     P = items[bz].p;
@@ -88,14 +89,14 @@ __global__ void __launch_bounds__(256) assemble_kernel(AsmParams P, const double
   __shared__ int gpb[kTB];
   const int n = P.n, ng = P.ng;
   const int a = blockIdx.x * 256 + threadIdx.x;
-  const int b0 = blockIdx.y * kTB;
+  const int b0 = blockIdx.y * tb;
   const int nblk = P.use_grad ? D + 1 : 1;
   // gradient rows / columns exist only for points whose gradient is used: index n + (I-1) ng + gpos[pt]
-  for (int t = threadIdx.x; t < kTB * D; t += 256) {
+  for (int t = threadIdx.x; t < tb * D; t += 256) {
     int bb = t / D, k = t % D, b = b0 + bb;
     xb[bb][k] = b < n ? Xt[(size_t)k * n + b] : 0.0;
   }
-  for (int t = threadIdx.x; t < kTB * (D + 1); t += 256) {
+  for (int t = threadIdx.x; t < tb * (D + 1); t += 256) {
     int bb = t / (D + 1), J = t % (D + 1), b = b0 + bb;
     double v = 0.0;
     if (b < n && J < nblk) {
@@ -105,7 +106,7 @@ __global__ void __launch_bounds__(256) assemble_kernel(AsmParams P, const double
     }
     ipb[bb][J] = v;
   }
-  if (threadIdx.x < kTB) gpb[threadIdx.x] = (b0 + threadIdx.x < n) ? P.gpos[b0 + threadIdx.x] : -1;
+  if (threadIdx.x < tb) gpb[threadIdx.x] = (b0 + threadIdx.x < n) ? P.gpos[b0 + threadIdx.x] : -1;
   __syncthreads();
   if (a >= n) return;
 
@@ -119,7 +120,7 @@ __global__ void __launch_bounds__(256) assemble_kernel(AsmParams P, const double
 
   const int mode = P.mode, precon = P.precon, ld = P.ld;
   const double varK = P.varK, eta = P.eta;
-  const int bend = min(kTB, n - b0);
+  const int bend = min(tb, n - b0);
   const double sqrt5 = sqrt(5.0);
   const double rq_alpha = P.hp_kernel, rq_const = 4.0 * (1.0 + 1.0 / P.hp_kernel);   // KernelRatQuad.py:529
 
@@ -346,11 +347,16 @@ __global__ void __launch_bounds__(256) rtensor_kern_kernel(RtParams P, const dou
 
 template <int KERN>
 void launch_assemble_d(gpg_ctx* c, const AsmParams& p, int B, const gpg_batch_item* items, size_t v_stride, size_t a_stride) {
-  dim3 grid((p.n + 255) / 256, (p.n + kTB - 1) / kTB, B);
+  // every thread owns one point a and walks the tb points b of its workgroup one after the other (~2.5 us per pair at d = 4): small
+  // data sets get fewer points b per workgroup, so that the launch is ~1000 workgroups wide instead of n / 16 deep chains
+  const long wide = (long)((p.n + 255) / 256) * p.n * B;
+  int tb = wide >= 8192 ? kTB : (int)(wide / 1024);
+  tb = tb < 1 ? 1 : (tb > kTB ? kTB : tb);
+  dim3 grid((p.n + 255) / 256, (p.n + tb - 1) / tb, B);
 #define CASE_D(DD)                                                                                  \
   case DD:                                                                                          \
     hipLaunchKernelGGL((assemble_kernel<KERN, DD>), grid, dim3(256), 0, c->stream, p, c->Xt, c->dvec, \
-                       c->invp, c->A, items, v_stride, a_stride);                                   \
+                       c->invp, c->A, items, v_stride, a_stride, tb);                               \
     break;
   switch (p.d) {
     CASE_D(1) CASE_D(2) CASE_D(3) CASE_D(4) CASE_D(5) CASE_D(6) CASE_D(7) CASE_D(8)
@@ -380,8 +386,10 @@ void launch_cross_d(gpg_ctx* c, const AsmParams& p, int nx, int nxp) {
 void gpg_launch_prep(gpg_ctx* c, const AsmParams& p, double var_fval, double var_fgrad, double s0, double t0,
                      double s1, double t1) {
   if (c->ws_cur == 0) c->alpha_valid = false;   // invp of set 0 is rewritten
+  int* zero_info = c->zero_info_in_prep ? c->info : nullptr;
+  c->zero_info_in_prep = false;
   hipLaunchKernelGGL(prep_diag_kernel, dim3((p.Npad + 255) / 256), dim3(256), 0, c->stream, p, c->noise, var_fval,
-                     var_fgrad, c->dvec, c->invp, (const gpg_batch_item*)nullptr, (size_t)0);
+                     var_fgrad, c->dvec, c->invp, (const gpg_batch_item*)nullptr, (size_t)0, zero_info);
   hipLaunchKernelGGL(prep_rows_kernel, dim3(p.Npad), dim3(256), 0, c->stream, p, c->y, c->invp, s0, t0, s1, t1, c->A,
                      (const gpg_batch_item*)nullptr, (size_t)0, (size_t)0);
 }
@@ -402,7 +410,7 @@ void gpg_launch_prep_assembly_batch(gpg_ctx* c, const AsmParams& p, int B, const
                                     size_t a_stride) {
   c->alpha_valid = false;
   hipLaunchKernelGGL(prep_diag_kernel, dim3((p.Npad + 255) / 256, B), dim3(256), 0, c->stream, p, c->noise, 0.0, 0.0, c->dvec,
-                     c->invp, items, v_stride);
+                     c->invp, items, v_stride, (int*)nullptr);
   hipLaunchKernelGGL(prep_rows_kernel, dim3(p.Npad, B), dim3(256), 0, c->stream, p, c->y, c->invp, 1.0, 0.0, 0.0, 1.0, c->A,
                      items, v_stride, a_stride);
   double bytes = 8.0 * (double)p.N * ((double)p.N + 1.0) / 2.0 * B;

@@ -1452,7 +1452,11 @@ static int persistent_grid(gpg_ctx* c, K kernel, long ntask) {
 }
 
 // Completion flags of the dataflow launches (grown on demand); false: allocation failed, nothing may be launched.
+// The buffer is a multiple of 64 bytes long and cleared in such multiples: the runtime's fill then is ONE kernel instead of an aligned
+// body plus a tail.
+static inline size_t flags_fill(size_t nflag) { return (nflag + 15) & ~(size_t)15; }
 static bool ensure_tile_flags(gpg_ctx* c, size_t nflag) {
+  nflag = flags_fill(nflag);
   if (c->tile_flags_cap >= nflag && c->tile_flags) return true;
   if (c->tile_flags) (void)hipFree(c->tile_flags);
   c->tile_flags = nullptr;
@@ -1473,7 +1477,7 @@ static void launch_tile_chol(gpg_ctx* c, int c0) {
   if (!tm.dev) return;
   const size_t nflag = (size_t)Mt * Rt + 1 + 4 * (size_t)Mt + 8;   // tile flags, abort word, four piece flags per diagonal tile, ticket words
   if (!ensure_tile_flags(c, nflag)) return;
-  (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
+  (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * flags_fill(nflag), c->stream);
   const double m = (double)(c->N - c0);                    // algorithmic flops: N^3 / 3 of the real matrix, not of the padded one
   gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, m > 0 ? m * m * m / 3.0 : 0.0);
   int* abort_word = c->tile_flags + (size_t)Mt * Rt;
@@ -1508,7 +1512,7 @@ static void launch_tile_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a_st
   const TileMap& tm = it->second;
   const size_t per = (size_t)Mt * Rt + 1 + 4 * (size_t)Mt, nflag = per * B + 8;   // + the ticket words of the launch
   if (!ensure_tile_flags(c, nflag)) return;
-  (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
+  (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * flags_fill(nflag), c->stream);
   const double m = (double)c->N;
   gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, B * m * m * m / 3.0);
   int* abort_word = c->tile_flags + (size_t)Mt * Rt;      // the abort word of matrix 0 serves the whole launch
@@ -1525,7 +1529,7 @@ static void launch_tile128_chol(gpg_ctx* c) {
   if (!tm.dev) return;
   const size_t nflag = (size_t)Mt * Rt + 1 + 9 * (size_t)Mt + 8;   // tile flags, abort word, 4 + 4 piece flags and the L21 flag per diagonal tile, ticket words
   if (!ensure_tile_flags(c, nflag)) return;
-  (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
+  (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * flags_fill(nflag), c->stream);
   const double m = (double)c->N;
   gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, m * m * m / 3.0);
   int* abort_word = c->tile_flags + (size_t)Mt * Rt;
@@ -1555,7 +1559,7 @@ static void launch_tile128_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a
   const TileMap& tm = it->second;
   const size_t per = (size_t)Mt * Rt + 1 + 9 * (size_t)Mt, nflag = per * B + 8;   // + the ticket words of the launch
   if (!ensure_tile_flags(c, nflag)) return;
-  (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
+  (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * flags_fill(nflag), c->stream);
   const double m = (double)c->N;
   gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, B * m * m * m / 3.0);
   int* abort_word = c->tile_flags + (size_t)Mt * Rt;
@@ -1606,7 +1610,7 @@ static bool launch_tile128_inverse_batch(gpg_ctx* c, int B, const double* Abase,
   const size_t nflag = per * B + 16;                // W tile flags per matrix | 9 ones | abort | ticket (trinv) | ticket (wwt)
   if (!ensure_tile_flags(c, nflag)) return false;
   int* ones = c->tile_flags + per * B;
-  (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
+  (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * flags_fill(nflag), c->stream);
   (void)hipMemsetD32Async((hipDeviceptr_t)ones, 1, 9, c->stream);
   for (int b = 0; b < B; ++b) gpg_launch_identity(c, Wbase + (size_t)b * w_stride, ldw);
   if (small)
@@ -1715,7 +1719,7 @@ static bool launch_rows_bwd(gpg_ctx* c, double* Z, int ldz, int rows, int valid)
   if ((long)Mt * nrt > 4096) return false;
   const size_t nflag = (size_t)Mt * nrt + 2;                    // flags, abort word, ticket
   if (!ensure_tile_flags(c, nflag)) return false;
-  (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
+  (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * flags_fill(nflag), c->stream);
   hipLaunchKernelGGL(rows_bwd_kernel, dim3(persistent_grid(c, rows_bwd_kernel, (long)Mt * nrt)), dim3(256), 0, c->stream,
                      (const double*)c->A, c->ld, (const double*)c->dinv, Z, ldz, Mt, nrt, valid < 0 ? rows : valid, c->tile_flags,
                      c->tile_flags + (nflag - 2), c->tile_flags + (nflag - 1), c->info);
@@ -1729,7 +1733,7 @@ static bool launch_rows_fwd(gpg_ctx* c, double* W, int ldw, int rows, int valid)
   if ((long)Mt * nrt > 4096) return false;             // many rows: the blocked sweep is throughput-bound, not latency-bound
   const size_t nflag = (size_t)Mt * nrt + 2;                    // flags, abort word, ticket
   if (!ensure_tile_flags(c, nflag)) return false;
-  (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * nflag, c->stream);
+  (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * flags_fill(nflag), c->stream);
   hipLaunchKernelGGL(rows_fwd_kernel, dim3(persistent_grid(c, rows_fwd_kernel, (long)Mt * nrt)), dim3(256), 0, c->stream,
                      (const double*)c->A, c->ld, (const double*)c->dinv, W, ldw, Mt, nrt, valid < 0 ? rows : valid, c->tile_flags,
                      c->tile_flags + (nflag - 2), c->tile_flags + (nflag - 1), c->info);

@@ -69,6 +69,7 @@ struct gpg_ctx {
   int* tile_flags = nullptr;   // device: completion flags of the dataflow kernel + abort word + ticket counter
   int num_cus = 0;             // compute units of the device (grid of the persistent launches)
   bool alpha_valid = false;    // zvec of workspace set 0 holds p * alpha of the last gpg_lkd_grad (gpg_lkd_alpha)
+  bool zero_info_in_prep = false;    // the next gpg_launch_prep also clears *c->info (consumed by it)
   int fuse_subdiag_max_tiles = 48;   // ... up to this many 64-column tile columns (3072 matrix columns)
   int fuse_subdiag = 1;        // 64-tile factorisation: diagonal tasks own the sub-diagonal tile below the previous diagonal tile (tile_chol_task)
   int task_order = 0;          // ticket order of the dataflow factorisation (for_each_chol_task in cholesky_dataflow.hip)
@@ -152,7 +153,7 @@ void gpg_launch_prep(gpg_ctx* c, const AsmParams& p, double var_fval, double var
 void gpg_launch_assembly(gpg_ctx* c, const AsmParams& p);
 void gpg_launch_prep_assembly_batch(gpg_ctx* c, const AsmParams& p, int B, const gpg_batch_item* items, size_t v_stride,
                                     size_t a_stride);
-void gpg_launch_lkd_reduce_batch(gpg_ctx* c, int slot0, int B, size_t v_stride, size_t a_stride);
+void gpg_launch_lkd_reduce_batch(gpg_ctx* c, int slot0, int B, size_t v_stride, size_t a_stride, const int* info0 /* B words */);
 void gpg_launch_cross(gpg_ctx* c, const AsmParams& p, int nx, int nxp);   // Wt <- P^-1 Kyx (transposed)
 void gpg_launch_abs_rowsum(gpg_ctx* c, double scale, double* out_dev);    // out[i] = scale * sum_j |M_ij|, M symmetric, lower triangle in A
 void gpg_launch_tile_chol(gpg_ctx* c, int c0);                          // dataflow factorisation of A[c0:, c0:], 64-tiles

@@ -20,7 +20,7 @@ namespace {
 
 constexpr int kTBg = 16;          // b-points staged per workgroup (at most)
 // Small designs: fewer b-points per workgroup, so that the launch has enough workgroups for the chip (n = 500: 64 -> 250).
-static inline int grad_tb(int n) { return n <= 1024 ? 4 : kTBg; }
+static inline int grad_tb(int n) { return n <= 256 ? 1 : n <= 1024 ? 4 : kTBg; }
 
 __device__ __forceinline__ double wave_sum_g(double v) {
 #pragma unroll

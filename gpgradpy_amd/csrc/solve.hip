@@ -34,10 +34,12 @@ __device__ void block_sum(double (&v)[NV], double* sh /* [NV * 16] */) {
   __syncthreads();
 }
 
-// scal[0] = ln_det, [1] = beta, [2] = r'K^-1 r, [3] = V'K^-1 V, [4] = V'K^-1 y
+// scal[0] = ln_det, [1] = beta, [2] = r'K^-1 r, [3] = V'K^-1 V, [4] = V'K^-1 y, [7] = the factorisation's info word (so that the
+// host fetches ONE buffer per evaluation)
 __global__ void __launch_bounds__(1024) lkd_reduce_kernel(const double* __restrict__ A, int ld, int N, int Npad,
                                                           const double* __restrict__ dvec, int precon,
-                                                          double* __restrict__ scal, size_t v_stride, size_t a_stride) {
+                                                          double* __restrict__ scal, size_t v_stride, size_t a_stride,
+                                                          const int* __restrict__ info) {
   A += blockIdx.x * a_stride; dvec += blockIdx.x * v_stride; scal += blockIdx.x * 8;   // batched: one workgroup per matrix
   __shared__ double sh[4 * 16];
   double v[4] = {0.0, 0.0, 0.0, 0.0};
@@ -64,6 +66,7 @@ __global__ void __launch_bounds__(1024) lkd_reduce_kernel(const double* __restri
     scal[2] = rr[0];
     scal[3] = v[2];
     scal[4] = v[3];
+    scal[7] = (double)info[blockIdx.x];
   }
 }
 
@@ -531,14 +534,14 @@ __global__ void extract_kernel(const double* __restrict__ A, int ld, int N, cons
 void gpg_launch_lkd_reduce(gpg_ctx* c, int slot) {
   gpg_prof_begin(c, GPG_PROF_REDUCE, 0.0);
   hipLaunchKernelGGL(lkd_reduce_kernel, dim3(1), dim3(1024), 0, c->stream, c->A, c->ld, c->N, c->Npad, c->dvec,
-                     c->last_precon, c->scal + (size_t)slot * 8, (size_t)0, (size_t)0);
+                     c->last_precon, c->scal + (size_t)slot * 8, (size_t)0, (size_t)0, c->info);   // c->info: this evaluation's word
   gpg_prof_end(c);
 }
 
-void gpg_launch_lkd_reduce_batch(gpg_ctx* c, int slot0, int B, size_t v_stride, size_t a_stride) {
+void gpg_launch_lkd_reduce_batch(gpg_ctx* c, int slot0, int B, size_t v_stride, size_t a_stride, const int* info0) {
   gpg_prof_begin(c, GPG_PROF_REDUCE, 0.0);
   hipLaunchKernelGGL(lkd_reduce_kernel, dim3(B), dim3(1024), 0, c->stream, c->A, c->ld, c->N, c->Npad, c->dvec,
-                     c->last_precon, c->scal + (size_t)slot0 * 8, v_stride, a_stride);
+                     c->last_precon, c->scal + (size_t)slot0 * 8, v_stride, a_stride, info0);
   gpg_prof_end(c);
 }
 

@@ -1,9 +1,9 @@
 """Randomised stress run of the C ABI through the Python mirror (diagnostic; GPU box): random shapes, kernels, noise models,
 factor schedules and interleavings of every entry point, checked against the CPU oracle (small sizes) and for
-self-consistency (batched = single, repeated calls bit-identical).    python tools/stress.py [seconds] [seed]"""
+self-consistency (batched = single, repeated calls bit-identical).    python tests/stress/stress.py [seconds] [seed]"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import gpgradpy_amd
 from oracle import gp_oracle as orc
 

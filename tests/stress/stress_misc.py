@@ -1,9 +1,9 @@
 """Randomised stress run of the less-travelled paths (diagnostic; GPU box): gradient-free models, bvec_use_grad masks, posterior
 gradients / Hessians against central differences of the posterior itself, the same object taking data sets of different sizes one after
-the other, kernel tables on random point sets.    python tools/stress_misc.py [seconds] [seed]"""
+the other, kernel tables on random point sets.    python tests/stress/stress_misc.py [seconds] [seed]"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import gpgradpy_amd
 from oracle import gp_oracle as orc
 

@@ -1,9 +1,9 @@
 """Randomised stress run of the non-'precon' well-conditioning methods and the round-2 additions (diagnostic; GPU box): 'base', the
 four data-rescaling methods, the row-sum nugget, caller-supplied noise vectors, direct against adjoint gradient, batched against
-single calls, posterior before / after likelihood calls, and the oracle on the scaled data.    python tools/stress_wellcond.py [seconds] [seed]"""
+single calls, posterior before / after likelihood calls, and the oracle on the scaled data.    python tests/stress/stress_wellcond.py [seconds] [seed]"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..'))
 import gpgradpy_amd
 from oracle import gp_oracle as orc
 
