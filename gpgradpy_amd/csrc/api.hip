@@ -96,6 +96,14 @@ static int check_hp(gpg_ctx* c, const gpg_hp* hp) {
   return 0;
 }
 
+// Pinned host scratch of n doubles, or nullptr (too large / no memory): the caller then copies into its own pageable buffer.
+constexpr size_t kPinDoubles = 16384;
+static double* pinned_scratch(gpg_ctx* c, size_t n) {
+  if (n > kPinDoubles) return nullptr;
+  if (!c->h_pin && hipHostMalloc(&c->h_pin, sizeof(double) * kPinDoubles) != hipSuccess) { (void)hipGetLastError(); c->h_pin = nullptr; }
+  return c->h_pin;
+}
+
 static int ensure_scal(gpg_ctx* c, int slots) {
   if (slots <= c->scal_slots) return 0;
   if (c->scal) (void)hipFree(c->scal);
@@ -231,6 +239,7 @@ void gpg_destroy(gpg_ctx* c) {
   if (c->info) (void)hipFree(c->info);
   if (c->gpos) (void)hipFree(c->gpos);
   if (c->h_scal) (void)hipHostFree(c->h_scal);
+  if (c->h_pin) (void)hipHostFree(c->h_pin);
   if (c->h_info) (void)hipHostFree(c->h_info);
   if (c->items_dev) (void)hipFree(c->items_dev);
   if (c->items_host) (void)hipHostFree(c->items_host);
@@ -363,14 +372,20 @@ static int gpg_lkd_grad_once(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out, dou
   c->zero_info_in_prep = true;
   enqueue_lkd(c, hp, 0);                                   // factor + beta + r'K^-1 r + ln det (scal slot 0)
   GPG_HIP_OK(c, hipMemcpyAsync(c->h_scal, c->scal, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
-  GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
-  GPG_HIP_OK(c, hipGetLastError());
-  GPG_LAUNCH_OK(c);
-  c->h_info[0] = (int)c->h_scal[7];
-  if (internal_failure(c, c->h_info, 1)) return -4;
-  c->factor_valid = (c->h_info[0] == 0);
-  finish_lkd(c, hp, c->h_scal, c->h_info[0], out);
-  if (out->info != 0) return out->info;
+  // Large matrices: look at the factorisation's info before spending two more N^3/3 sweeps on a failed factor.  Small ones
+  // (the sweeps cost less than a host round trip is worth): everything is enqueued at once and judged at the end; the kernels
+  // run to completion on whatever a failed factorisation left behind (their waits depend on flags, not on values).
+  const bool one_sync = c->Npad <= 2048;
+  if (!one_sync) {
+    GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
+    GPG_HIP_OK(c, hipGetLastError());
+    GPG_LAUNCH_OK(c);
+    c->h_info[0] = (int)c->h_scal[7];
+    if (internal_failure(c, c->h_info, 1)) return -4;
+    c->factor_valid = (c->h_info[0] == 0);
+    finish_lkd(c, hp, c->h_scal, c->h_info[0], out);
+    if (out->info != 0) return out->info;
+  }
   // alpha = Kcov^-1 (y - V beta):  z = L^-T (w2 - beta w1) = p * alpha
   AsmParams p = make_params(c, hp, 0);
   gpg_launch_combine_rows(c, 0);
@@ -378,13 +393,24 @@ static int gpg_lkd_grad_once(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out, dou
   gpg_inverse_from_factor(c, c->Wfull, c->Minv);
   double* res = c->gpartial + (size_t)nval * nblk;
   gpg_launch_grad_contract(c, p, c->gpartial, res, c->zvec, c->Minv);
-  std::vector<double> h(nval);
+  std::vector<double> hvec;
+  double* h = pinned_scratch(c, nval);
+  if (!h) { hvec.resize(nval); h = hvec.data(); }
   const int ns = c->d + 3 + (c->kernel == GPG_KERNEL_RATQU ? 1 : 0);
-  GPG_HIP_OK(c, hipMemcpyAsync(h.data(), res, sizeof(double) * 2 * ns, hipMemcpyDeviceToHost, c->stream));
+  GPG_HIP_OK(c, hipMemcpyAsync(h, res, sizeof(double) * 2 * ns, hipMemcpyDeviceToHost, c->stream));
   GPG_HIP_OK(c, hipMemcpyAsync(c->h_info, c->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));   // the dataflow solve
   GPG_HIP_OK(c, hipStreamSynchronize(c->stream));                                                      // reports through info
   GPG_HIP_OK(c, hipGetLastError());
   GPG_LAUNCH_OK(c);
+  if (one_sync) {
+    const int info_solves = c->h_info[0];
+    c->h_info[0] = (int)c->h_scal[7];                      // the word as the factorisation left it
+    if (internal_failure(c, c->h_info, 1)) return -4;
+    c->factor_valid = (c->h_info[0] == 0);
+    finish_lkd(c, hp, c->h_scal, c->h_info[0], out);
+    if (out->info != 0) return out->info;
+    c->h_info[0] = info_solves;
+  }
   if (solve_failure(c)) return -4;
   g_aa[c->d + 3] = g_inv[c->d + 3] = 0.0;                  // hp_kernel slot: RatQu only
   for (int k = 0; k < ns; ++k) { g_aa[k] = h[k]; g_inv[k] = h[ns + k]; }
@@ -817,7 +843,10 @@ static int predict_impl(gpg_ctx* c, int nx, const double* xq, double varK, doubl
   gpg_launch_predict_reduce(c, nx, nxp, c->eval_beta, varK, 0);
   gpg_forward_rows(c, c->Wt, nxp, nxp, nx);
   gpg_launch_predict_reduce(c, nx, nxp, c->eval_beta, varK, 1);
-  std::vector<double> hgrad;
+  std::vector<double> hgrad_vec;
+  double* hgrad = nullptr;
+  size_t n_hgrad = 0;
+  double* pin = pinned_scratch(c, 2 * (size_t)nxp * (1 + GPG_MAX_DIM));   // mu | sig2 | the two gradient blocks
   if (dmudx) {
     // K^-1 Kyx needs the second triangular sweep too (GpEvalModel.py:154), then the fused gradient reductions
     double* g1 = c->gradbuf;
@@ -825,11 +854,15 @@ static int predict_impl(gpg_ctx* c, int nx, const double* xq, double varK, doubl
     double* tbuf = c->gradbuf + (size_t)2 * nxp * GPG_MAX_DIM;
     gpg_backward_rows(c, c->Wt, nxp, nx, tbuf);
     gpg_launch_cross_grad(c, p, nx, nxp, g1, g2);
-    hgrad.resize((size_t)2 * nxp * GPG_MAX_DIM);
-    GPG_HIP_OK(c, hipMemcpyAsync(hgrad.data(), c->gradbuf, sizeof(double) * hgrad.size(), hipMemcpyDeviceToHost, c->stream));
+    n_hgrad = (size_t)2 * nxp * GPG_MAX_DIM;
+    hgrad = pin ? pin + 2 * (size_t)nxp : nullptr;
+    if (!hgrad) { hgrad_vec.resize(n_hgrad); hgrad = hgrad_vec.data(); }
+    GPG_HIP_OK(c, hipMemcpyAsync(hgrad, c->gradbuf, sizeof(double) * n_hgrad, hipMemcpyDeviceToHost, c->stream));
   }
-  std::vector<double> host(2 * (size_t)nxp);
-  GPG_HIP_OK(c, hipMemcpyAsync(host.data(), c->musig, sizeof(double) * 2 * nxp, hipMemcpyDeviceToHost, c->stream));
+  std::vector<double> host_vec;
+  double* host = pin;
+  if (!host) { host_vec.resize(2 * (size_t)nxp); host = host_vec.data(); }
+  GPG_HIP_OK(c, hipMemcpyAsync(host, c->musig, sizeof(double) * 2 * nxp, hipMemcpyDeviceToHost, c->stream));
   GPG_HIP_OK(c, hipMemcpyAsync(c->h_info, c->info, sizeof(int), hipMemcpyDeviceToHost, c->stream));
   GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
   GPG_HIP_OK(c, hipGetLastError());

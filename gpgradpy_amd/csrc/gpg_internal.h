@@ -123,6 +123,7 @@ struct gpg_ctx {
   double* gpartial = nullptr;   // per-workgroup partial sums of the gradient contraction + 2 (d+3) results
   // pinned host staging
   double* h_scal = nullptr;
+  double* h_pin = nullptr;           // pinned host scratch for small results (a copy into pageable memory costs ~20 us more)
   int* h_info = nullptr;
   // state
   bool have_data = false;

@@ -37,9 +37,16 @@ __global__ void combine_rows_kernel(double* __restrict__ A, int ld, int Npad, co
   col[0] = col[1] - beta * col[0];
 }
 
-__global__ void set_identity_kernel(double* __restrict__ W, int ldw, int Npad) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r < Npad) W[(size_t)r + (size_t)r * ldw] = 1.0;
+// W (ldw x Npad, ldw even) <- identity, two entries per thread: one launch instead of a fill and a diagonal pass
+__global__ void __launch_bounds__(256) set_identity_kernel(double* __restrict__ W, int ldw, int Npad) {
+  const size_t half = (size_t)ldw / 2, total = half * Npad;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t col = i / half, r = 2 * (i - col * half);
+    double2 v;
+    v.x = r == col ? 1.0 : 0.0;
+    v.y = r + 1 == col ? 1.0 : 0.0;
+    *reinterpret_cast<double2*>(W + col * (size_t)ldw + r) = v;
+  }
 }
 
 // z[r] = v[r] / invp[r] (zero tail): the vector whose "alpha" in grad_contract_kernel is v itself
@@ -362,8 +369,9 @@ void gpg_launch_combine_rows(gpg_ctx* c, int slot) {
 }
 
 void gpg_launch_identity(gpg_ctx* c, double* W, int ldw) {
-  (void)hipMemsetAsync(W, 0, sizeof(double) * (size_t)ldw * c->Npad, c->stream);
-  hipLaunchKernelGGL(set_identity_kernel, dim3((c->Npad + 255) / 256), dim3(256), 0, c->stream, W, ldw, c->Npad);
+  const size_t total = (size_t)ldw / 2 * c->Npad;
+  const size_t nb = (total + 255) / 256;
+  hipLaunchKernelGGL(set_identity_kernel, dim3((unsigned)(nb < 65536 ? nb : 65536)), dim3(256), 0, c->stream, W, ldw, c->Npad);
 }
 
 // out_dev[0 .. ns) = g_aa, out_dev[ns .. 2 ns) = g_inv, ns = d + 3 (+ 1 for RatQu: alpha last)

@@ -70,6 +70,14 @@ __global__ void __launch_bounds__(1024) lkd_reduce_kernel(const double* __restri
   }
 }
 
+// rows[64 c + r] = (r == 0) ? src[c ld] : 0 -- a vector as row 0 of a zeroed 64-row tile row (one launch instead of a fill and a
+// strided copy)
+__global__ void __launch_bounds__(256) vec_rows_load_kernel(double* __restrict__ rows, const double* __restrict__ src, int ld, int Npad) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= 64 * (size_t)Npad) return;
+  rows[i] = (i & 63) == 0 ? src[(i >> 6) * (size_t)ld] : 0.0;
+}
+
 // t[j] = sum_{i >= k0+64} L[i, k0+j] z[i]   (one workgroup per column j)
 __global__ void __launch_bounds__(256) bs_dot_kernel(const double* __restrict__ A, int ld, int Npad, int k0,
                                                      const double* __restrict__ z, double* __restrict__ t) {
@@ -552,10 +560,9 @@ void gpg_backward_solve(gpg_ctx* c) {
     // 2 Npad / 64 dependent ones)
     if (!c->vec_rows) (void)gpg_dev_alloc(c, &c->vec_rows, sizeof(double) * 64 * (size_t)c->vec_rows_cols);
     if (c->vec_rows) {
-      (void)hipMemsetAsync(c->vec_rows, 0, sizeof(double) * 64 * (size_t)Npad, c->stream);
-      // right-hand side: the forward-solved RHS row 0 of the factorisation workspace (row Npad of A)
-      (void)hipMemcpy2DAsync(c->vec_rows, 64 * sizeof(double), c->A + Npad, (size_t)c->ld * sizeof(double), sizeof(double), Npad,
-                             hipMemcpyDeviceToDevice, c->stream);
+      // right-hand side: the forward-solved RHS row 0 of the factorisation workspace (row Npad of A); rows 1..63 of the tile zero
+      hipLaunchKernelGGL(vec_rows_load_kernel, dim3((unsigned)((64 * (size_t)Npad + 255) / 256)), dim3(256), 0, c->stream, c->vec_rows,
+                         c->A + Npad, c->ld, Npad);
       if (gpg_launch_rows_bwd(c, c->vec_rows, 64, 64, 1)) {
         (void)hipMemcpy2DAsync(c->zvec, sizeof(double), c->vec_rows, 64 * sizeof(double), sizeof(double), Npad,
                                hipMemcpyDeviceToDevice, c->stream);
@@ -656,9 +663,8 @@ int gpg_factor_apply_dev(gpg_ctx* c, int op, double* v, double* out) {
     return hipMemcpyAsync(out, v, sizeof(double) * Npad, hipMemcpyDeviceToDevice, c->stream) == hipSuccess ? 0 : -2;
   }
   if (!c->vec_rows && !gpg_dev_alloc(c, &c->vec_rows, sizeof(double) * 64 * (size_t)c->vec_rows_cols)) return -2;
-  (void)hipMemsetAsync(c->vec_rows, 0, sizeof(double) * 64 * (size_t)Npad, c->stream);
-  (void)hipMemcpy2DAsync(c->vec_rows, 64 * sizeof(double), v, sizeof(double), sizeof(double), Npad, hipMemcpyDeviceToDevice,
-                         c->stream);                                              // row 0 of the carrier <- v
+  hipLaunchKernelGGL(vec_rows_load_kernel, dim3((unsigned)((64 * (size_t)Npad + 255) / 256)), dim3(256), 0, c->stream, c->vec_rows, v, 1,
+                     Npad);                                                       // row 0 of the carrier <- v
   if (c->chol_impl != 0 || c->tail_cols != 0) {
     if (!gpg_launch_rows_fwd(c, c->vec_rows, 64, 64, 1) || !gpg_launch_rows_bwd(c, c->vec_rows, 64, 64, 1)) return -2;
   } else {
