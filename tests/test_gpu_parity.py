@@ -64,6 +64,14 @@ def test_golden_case(path):
     assert ok == c["b_chofac_good"]
     if not ok:
         assert info.ln_lkd is None
+        # value + gradient of a small matrix is enqueued whole and judged after ONE synchronisation: the failed factorisation must come
+        # back the same way, and the context must be usable afterwards
+        info_g, ok_g = GP.calc_lkd_all(hp, calc_grad=True)
+        assert not ok_g and info_g.ln_lkd is None
+        GP._etaK = GP._eta_Kgrad = 1e-6
+        info_ok, ok2 = GP.calc_lkd_all(hp, calc_grad=True)
+        assert ok2 and np.isfinite(info_ok.ln_lkd) and np.all(np.isfinite(info_ok.ln_lkd_grad))
+        assert np.isclose(GP.calc_lkd_all(hp)[0].ln_lkd, info_ok.ln_lkd, rtol=1e-12)
         return
     noisy = c["b_has_noisy_data"]
     tol.check_scalars(info.hp_beta[0], info.hp_varK, info.ln_det_Kmat, info.ln_lkd, c, GP.n_data, noisy)
