@@ -178,6 +178,7 @@ int gpg_create(gpg_ctx** out, int device, int n_eval, int dim, int use_grad, int
   // factorisation schedule (measured, profiles/r01_tile_probe.log): one dataflow launch, 64-tile kernel for small
   // matrices (shorter dependency chain), 128-tile kernel above; chol_impl 0 = blocked right-looking (A/B runs)
   c->chol_impl = 1;
+  if (const char* e = getenv("GPG_ROWS_MAX_TASKS")) { const int v = atoi(e); if (v >= 64) c->rows_max_tasks = v; }   // diagnostic override
   c->tail_cols = 12288;
 #define CREATE_OK(call)                                                              \
   do {                                                                               \

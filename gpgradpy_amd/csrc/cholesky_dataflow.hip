@@ -1716,7 +1716,7 @@ static bool launch_rows_bwd(gpg_ctx* c, double* Z, int ldz, int rows, int valid)
   if (rows <= 0 || rows % 64 != 0) return false;
   if (valid >= 1 && valid <= 4 && c->Npad / 64 <= 512) return launch_vec_solve(c, Z, ldz, valid, true);
   const int Mt = c->Npad / 64, nrt = rows / 64;
-  if ((long)Mt * nrt > 4096) return false;
+  if ((long)Mt * nrt > c->rows_max_tasks) return false;
   const size_t nflag = (size_t)Mt * nrt + 2;                    // flags, abort word, ticket
   if (!ensure_tile_flags(c, nflag)) return false;
   (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * flags_fill(nflag), c->stream);
@@ -1730,7 +1730,7 @@ static bool launch_rows_fwd(gpg_ctx* c, double* W, int ldw, int rows, int valid)
   if (rows <= 0 || rows % 64 != 0) return false;
   if (valid >= 1 && valid <= 4 && c->Npad / 64 <= 512) return launch_vec_solve(c, W, ldw, valid, false);
   const int Mt = c->Npad / 64, nrt = rows / 64;
-  if ((long)Mt * nrt > 4096) return false;             // many rows: the blocked sweep is throughput-bound, not latency-bound
+  if ((long)Mt * nrt > c->rows_max_tasks) return false;   // beyond: the blocked sweep (or one launch per group of row tiles)
   const size_t nflag = (size_t)Mt * nrt + 2;                    // flags, abort word, ticket
   if (!ensure_tile_flags(c, nflag)) return false;
   (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * flags_fill(nflag), c->stream);

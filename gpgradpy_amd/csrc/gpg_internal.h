@@ -65,6 +65,8 @@ struct gpg_ctx {
   int last_factor_batch = 0;  // matrices it factorised
   int chol_impl = 0;    // 1: whole factorisation by the 128-tile dataflow kernel
   int tail_cols = 0;    // trailing block of at most this many columns goes to the dataflow tile kernel (0: off)
+  int rows_max_tasks = 1 << 15;  // dataflow row solves (posterior at many points): at most this many 64 x 64 tile tasks per launch; beyond, the
+                                 // blocked forward sweep is as fast (cfg3: ~5000 points; tools/post_many.py; env GPG_ROWS_MAX_TASKS overrides)
   int inv_tile64_cols = 4096;   // explicit inverse: W = L^-T on 64 x 64 tiles up to this many padded columns (0: always 128-tiles)
   int* tile_flags = nullptr;   // device: completion flags of the dataflow kernel + abort word + ticket counter
   int num_cus = 0;             // compute units of the device (grid of the persistent launches)

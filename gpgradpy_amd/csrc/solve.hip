@@ -585,7 +585,7 @@ void gpg_backward_rows(gpg_ctx* c, double* Z, int ldz, int nrhs, double* tbuf) {
   if (c->chol_impl != 0 || c->tail_cols != 0) {
     if (gpg_launch_rows_bwd(c, Z, ldz, rows, nrhs)) return;
     // more row tiles than one dataflow launch takes: one launch per group of row tiles (rows are the fast index of Z)
-    const int chunk = (4096 / (c->Npad / 64)) * 64;
+    const int chunk = (c->rows_max_tasks / (c->Npad / 64)) * 64;
     if (chunk >= 64) {
       bool ok = true;
       for (int r0 = 0; r0 < rows && ok; r0 += chunk) {

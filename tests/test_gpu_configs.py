@@ -463,3 +463,39 @@ def test_caller_supplied_noise_vector():
     mu1, sig1 = GP.eval_model(xq)[:2]
     np.testing.assert_array_equal(mu1, mu0)
     np.testing.assert_array_equal(sig1, sig0)
+
+
+def test_posterior_at_many_points_one_dataflow_launch():
+    """eval_model at thousands of points: the forward / backward row solves take up to 32768 tile tasks in ONE dataflow launch (4096 in
+    round 1, with a 2x cliff at the limit); beyond that, groups of row tiles / the blocked sweep.  The three regimes must agree: row
+    tiles are independent, so the whole call equals the call in pieces; a sample is checked against the CPU oracle."""
+    import gpgradpy_amd
+    from oracle import gp_oracle as orc
+    n, d = 300, 4                                              # N = 1500, 24 tile columns
+    X, f, g = orc.synthetic_design(n, d, seed=21)
+    GP = gpgradpy_amd.GaussianProcess(d, True, 'SqExp', 'precon')
+    GP.set_data(X, f, np.zeros(n), g, np.zeros((n, d)))
+    hp = GP.optz_closed_form_hp(GP.make_hp_class(theta=np.full(d, 0.2)))
+    GP.set_hpara('set', 0, hp_vals=hp)
+    rng = np.random.default_rng(5)
+    xq = rng.uniform(-2, 2, (90000, d))
+    pieces = {}
+    for nx in (12000, 90000):                                  # 4512 tasks (new single-launch regime), 33768 (> 32768: groups / blocked sweep)
+        mu, sig, dmu, dsig = GP.eval_model(xq[:nx], calc_grad=True)[:4]
+        mu_p = np.concatenate([GP.eval_model(xq[i:i + 2000])[0] for i in range(0, 12000, 2000)])
+        out_p = [GP.eval_model(xq[i:i + 2000], calc_grad=True)[:4] for i in range(0, 12000, 2000)]
+        np.testing.assert_allclose(mu[:12000], mu_p, rtol=1e-12, atol=1e-12 * np.abs(mu_p).max())
+        for k, ref in enumerate((mu, sig, dmu, dsig)):
+            got = np.concatenate([o[k] for o in out_p])
+            # (the slice count of the predictive reductions depends on the call's size: sums in another order, and dsigdx divides by sigma)
+            np.testing.assert_allclose(ref[:12000], got, rtol=1e-7, atol=1e-8 * max(1.0, np.abs(got).max()))
+        pieces[nx] = (mu, sig)
+    np.testing.assert_allclose(pieces[90000][0][:12000], pieces[12000][0], rtol=1e-12, atol=1e-12 * np.abs(pieces[12000][0]).max())
+    y = orc.make_data_vec(f, g)
+    r = orc.calc_lkd(X, y, hp.theta, 'SqExp', True, 'precon', GP._etaK, np.zeros(y.size), False)
+    mo = orc.setup_eval_model(X, y, hp.theta, 'SqExp', True, 'precon', GP._etaK, np.zeros(y.size), np.atleast_1d(r.hp_beta), hp.varK)
+    idx = rng.integers(0, 90000, 60)
+    mu_o, sig_o = orc.eval_model(mo, xq[idx])
+    np.testing.assert_allclose(pieces[90000][0][idx], mu_o, rtol=1e-6, atol=1e-7 * max(1.0, np.abs(mu_o).max()))
+    np.testing.assert_allclose(pieces[90000][1][idx], sig_o, rtol=1e-4, atol=1e-6 * np.sqrt(hp.varK))
+    assert GP.factor_fallbacks() == 0
