@@ -2,6 +2,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <cstring>
 #include <functional>
 #include <limits>
@@ -96,6 +97,15 @@ static int check_hp(gpg_ctx* c, const gpg_hp* hp) {
   return 0;
 }
 
+// Streams and pinned host blocks are the expensive part of creating / destroying a context (~1 ms each on this runtime; the device
+// allocations are ~0.1 ms each), and a Bayesian-optimisation loop makes a new context for every added point: a destroyed context
+// parks them here (per device, a handful at most) and the next gpg_create takes them over.
+struct ParkedHost { int device; hipStream_t stream, stream_upd; double* h_scal; int* h_info; double* h_pin; };
+static std::mutex g_park_mutex;
+static std::vector<ParkedHost> g_parked;
+constexpr int kScalSlotsDefault = 64;
+constexpr size_t kParkMax = 4;
+
 // Pinned host scratch of n doubles, or nullptr (too large / no memory): the caller then copies into its own pageable buffer.
 constexpr size_t kPinDoubles = 16384;
 static double* pinned_scratch(gpg_ctx* c, size_t n) {
@@ -108,13 +118,19 @@ static int ensure_scal(gpg_ctx* c, int slots) {
   if (slots <= c->scal_slots) return 0;
   if (c->scal) (void)hipFree(c->scal);
   if (c->info) (void)hipFree(c->info);
-  if (c->h_scal) (void)hipHostFree(c->h_scal);
-  if (c->h_info) (void)hipHostFree(c->h_info);
-  c->scal = nullptr; c->info = nullptr; c->h_scal = nullptr; c->h_info = nullptr; c->scal_slots = 0;
+  const bool keep_host = c->scal_slots == 0 && slots == kScalSlotsDefault && c->h_scal && c->h_info;   // taken over from a parked context
+  if (!keep_host) {
+    if (c->h_scal) (void)hipHostFree(c->h_scal);
+    if (c->h_info) (void)hipHostFree(c->h_info);
+    c->h_scal = nullptr; c->h_info = nullptr;
+  }
+  c->scal = nullptr; c->info = nullptr; c->scal_slots = 0;
   GPG_HIP_OK(c, hipMalloc(&c->scal, sizeof(double) * 8 * slots));
   GPG_HIP_OK(c, hipMalloc(&c->info, sizeof(int) * slots));
-  GPG_HIP_OK(c, hipHostMalloc(&c->h_scal, sizeof(double) * 8 * slots));
-  GPG_HIP_OK(c, hipHostMalloc(&c->h_info, sizeof(int) * slots));
+  if (!keep_host) {
+    GPG_HIP_OK(c, hipHostMalloc(&c->h_scal, sizeof(double) * 8 * slots));
+    GPG_HIP_OK(c, hipHostMalloc(&c->h_info, sizeof(int) * slots));
+  }
   c->scal_slots = slots;
   return 0;
 }
@@ -192,6 +208,16 @@ int gpg_create(gpg_ctx** out, int device, int n_eval, int dim, int use_grad, int
   CREATE_OK(hipSetDevice(device));
   CREATE_OK(hipDeviceGetAttribute(&c->num_cus, hipDeviceAttributeMultiprocessorCount, device));
   {
+    std::lock_guard<std::mutex> lock(g_park_mutex);
+    for (size_t k = 0; k < g_parked.size(); ++k)
+      if (g_parked[k].device == device) {
+        c->stream = g_parked[k].stream; c->stream_upd = g_parked[k].stream_upd;
+        c->h_scal = g_parked[k].h_scal; c->h_info = g_parked[k].h_info; c->h_pin = g_parked[k].h_pin;
+        g_parked.erase(g_parked.begin() + k);
+        break;
+      }
+  }
+  if (!c->stream) {
     int prio_lo = 0, prio_hi = 0;
     CREATE_OK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));   // numerically lowest = highest priority
     CREATE_OK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_lo));
@@ -218,7 +244,7 @@ int gpg_create(gpg_ctx** out, int device, int n_eval, int dim, int use_grad, int
   CREATE_OK(hipMemsetAsync(c->A, 0, sizeof(double) * (size_t)c->ld * c->Npad, c->stream));   // ordered on the context's own
   CREATE_OK(hipStreamSynchronize(c->stream));                                                  // (non-blocking) stream
 #undef CREATE_OK
-  if (ensure_scal(c, 64) != 0) { g_create_err = c->err; gpg_destroy(c); return -2; }
+  if (ensure_scal(c, kScalSlotsDefault) != 0) { g_create_err = c->err; gpg_destroy(c); return -2; }
   *out = c;
   return 0;
 }
@@ -239,16 +265,28 @@ void gpg_destroy(gpg_ctx* c) {
   for (double* b : bufs) if (b) (void)hipFree(b);
   if (c->info) (void)hipFree(c->info);
   if (c->gpos) (void)hipFree(c->gpos);
-  if (c->h_scal) (void)hipHostFree(c->h_scal);
-  if (c->h_pin) (void)hipHostFree(c->h_pin);
-  if (c->h_info) (void)hipHostFree(c->h_info);
+  bool parked = false;
+  if (c->stream && c->stream_upd && c->h_scal && c->h_info && c->scal_slots == kScalSlotsDefault) {
+    std::lock_guard<std::mutex> lock(g_park_mutex);
+    if (g_parked.size() < kParkMax) {
+      g_parked.push_back(ParkedHost{c->device, c->stream, c->stream_upd, c->h_scal, c->h_info, c->h_pin});   // (both streams are idle: synchronised above)
+      parked = true;
+    }
+  }
+  if (!parked) {
+    if (c->h_scal) (void)hipHostFree(c->h_scal);
+    if (c->h_pin) (void)hipHostFree(c->h_pin);
+    if (c->h_info) (void)hipHostFree(c->h_info);
+  }
   if (c->items_dev) (void)hipFree(c->items_dev);
   if (c->items_host) (void)hipHostFree(c->items_host);
   for (auto& kv : c->tilemaps) if (kv.second.dev) (void)hipFree(kv.second.dev);
   for (auto e : c->ev_panel) (void)hipEventDestroy(e);
   for (auto e : c->ev_upd) (void)hipEventDestroy(e);
-  if (c->stream_upd) (void)hipStreamDestroy(c->stream_upd);
-  if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (!parked) {
+    if (c->stream_upd) (void)hipStreamDestroy(c->stream_upd);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+  }
   delete c;
 }
 
