@@ -18,12 +18,19 @@ class LanczosNotConverged(RuntimeWarning):
 
 
 def _tridiag_eigh(alpha, beta):
-    """Eigenpairs of the Lanczos tridiagonal matrix.  LAPACK's stemr (SciPy's default driver) occasionally gives up on matrices
-    with a very wide spectrum -- the operator here may be K^-1 with cond(K) ~ 1e10 and beyond -- ; the QR iteration (stev) does not."""
+    """Largest eigenpair (value, unit vector) of the Lanczos tridiagonal matrix -- only that one is computed (bisection + inverse
+    iteration: O(k) instead of the O(k^2) of all pairs, which at every step was most of a small problem's condition number).  LAPACK
+    occasionally gives up on matrices with a very wide spectrum -- the operator here may be K^-1 with cond(K) ~ 1e10 and beyond -- ; the
+    QR iteration (stev, all pairs) does not."""
+    m = len(alpha)
     try:
-        return eigh_tridiagonal(alpha, beta)
-    except np.linalg.LinAlgError:
-        return eigh_tridiagonal(alpha, beta, lapack_driver='stev')
+        ev, evec = eigh_tridiagonal(alpha, beta, select='i', select_range=(m - 1, m - 1))
+        if np.all(np.isfinite(evec)) and np.isfinite(ev[0]):
+            return ev[0], evec[:, 0]
+    except (np.linalg.LinAlgError, ValueError):
+        pass
+    ev, evec = eigh_tridiagonal(alpha, beta, lapack_driver='stev')
+    return ev[-1], evec[:, -1]
 
 
 def lanczos_largest(apply, n, k_max=120, rtol=1e-9, seed=0, want_vector=False):
@@ -51,25 +58,24 @@ def lanczos_largest(apply, n, k_max=120, rtol=1e-9, seed=0, want_vector=False):
         for _ in range(2):                                   # full reorthogonalisation, twice
             w -= Q[:j + 1].T @ (Q[:j + 1] @ w)
         b = float(np.linalg.norm(w))
-        if j >= 1:
-            ev, evec = _tridiag_eigh(np.array(alpha), np.array(beta))
-            theta = ev[-1]
-            ritz = evec[:, -1]
-            if b * abs(evec[-1, -1]) <= rtol * abs(theta):   # residual bound of the largest Ritz pair
+        if j >= 1 and (j < 24 or j % 4 == 3 or j + 1 >= k_max):      # the convergence tests: every step at first, then every fourth
+            theta, ritz = _tridiag_eigh(np.array(alpha), np.array(beta))
+            if b * abs(ritz[-1]) <= rtol * abs(theta):       # residual bound of the largest Ritz pair
                 return done(theta, ritz, j)
             # a cluster at the top of the spectrum (K^-1 of a matrix whose small eigenvalues sit on the nugget): the residual of ONE
             # Ritz vector stays large while the Ritz VALUE -- second order in that residual -- has long settled; any vector of the
             # cluster's invariant subspace serves the gradient formula as well as the one a dense eigensolver would pick
-            hist.append(theta)
-            if j >= 12 and abs(theta - hist[-7]) <= 1e-13 * abs(theta):
+            old = [t for (jj, t) in hist if jj <= j - 6]
+            hist.append((j, theta))
+            if j >= 12 and old and abs(theta - old[-1]) <= 1e-13 * abs(theta):
                 return done(theta, ritz, j)
-        else:
+        elif j == 0:
             theta = a
         if b <= 1e-300 or b <= 4e-16 * abs(theta) or not np.isfinite(b):   # invariant subspace (what is left of w is rounding): the Ritz
             return done(theta, ritz, j)                                      # values are exact; nothing to normalise a next vector from
         if j + 1 >= k_max:
             if k_max < n:                                    # (k_max = n is the full Krylov space: exact up to rounding)
-                res = b * abs(evec[-1, -1]) / abs(theta) if j >= 1 else np.inf
+                res = b * abs(ritz[-1]) / abs(theta) if ritz is not None else np.inf
                 warnings.warn(f'Lanczos: largest Ritz value not converged after {k_max} steps '
                               f'(relative residual bound {res:.2e} > {rtol:.1e}); the condition number is a lower bound',
                               LanczosNotConverged, stacklevel=2)

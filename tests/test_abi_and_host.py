@@ -237,5 +237,6 @@ def test_lanczos_survives_exhausted_krylov_space_and_wide_spectra():
         c2, lam_min, v_max, v_min = cond_from_factor(lambda v: K @ v, lambda v: Ki @ v, n, want_vectors=True)
         assert np.isclose(c2, cond, rtol=1e-5) and np.isclose(lam_min, lam[-1], rtol=1e-5)
         assert abs(abs(v_max @ Q[:, 0]) - 1) < 1e-6 and abs(abs(v_min @ Q[:, -1]) - 1) < 1e-4
-    ev, _ = _tridiag_eigh(np.array([1.0, 2.0, 3.0]), np.array([0.1, 0.2]))
-    assert np.all(np.diff(ev) > 0)
+    ev, vec = _tridiag_eigh(np.array([1.0, 2.0, 3.0]), np.array([0.1, 0.2]))          # the largest pair only
+    T = np.diag([1.0, 2.0, 3.0]) + np.diag([0.1, 0.2], 1) + np.diag([0.1, 0.2], -1)
+    assert np.isclose(ev, np.linalg.eigvalsh(T)[-1], rtol=1e-14) and np.allclose(T @ vec, ev * vec, atol=1e-13)
