@@ -18,7 +18,7 @@ for n in (20, 21, 100, 101, 300):
     GP.eval_model(X[n:n + 1] * 0.9, calc_grad=True)
     t3 = time.perf_counter()
     print(f'n = {n:4d} (N = {n * (d + 1):5d}): set_data {1e3 * (t1 - t0):7.2f} ms, set_hpara(optz) {1e3 * (t2 - t1):8.2f} ms, eval_model {1e3 * (t3 - t2):6.2f} ms', flush=True)
-n = 100
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 GP.set_data(X[:n], f[:n], np.zeros(n), g[:n], np.zeros((n, d)))
 pr = cProfile.Profile(); pr.enable()
 GP.set_hpara('optz', i_optz)
