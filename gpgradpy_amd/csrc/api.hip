@@ -194,6 +194,7 @@ int gpg_create(gpg_ctx** out, int device, int n_eval, int dim, int use_grad, int
   // factorisation schedule (measured, profiles/r01_tile_probe.log): one dataflow launch, 64-tile kernel for small
   // matrices (shorter dependency chain), 128-tile kernel above; chol_impl 0 = blocked right-looking (A/B runs)
   c->chol_impl = 1;
+  if (const char* e = getenv("GPG_OVERLAP_INVERSE")) c->overlap_inverse = atoi(e);   // diagnostic override (A/B runs)
   if (const char* e = getenv("GPG_ROWS_MAX_TASKS")) { const int v = atoi(e); if (v >= 64) c->rows_max_tasks = v; }   // diagnostic override
   c->tail_cols = 12288;
 #define CREATE_OK(call)                                                              \
@@ -281,6 +282,9 @@ void gpg_destroy(gpg_ctx* c) {
   if (c->items_dev) (void)hipFree(c->items_dev);
   if (c->items_host) (void)hipHostFree(c->items_host);
   for (auto& kv : c->tilemaps) if (kv.second.dev) (void)hipFree(kv.second.dev);
+  if (c->ev_flags) (void)hipEventDestroy(c->ev_flags);
+  if (c->ev_trinv) (void)hipEventDestroy(c->ev_trinv);
+  if (c->keep_flags) (void)hipFree(c->keep_flags);
   for (auto e : c->ev_panel) (void)hipEventDestroy(e);
   for (auto e : c->ev_upd) (void)hipEventDestroy(e);
   if (!parked) {
@@ -409,12 +413,16 @@ static int gpg_lkd_grad_once(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out, dou
   const int nval = 2 * GPG_GRAD_SLOTS_MAX;
   if (!c->gpartial) GPG_HIP_OK(c, hipMalloc(&c->gpartial, sizeof(double) * (size_t)nval * (nblk + 1)));
   c->zero_info_in_prep = true;
+  // small matrix on the dataflow schedule: W = L^-T goes to the second stream right behind the factorisation (cholesky_dataflow.hip)
+  const bool overlap = c->Npad <= 4096 && gpg_overlap_inverse_begin(c);
   enqueue_lkd(c, hp, 0);                                   // factor + beta + r'K^-1 r + ln det (scal slot 0)
+  c->chol_flags_override = nullptr;                        // (consumed by the 64-tile launch; cleared in case another schedule ran)
+  if (overlap && !gpg_overlap_inverse_trinv(c, c->Wfull)) { c->err = "overlapped inverse: launch refused"; return -2; }
   GPG_HIP_OK(c, hipMemcpyAsync(c->h_scal, c->scal, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
   // Large matrices: look at the factorisation's info before spending two more N^3/3 sweeps on a failed factor.  Small ones
   // (the sweeps cost less than a host round trip is worth): everything is enqueued at once and judged at the end; the kernels
   // run to completion on whatever a failed factorisation left behind (their waits depend on flags, not on values).
-  const bool one_sync = c->Npad <= 2048;
+  const bool one_sync = c->Npad <= 2048 || overlap;
   if (!one_sync) {
     GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
     GPG_HIP_OK(c, hipGetLastError());
@@ -429,7 +437,8 @@ static int gpg_lkd_grad_once(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out, dou
   AsmParams p = make_params(c, hp, 0);
   gpg_launch_combine_rows(c, 0);
   gpg_backward_solve(c);
-  gpg_inverse_from_factor(c, c->Wfull, c->Minv);
+  if (overlap) { if (!gpg_overlap_inverse_wwt(c, c->Wfull, c->Minv)) { c->err = "overlapped inverse: launch refused"; return -2; } }
+  else gpg_inverse_from_factor(c, c->Wfull, c->Minv);
   double* res = c->gpartial + (size_t)nval * nblk;
   gpg_launch_grad_contract(c, p, c->gpartial, res, c->zvec, c->Minv);
   std::vector<double> hvec;

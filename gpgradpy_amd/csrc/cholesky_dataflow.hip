@@ -1037,12 +1037,13 @@ rows_fwd_kernel(const double* __restrict__ A, int ld, const double* __restrict__
 struct Trinv64Args {
   const double* A; int ld; const double* dinv; double* W; int ldw, Mt; const int* tasks; int ntask; int* flags; int* abort_word;
   int* ticket; int* info; const int* batch_of; size_t a_stride, w_stride; int d_stride, f_stride;
+  int* lflags;   // non-null: the factorisation may still be running; its tile flags [ti * Mt + tj] (one matrix, 64 x 64 tiles)
 };
 
 __device__ __forceinline__ bool
 tile64_trinv_task(int tix, const double* __restrict__ A, int ld, const double* __restrict__ dinv, double* W, int ldw, int Mt,
                   const int* __restrict__ tasks, int* flags, int* abort_word, int* ticket, int* info,
-                  const int* __restrict__ batch_of, size_t a_stride, size_t w_stride, int d_stride, int f_stride) {
+                  const int* __restrict__ batch_of, size_t a_stride, size_t w_stride, int d_stride, int f_stride, int* lflags) {
   constexpr int KB = 16, SA = 80, BUF = KB * SA;
   __shared__ __attribute__((aligned(16))) double U[4 * BUF];
   __shared__ __attribute__((aligned(16))) double Ls[64][4][18];
@@ -1075,6 +1076,9 @@ tile64_trinv_task(int tix, const double* __restrict__ A, int ld, const double* _
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[ni][r] = Cw[(size_t)(ni * 16 + 4 * r) * ldw];
   }
+  // Overlapped with the factorisation (lflags): column tile tj of W needs row tile tj of L, L_(tj,k) for k <= tj -- all of it is final once
+  // the diagonal tile (tj, tj) is (its task consumed the others), so ONE wait on that flag covers the whole task.
+  if (lflags && !wg_wait_flag(lflags + (size_t)tj * Mt + tj, abort_word, info, &sh_kr)) return false;
   {   // L_jj is final: its image is fetched before the first wait
     const double* Ljj = A + cj + cj * (size_t)ld;
     for (int t = tid; t < 64 * 64; t += 256) {
@@ -1145,7 +1149,7 @@ __global__ void __launch_bounds__(256, 2) tile64_trinv_kernel(Trinv64Args) {
     GPG_KERNARGS(Trinv64Args, ap);
     if (tix >= ap->ntask) return;
     if (!tile64_trinv_task(tix, ap->A, ap->ld, ap->dinv, ap->W, ap->ldw, ap->Mt, ap->tasks, ap->flags, ap->abort_word, ap->ticket,
-                           ap->info, ap->batch_of, ap->a_stride, ap->w_stride, ap->d_stride, ap->f_stride))
+                           ap->info, ap->batch_of, ap->a_stride, ap->w_stride, ap->d_stride, ap->f_stride, ap->lflags))
       return;
     tix = g_next_ticket;
   }
@@ -1476,13 +1480,20 @@ static void launch_tile_chol(gpg_ctx* c, int c0) {
   const TileMap& tm = get_tile_tasks(c, Mt, Rt, fuse);
   if (!tm.dev) return;
   const size_t nflag = (size_t)Mt * Rt + 1 + 4 * (size_t)Mt + 8;   // tile flags, abort word, four piece flags per diagonal tile, ticket words
-  if (!ensure_tile_flags(c, nflag)) return;
-  (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * flags_fill(nflag), c->stream);
+  int* fl = c->chol_flags_override;                        // overlapped inverse: flags that stay valid after this launch (one-shot)
+  c->chol_flags_override = nullptr;
+  const bool keep = fl != nullptr && c0 == 0;
+  if (!keep) {
+    if (!ensure_tile_flags(c, nflag)) return;
+    fl = c->tile_flags;
+  }
+  (void)hipMemsetAsync(fl, 0, sizeof(int) * flags_fill(nflag), c->stream);
+  if (keep) (void)hipEventRecord(c->ev_flags, c->stream);  // from here on the second stream may poll them
   const double m = (double)(c->N - c0);                    // algorithmic flops: N^3 / 3 of the real matrix, not of the padded one
   gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, m > 0 ? m * m * m / 3.0 : 0.0);
-  int* abort_word = c->tile_flags + (size_t)Mt * Rt;
+  int* abort_word = fl + (size_t)Mt * Rt;
   hipLaunchKernelGGL(tile_chol_kernel, dim3(persistent_grid(c, tile_chol_kernel, tm.n)), dim3(256), 0, c->stream,
-                     TileCholArgs{c->A, c->ld, c0, Mt, tm.dev, tm.n, c->tile_flags, abort_word + 1, abort_word, c->tile_flags + (nflag - 8),
+                     TileCholArgs{c->A, c->ld, c0, Mt, tm.dev, tm.n, fl, abort_word + 1, abort_word, fl + (nflag - 8),
                                   c->dinv, c->info, c->N, nullptr, 0, 0, 0, fuse ? 1 : 0});
   gpg_prof_end(c);
 }
@@ -1573,8 +1584,11 @@ static void launch_tile128_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a
 // dataflow launches of N^3/3 flops each per matrix (tile128_trinv_kernel, tile128_wwt_kernel).  B matrices at once
 // (factor b at Abase + b a_stride with reciprocal pivots dinv_base + b d_stride, W / Minv of matrix b at + b Npad^2;
 // task lists interleaved tile column by tile column like the batched factorisation).  false: not applicable / no memory.
+// phase 0: both launches on c->stream; 1: W = L^-T only (flag buffer fbuf, factorisation flags lflags: gpg_overlap_inverse_trinv);
+// 2: -(W W^T) only (same fbuf).
 static bool launch_tile128_inverse_batch(gpg_ctx* c, int B, const double* Abase, size_t a_stride, const double* dinv_base, int d_stride,
-                                         double* Wbase, double* Mbase, int* info_base) {
+                                         double* Wbase, double* Mbase, int* info_base, int phase = 0, int* fbuf = nullptr,
+                                         int* lflags = nullptr) {
   const int Mt = c->Npad / 128, ldw = c->Npad;
   if (Mt < 1 || Mt > 0xffff || B < 1) return false;
   const size_t w_stride = (size_t)ldw * c->Npad;
@@ -1608,19 +1622,26 @@ static bool launch_tile128_inverse_batch(gpg_ctx* c, int B, const double* Abase,
   const int* bof2 = bof1 + tm.n;
   const size_t per = small ? (size_t)Mt64 * Mt64 : (size_t)Mt * Mt;
   const size_t nflag = per * B + 16;                // W tile flags per matrix | 9 ones | abort | ticket (trinv) | ticket (wwt)
-  if (!ensure_tile_flags(c, nflag)) return false;
-  int* ones = c->tile_flags + per * B;
-  (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * flags_fill(nflag), c->stream);
-  (void)hipMemsetD32Async((hipDeviceptr_t)ones, 1, 9, c->stream);
-  for (int b = 0; b < B; ++b) gpg_launch_identity(c, Wbase + (size_t)b * w_stride, ldw);
-  if (small)
-    hipLaunchKernelGGL(tile64_trinv_kernel, dim3(persistent_grid(c, tile64_trinv_kernel, tm.n)), dim3(256), 0, c->stream,
-                       Trinv64Args{Abase, c->ld, dinv_base, Wbase, ldw, Mt64, tasks1, tm.n, c->tile_flags, ones + 9, ones + 10, info_base,
+  int* fl = fbuf;
+  if (!fl) {
+    if (!ensure_tile_flags(c, nflag)) return false;
+    fl = c->tile_flags;
+  }
+  int* ones = fl + per * B;
+  if (phase != 2) {
+    (void)hipMemsetAsync(fl, 0, sizeof(int) * flags_fill(nflag), c->stream);
+    (void)hipMemsetD32Async((hipDeviceptr_t)ones, 1, 9, c->stream);
+    for (int b = 0; b < B; ++b) gpg_launch_identity(c, Wbase + (size_t)b * w_stride, ldw);
+    if (small)
+      hipLaunchKernelGGL(tile64_trinv_kernel, dim3(persistent_grid(c, tile64_trinv_kernel, tm.n)), dim3(256), 0, c->stream,
+                         Trinv64Args{Abase, c->ld, dinv_base, Wbase, ldw, Mt64, tasks1, tm.n, fl, ones + 9, ones + 10, info_base,
+                                     B > 1 ? bof1 : nullptr, a_stride, w_stride, d_stride, (int)per, lflags});
+    else
+      hipLaunchKernelGGL(tile128_trinv_kernel, dim3(persistent_grid(c, tile128_trinv_kernel, tm.n)), dim3(256), 0, c->stream,
+                         TrinvArgs{Abase, c->ld, dinv_base, Wbase, ldw, Mt, tasks1, tm.n, fl, ones, ones + 9, ones + 10, info_base,
                                    B > 1 ? bof1 : nullptr, a_stride, w_stride, d_stride, (int)per});
-  else
-    hipLaunchKernelGGL(tile128_trinv_kernel, dim3(persistent_grid(c, tile128_trinv_kernel, tm.n)), dim3(256), 0, c->stream,
-                       TrinvArgs{Abase, c->ld, dinv_base, Wbase, ldw, Mt, tasks1, tm.n, c->tile_flags, ones, ones + 9, ones + 10, info_base,
-                                 B > 1 ? bof1 : nullptr, a_stride, w_stride, d_stride, (int)per});
+    if (phase == 1) return true;
+  }
   if (small && B == 1) {   // one small matrix: -(W W^T) on 64-tiles too (task list cached under its own key)
     const unsigned long long key64 = (3ull << 61) | (1ull << 59) | (unsigned long long)Mt64;
     auto i64 = c->tilemaps.find(key64);
@@ -1749,6 +1770,47 @@ void gpg_launch_tile_chol(gpg_ctx* c, int c0) {
 void gpg_launch_tile128_chol(gpg_ctx* c) {
   launch_tile128_chol(c);
   c->last_factor_kernel = 2; c->last_factor_batch = 1;
+}
+// ---- value + gradient of ONE small matrix: W = L^-T overlapped with the factorisation ------------------------------------------------
+// The two chains (factorisation: one diagonal tile after the other; W = L^-T: one tile column after the other) are each latency-bound on
+// a small matrix and most of the chip idles through both.  The inverse's first launch goes to the context's second (lower-priority)
+// stream as soon as the factorisation has been enqueued; its tasks wait for the factorisation's diagonal-tile flags, so column tile j
+// of W is under way right after tile column j of L.  Progress: both grids are persistent and draw tickets; a W task waits only for
+// factorisation tasks (which never wait for W) and for W tasks with lower tickets, so whichever workgroups the hardware makes resident,
+// the factorisation advances, and behind it the inverse.  Bounded waits and the blocked fallback apply as everywhere.
+static size_t chol64_nflag(const gpg_ctx* c) {
+  const size_t Mt = c->Npad / 64, Rt = c->ld / 64;
+  return flags_fill(Mt * Rt + 1 + 4 * Mt + 8);
+}
+bool gpg_overlap_inverse_begin(gpg_ctx* c) {
+  const bool small_inv = c->inv_tile64_cols > 0 && c->Npad <= c->inv_tile64_cols;
+  const bool chol64 = c->tail_cols > 0 && c->Npad <= c->tail_cols && c->tail_cols < (1 << 30) + 1;
+  if (!c->overlap_inverse || !small_inv || !chol64 || c->prof_mask != 0 || c->stream_upd == c->stream || !c->stream_upd) return false;
+  const size_t Mt64 = c->Npad / 64;
+  const size_t need = chol64_nflag(c) + flags_fill(Mt64 * Mt64 + 16);
+  if (c->keep_flags_cap < need) {
+    if (c->keep_flags) (void)hipFree(c->keep_flags);
+    c->keep_flags = nullptr; c->keep_flags_cap = 0;
+    if (hipMalloc(reinterpret_cast<void**>(&c->keep_flags), sizeof(int) * need) != hipSuccess) { (void)hipGetLastError(); c->keep_flags = nullptr; return false; }
+    c->keep_flags_cap = need;
+  }
+  if (!c->ev_flags && hipEventCreateWithFlags(&c->ev_flags, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (!c->ev_trinv && hipEventCreateWithFlags(&c->ev_trinv, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
+  c->chol_flags_override = c->keep_flags;
+  return true;
+}
+bool gpg_overlap_inverse_trinv(gpg_ctx* c, double* W) {
+  hipStream_t main_stream = c->stream;
+  (void)hipStreamWaitEvent(c->stream_upd, c->ev_flags, 0);          // the factorisation's flags have been cleared
+  c->stream = c->stream_upd;
+  const bool ok = launch_tile128_inverse_batch(c, 1, c->A, 0, c->dinv, 0, W, nullptr, c->info, 1, c->keep_flags + chol64_nflag(c), c->keep_flags);
+  (void)hipEventRecord(c->ev_trinv, c->stream_upd);
+  c->stream = main_stream;
+  return ok;
+}
+bool gpg_overlap_inverse_wwt(gpg_ctx* c, double* W, double* Minv) {
+  (void)hipStreamWaitEvent(c->stream, c->ev_trinv, 0);
+  return launch_tile128_inverse_batch(c, 1, c->A, 0, c->dinv, 0, W, Minv, c->info, 2, c->keep_flags + chol64_nflag(c), nullptr);
 }
 bool gpg_launch_tile128_inverse(gpg_ctx* c, double* W, double* Minv) { return launch_tile128_inverse(c, W, Minv); }
 // out_dev[0] = squared Frobenius norm of the symmetric N x N matrix whose lower triangle sits in M (leading dimension ld)

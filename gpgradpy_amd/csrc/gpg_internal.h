@@ -69,6 +69,14 @@ struct gpg_ctx {
                                  // blocked forward sweep is as fast (cfg3: ~5000 points; tools/post_many.py; env GPG_ROWS_MAX_TASKS overrides)
   int inv_tile64_cols = 4096;   // explicit inverse: W = L^-T on 64 x 64 tiles up to this many padded columns (0: always 128-tiles)
   int* tile_flags = nullptr;   // device: completion flags of the dataflow kernel + abort word + ticket counter
+  // value + gradient of ONE small matrix: W = L^-T is launched on the second stream while the factorisation is still running and waits
+  // for the factorisation's own diagonal-tile flags (gpg_overlap_inverse_* in cholesky_dataflow.hip).  Both launches keep their flags in
+  // keep_flags, which nothing else clears meanwhile.
+  int overlap_inverse = 1;     // 0: off (env GPG_OVERLAP_INVERSE)
+  int* keep_flags = nullptr;
+  size_t keep_flags_cap = 0;
+  int* chol_flags_override = nullptr;   // launch_tile_chol: use this (large enough) buffer for the next launch and record ev_flags after clearing it
+  hipEvent_t ev_flags = nullptr, ev_trinv = nullptr;
   int num_cus = 0;             // compute units of the device (grid of the persistent launches)
   bool alpha_valid = false;    // zvec of workspace set 0 holds p * alpha of the last gpg_lkd_grad (gpg_lkd_alpha)
   bool zero_info_in_prep = false;    // the next gpg_launch_prep also clears *c->info (consumed by it)
@@ -163,6 +171,9 @@ void gpg_launch_tile_chol(gpg_ctx* c, int c0);                          // dataf
 void gpg_launch_tile128_chol(gpg_ctx* c);
 // dataflow W <- W L^-T / Z <- Z L^-1 for a few 64-row tiles; rows >= valid must be zero (their substitution is skipped);
 // false: not applicable (caller falls back on the blocked sweep)
+bool gpg_overlap_inverse_begin(gpg_ctx* c);                 // eligible? then the next factorisation keeps its flags (call before enqueueing it)
+bool gpg_overlap_inverse_trinv(gpg_ctx* c, double* W);      // after the factorisation was enqueued: W = L^-T on the second stream
+bool gpg_overlap_inverse_wwt(gpg_ctx* c, double* W, double* Minv);   // Minv = -W W^T on the main stream, after W
 bool gpg_launch_tile128_inverse(gpg_ctx* c, double* W, double* Minv);   // Minv <- -(L L^T)^-1 by two dataflow launches
 bool gpg_launch_tile128_inverse_batch(gpg_ctx* c, int B, const double* Abase, size_t a_stride, const double* dinv_base, int d_stride,
                                       double* Wbase, double* Mbase, int* info_base);   // the same for B factors at once

@@ -499,3 +499,31 @@ def test_posterior_at_many_points_one_dataflow_launch():
     np.testing.assert_allclose(pieces[90000][0][idx], mu_o, rtol=1e-6, atol=1e-7 * max(1.0, np.abs(mu_o).max()))
     np.testing.assert_allclose(pieces[90000][1][idx], sig_o, rtol=1e-4, atol=1e-6 * np.sqrt(hp.varK))
     assert GP.factor_fallbacks() == 0
+
+
+def test_overlapped_inverse_equals_sequential(monkeypatch):
+    """Value + gradient of one small matrix: W = L^-T runs on the context's second stream behind the factorisation, gated by the
+    factorisation's diagonal-tile flags.  Same arithmetic in the same order as the sequential schedule: bit-identical gradients; and
+    the progress argument must hold with any number of resident workgroups (gpg_set_max_workgroups)."""
+    import gpgradpy_amd
+    from oracle import gp_oracle as orc
+    for n, d, kernel in ((30, 3, 'SqExp'), (200, 4, 'Ma5f2'), (450, 6, 'SqExp')):          # 2, 16 and 50 tile columns
+        X, f, g = orc.synthetic_design(n, d, seed=n)
+        res = {}
+        for mode in ('0', '1'):
+            monkeypatch.setenv('GPG_OVERLAP_INVERSE', mode)
+            GP = gpgradpy_amd.GaussianProcess(d, True, kernel, 'precon')
+            GP.set_data(X, f, np.full(n, 1e-3), g, np.full((n, d), 1e-2))
+            hp = GP.make_hp_class(theta=np.linspace(0.05, 0.3, d), varK=1.3)
+            out = []
+            for cap in (0, 1, 3, 100):
+                GP.set_max_workgroups(cap)
+                info, ok = GP.calc_lkd_all(hp, calc_grad=True)
+                assert ok and GP.factor_fallbacks() == 0
+                out.append((info.ln_lkd, info.ln_lkd_grad.copy()))
+            for ln, gr in out[1:]:
+                assert ln == out[0][0] and np.array_equal(gr, out[0][1])
+            res[mode] = out[0]
+            GP.close()
+        assert res['0'][0] == res['1'][0]
+        np.testing.assert_array_equal(res['0'][1], res['1'][1])
