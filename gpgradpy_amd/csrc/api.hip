@@ -414,10 +414,10 @@ static int gpg_lkd_grad_once(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out, dou
   if (!c->gpartial) GPG_HIP_OK(c, hipMalloc(&c->gpartial, sizeof(double) * (size_t)nval * (nblk + 1)));
   c->zero_info_in_prep = true;
   // small matrix on the dataflow schedule: W = L^-T goes to the second stream right behind the factorisation (cholesky_dataflow.hip)
-  const bool overlap = c->Npad <= 4096 && gpg_overlap_inverse_begin(c);
+  const bool overlap = c->Npad <= 4096 && gpg_overlap_inverse_begin(c, 1);
   enqueue_lkd(c, hp, 0);                                   // factor + beta + r'K^-1 r + ln det (scal slot 0)
   c->chol_flags_override = nullptr;                        // (consumed by the 64-tile launch; cleared in case another schedule ran)
-  if (overlap && !gpg_overlap_inverse_trinv(c, c->Wfull)) { c->err = "overlapped inverse: launch refused"; return -2; }
+  if (overlap && !gpg_overlap_inverse_trinv(c, 1, c->A, 0, c->dinv, 0, c->Wfull, c->info)) { c->err = "overlapped inverse: launch refused"; return -2; }
   GPG_HIP_OK(c, hipMemcpyAsync(c->h_scal, c->scal, sizeof(double) * 8, hipMemcpyDeviceToHost, c->stream));
   // Large matrices: look at the factorisation's info before spending two more N^3/3 sweeps on a failed factor.  Small ones
   // (the sweeps cost less than a host round trip is worth): everything is enqueued at once and judged at the end; the kernels
@@ -437,7 +437,7 @@ static int gpg_lkd_grad_once(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out, dou
   AsmParams p = make_params(c, hp, 0);
   gpg_launch_combine_rows(c, 0);
   gpg_backward_solve(c);
-  if (overlap) { if (!gpg_overlap_inverse_wwt(c, c->Wfull, c->Minv)) { c->err = "overlapped inverse: launch refused"; return -2; } }
+  if (overlap) { if (!gpg_overlap_inverse_wwt(c, 1, c->A, 0, c->dinv, 0, c->Wfull, c->Minv, c->info)) { c->err = "overlapped inverse: launch refused"; return -2; } }
   else gpg_inverse_from_factor(c, c->Wfull, c->Minv);
   double* res = c->gpartial + (size_t)nval * nblk;
   gpg_launch_grad_contract(c, p, c->gpartial, res, c->zvec, c->Minv);
@@ -709,8 +709,15 @@ static int gpg_lkd_grad_batch_once(gpg_ctx* c, int m, const double* hp_rows, int
       c->last_precon = c->items_host[r0].p.precon;
       GPG_HIP_OK(c, hipMemcpyAsync(c->items_dev + r0, c->items_host + r0, sizeof(gpg_batch_item) * Bg, hipMemcpyHostToDevice, c->stream));
       gpg_launch_prep_assembly_batch(c, c->items_host[r0].p, Bg, c->items_dev + r0, vs, c->A_elems);
+      // small matrices: W = L^-T of the group on the second stream behind the factorisation (cholesky_dataflow.hip)
+      const bool overlap = c->Npad <= 4096 && gpg_overlap_inverse_begin(c, Bg);
       if (Bg > 1) gpg_launch_tile_chol_batch(c, Bg, c->batchA, c->A_elems, c->batchV + 2 * (size_t)c->Npad, 3 * c->Npad, info0 + r0);
       else { c->info = info0 + r0; gpg_cholesky(c); c->info = info0; }
+      c->chol_flags_override = nullptr;
+      if (overlap && !gpg_overlap_inverse_trinv(c, Bg, c->batchA, c->A_elems, c->batchV + 2 * (size_t)c->Npad, 3 * c->Npad, c->batchW, info0 + r0)) {
+        c->err = "overlapped batched inverse: launch refused";
+        return -2;
+      }
       gpg_launch_lkd_reduce_batch(c, r0, Bg, vs, c->A_elems, info0 + r0);
       for (int b = 0; b < Bg; ++b) {     // alpha of matrix b: RHS row 0 <- w2 - beta w1, then z = L^-T (.) by the vector solve
         c->A = c->batchA + (size_t)b * c->A_elems;
@@ -721,8 +728,10 @@ static int gpg_lkd_grad_batch_once(gpg_ctx* c, int m, const double* hp_rows, int
         gpg_backward_solve(c);
       }
       c->info = info0;
-      if (!gpg_launch_tile128_inverse_batch(c, Bg, c->batchA, c->A_elems, c->batchV + 2 * (size_t)c->Npad, 3 * c->Npad, c->batchW,
-                                            c->batchM, info0 + r0)) {
+      if (overlap ? !gpg_overlap_inverse_wwt(c, Bg, c->batchA, c->A_elems, c->batchV + 2 * (size_t)c->Npad, 3 * c->Npad, c->batchW, c->batchM,
+                                             info0 + r0)
+                  : !gpg_launch_tile128_inverse_batch(c, Bg, c->batchA, c->A_elems, c->batchV + 2 * (size_t)c->Npad, 3 * c->Npad, c->batchW,
+                                                      c->batchM, info0 + r0)) {
         c->err = "batched inverse could not be launched";
         return -2;
       }

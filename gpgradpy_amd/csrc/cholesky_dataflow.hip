@@ -1037,13 +1037,14 @@ rows_fwd_kernel(const double* __restrict__ A, int ld, const double* __restrict__
 struct Trinv64Args {
   const double* A; int ld; const double* dinv; double* W; int ldw, Mt; const int* tasks; int ntask; int* flags; int* abort_word;
   int* ticket; int* info; const int* batch_of; size_t a_stride, w_stride; int d_stride, f_stride;
-  int* lflags;   // non-null: the factorisation may still be running; its tile flags [ti * Mt + tj] (one matrix, 64 x 64 tiles)
+  int* lflags;   // non-null: the factorisation may still be running; its tile flags [ti * Mt + tj] (64 x 64 tiles; matrix b at + b lf_stride)
+  int lf_stride;
 };
 
 __device__ __forceinline__ bool
 tile64_trinv_task(int tix, const double* __restrict__ A, int ld, const double* __restrict__ dinv, double* W, int ldw, int Mt,
                   const int* __restrict__ tasks, int* flags, int* abort_word, int* ticket, int* info,
-                  const int* __restrict__ batch_of, size_t a_stride, size_t w_stride, int d_stride, int f_stride, int* lflags) {
+                  const int* __restrict__ batch_of, size_t a_stride, size_t w_stride, int d_stride, int f_stride, int* lflags, int lf_stride) {
   constexpr int KB = 16, SA = 80, BUF = KB * SA;
   __shared__ __attribute__((aligned(16))) double U[4 * BUF];
   __shared__ __attribute__((aligned(16))) double Ls[64][4][18];
@@ -1062,6 +1063,7 @@ tile64_trinv_task(int tix, const double* __restrict__ A, int ld, const double* _
     W += (size_t)b * w_stride;
     flags += (size_t)b * f_stride;
     info += b;
+    if (lflags) lflags += (size_t)b * lf_stride;
   }
   const size_t r0 = 64 * (size_t)rt, cj = 64 * (size_t)tj;
   const int q = tid & 3;
@@ -1149,7 +1151,7 @@ __global__ void __launch_bounds__(256, 2) tile64_trinv_kernel(Trinv64Args) {
     GPG_KERNARGS(Trinv64Args, ap);
     if (tix >= ap->ntask) return;
     if (!tile64_trinv_task(tix, ap->A, ap->ld, ap->dinv, ap->W, ap->ldw, ap->Mt, ap->tasks, ap->flags, ap->abort_word, ap->ticket,
-                           ap->info, ap->batch_of, ap->a_stride, ap->w_stride, ap->d_stride, ap->f_stride, ap->lflags))
+                           ap->info, ap->batch_of, ap->a_stride, ap->w_stride, ap->d_stride, ap->f_stride, ap->lflags, ap->lf_stride))
       return;
     tix = g_next_ticket;
   }
@@ -1522,13 +1524,20 @@ static void launch_tile_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a_st
   }
   const TileMap& tm = it->second;
   const size_t per = (size_t)Mt * Rt + 1 + 4 * (size_t)Mt, nflag = per * B + 8;   // + the ticket words of the launch
-  if (!ensure_tile_flags(c, nflag)) return;
-  (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * flags_fill(nflag), c->stream);
+  int* fl = c->chol_flags_override;                        // overlapped inverse (gpg_overlap_inverse_begin): one-shot
+  c->chol_flags_override = nullptr;
+  const bool keep = fl != nullptr;
+  if (!keep) {
+    if (!ensure_tile_flags(c, nflag)) return;
+    fl = c->tile_flags;
+  }
+  (void)hipMemsetAsync(fl, 0, sizeof(int) * flags_fill(nflag), c->stream);
+  if (keep) (void)hipEventRecord(c->ev_flags, c->stream);
   const double m = (double)c->N;
   gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, B * m * m * m / 3.0);
-  int* abort_word = c->tile_flags + (size_t)Mt * Rt;      // the abort word of matrix 0 serves the whole launch
+  int* abort_word = fl + (size_t)Mt * Rt;                 // the abort word of matrix 0 serves the whole launch
   hipLaunchKernelGGL(tile_chol_kernel, dim3(persistent_grid(c, tile_chol_kernel, tm.n)), dim3(256), 0, c->stream,
-                     TileCholArgs{Abase, c->ld, 0, Mt, tm.dev, tm.n, c->tile_flags, abort_word + 1, abort_word, c->tile_flags + (nflag - 8),
+                     TileCholArgs{Abase, c->ld, 0, Mt, tm.dev, tm.n, fl, abort_word + 1, abort_word, fl + (nflag - 8),
                                   dinv_base, info_base, c->N, tm.dev + tm.n, a_stride, d_stride, (int)per, fuse ? 1 : 0});
   gpg_prof_end(c);
 }
@@ -1588,7 +1597,7 @@ static void launch_tile128_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a
 // 2: -(W W^T) only (same fbuf).
 static bool launch_tile128_inverse_batch(gpg_ctx* c, int B, const double* Abase, size_t a_stride, const double* dinv_base, int d_stride,
                                          double* Wbase, double* Mbase, int* info_base, int phase = 0, int* fbuf = nullptr,
-                                         int* lflags = nullptr) {
+                                         int* lflags = nullptr, int lf_stride = 0) {
   const int Mt = c->Npad / 128, ldw = c->Npad;
   if (Mt < 1 || Mt > 0xffff || B < 1) return false;
   const size_t w_stride = (size_t)ldw * c->Npad;
@@ -1635,7 +1644,7 @@ static bool launch_tile128_inverse_batch(gpg_ctx* c, int B, const double* Abase,
     if (small)
       hipLaunchKernelGGL(tile64_trinv_kernel, dim3(persistent_grid(c, tile64_trinv_kernel, tm.n)), dim3(256), 0, c->stream,
                          Trinv64Args{Abase, c->ld, dinv_base, Wbase, ldw, Mt64, tasks1, tm.n, fl, ones + 9, ones + 10, info_base,
-                                     B > 1 ? bof1 : nullptr, a_stride, w_stride, d_stride, (int)per, lflags});
+                                     B > 1 ? bof1 : nullptr, a_stride, w_stride, d_stride, (int)per, lflags, lf_stride});
     else
       hipLaunchKernelGGL(tile128_trinv_kernel, dim3(persistent_grid(c, tile128_trinv_kernel, tm.n)), dim3(256), 0, c->stream,
                          TrinvArgs{Abase, c->ld, dinv_base, Wbase, ldw, Mt, tasks1, tm.n, fl, ones, ones + 9, ones + 10, info_base,
@@ -1778,16 +1787,23 @@ void gpg_launch_tile128_chol(gpg_ctx* c) {
 // of W is under way right after tile column j of L.  Progress: both grids are persistent and draw tickets; a W task waits only for
 // factorisation tasks (which never wait for W) and for W tasks with lower tickets, so whichever workgroups the hardware makes resident,
 // the factorisation advances, and behind it the inverse.  Bounded waits and the blocked fallback apply as everywhere.
-static size_t chol64_nflag(const gpg_ctx* c) {
+static size_t chol64_per(const gpg_ctx* c) {
   const size_t Mt = c->Npad / 64, Rt = c->ld / 64;
-  return flags_fill(Mt * Rt + 1 + 4 * Mt + 8);
+  return Mt * Rt + 1 + 4 * Mt;
 }
-bool gpg_overlap_inverse_begin(gpg_ctx* c) {
+static size_t chol64_nflag(const gpg_ctx* c, int B) { return flags_fill(chol64_per(c) * B + 8); }
+// Does a batch of B matrices go to the 128-tile factorisation kernel?  (gpg_launch_tile_chol_batch below decides with this.)
+static bool batch_uses_tile128(const gpg_ctx* c, int B) {
+  if (c->tail_cols >= (1 << 30)) return false;
+  if (c->tail_cols == 0) return true;
+  return c->Npad > c->tail_cols || (c->Npad >= 2048 && (long)B * (c->Npad / 128) >= 320);
+}
+bool gpg_overlap_inverse_begin(gpg_ctx* c, int B) {
   const bool small_inv = c->inv_tile64_cols > 0 && c->Npad <= c->inv_tile64_cols;
-  const bool chol64 = c->tail_cols > 0 && c->Npad <= c->tail_cols && c->tail_cols < (1 << 30) + 1;
-  if (!c->overlap_inverse || !small_inv || !chol64 || c->prof_mask != 0 || c->stream_upd == c->stream || !c->stream_upd) return false;
+  const bool chol64 = B > 1 ? !batch_uses_tile128(c, B) : (c->tail_cols > 0 && c->Npad <= c->tail_cols);
+  if (!c->overlap_inverse || B < 1 || !small_inv || !chol64 || c->prof_mask != 0 || c->stream_upd == c->stream || !c->stream_upd) return false;
   const size_t Mt64 = c->Npad / 64;
-  const size_t need = chol64_nflag(c) + flags_fill(Mt64 * Mt64 + 16);
+  const size_t need = chol64_nflag(c, B) + flags_fill(Mt64 * Mt64 * B + 16);
   if (c->keep_flags_cap < need) {
     if (c->keep_flags) (void)hipFree(c->keep_flags);
     c->keep_flags = nullptr; c->keep_flags_cap = 0;
@@ -1799,18 +1815,21 @@ bool gpg_overlap_inverse_begin(gpg_ctx* c) {
   c->chol_flags_override = c->keep_flags;
   return true;
 }
-bool gpg_overlap_inverse_trinv(gpg_ctx* c, double* W) {
+bool gpg_overlap_inverse_trinv(gpg_ctx* c, int B, const double* Abase, size_t a_stride, const double* dinv_base, int d_stride, double* Wbase,
+                               int* info_base) {
   hipStream_t main_stream = c->stream;
   (void)hipStreamWaitEvent(c->stream_upd, c->ev_flags, 0);          // the factorisation's flags have been cleared
   c->stream = c->stream_upd;
-  const bool ok = launch_tile128_inverse_batch(c, 1, c->A, 0, c->dinv, 0, W, nullptr, c->info, 1, c->keep_flags + chol64_nflag(c), c->keep_flags);
+  const bool ok = launch_tile128_inverse_batch(c, B, Abase, a_stride, dinv_base, d_stride, Wbase, nullptr, info_base, 1,
+                                               c->keep_flags + chol64_nflag(c, B), c->keep_flags, (int)chol64_per(c));
   (void)hipEventRecord(c->ev_trinv, c->stream_upd);
   c->stream = main_stream;
   return ok;
 }
-bool gpg_overlap_inverse_wwt(gpg_ctx* c, double* W, double* Minv) {
+bool gpg_overlap_inverse_wwt(gpg_ctx* c, int B, const double* Abase, size_t a_stride, const double* dinv_base, int d_stride, double* Wbase,
+                             double* Mbase, int* info_base) {
   (void)hipStreamWaitEvent(c->stream, c->ev_trinv, 0);
-  return launch_tile128_inverse_batch(c, 1, c->A, 0, c->dinv, 0, W, Minv, c->info, 2, c->keep_flags + chol64_nflag(c), nullptr);
+  return launch_tile128_inverse_batch(c, B, Abase, a_stride, dinv_base, d_stride, Wbase, Mbase, info_base, 2, c->keep_flags + chol64_nflag(c, B));
 }
 bool gpg_launch_tile128_inverse(gpg_ctx* c, double* W, double* Minv) { return launch_tile128_inverse(c, W, Minv); }
 // out_dev[0] = squared Frobenius norm of the symmetric N x N matrix whose lower triangle sits in M (leading dimension ld)
@@ -1856,10 +1875,7 @@ void gpg_launch_tile_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a_strid
   // dependency chain per column) as soon as the batch puts enough of its tasks in flight to hide that chain
   // (measured, tools/tile_probe 5 / 6: 2560 columns x 8 matrices 21 TF against 28 for the 64-tile kernel, x 32
   // matrices 37 against 33; 4608 x 8: 42 / 39; 9216 x 8: 59 / 47).
-  bool use128;
-  if (c->tail_cols >= (1 << 30)) use128 = false;
-  else if (c->tail_cols == 0) use128 = true;
-  else use128 = c->Npad > c->tail_cols || (c->Npad >= 2048 && (long)B * (c->Npad / 128) >= 320);
+  const bool use128 = batch_uses_tile128(c, B);
   if (use128) launch_tile128_chol_batch(c, B, Abase, a_stride, dinv_base, d_stride, info_base);
   else launch_tile_chol_batch(c, B, Abase, a_stride, dinv_base, d_stride, info_base);
   c->last_factor_kernel = use128 ? 2 : 1;

@@ -171,9 +171,11 @@ void gpg_launch_tile_chol(gpg_ctx* c, int c0);                          // dataf
 void gpg_launch_tile128_chol(gpg_ctx* c);
 // dataflow W <- W L^-T / Z <- Z L^-1 for a few 64-row tiles; rows >= valid must be zero (their substitution is skipped);
 // false: not applicable (caller falls back on the blocked sweep)
-bool gpg_overlap_inverse_begin(gpg_ctx* c);                 // eligible? then the next factorisation keeps its flags (call before enqueueing it)
-bool gpg_overlap_inverse_trinv(gpg_ctx* c, double* W);      // after the factorisation was enqueued: W = L^-T on the second stream
-bool gpg_overlap_inverse_wwt(gpg_ctx* c, double* W, double* Minv);   // Minv = -W W^T on the main stream, after W
+bool gpg_overlap_inverse_begin(gpg_ctx* c, int B);          // eligible? then the next (batched) factorisation keeps its flags (call before enqueueing it)
+bool gpg_overlap_inverse_trinv(gpg_ctx* c, int B, const double* Abase, size_t a_stride, const double* dinv_base, int d_stride, double* Wbase,
+                               int* info_base);             // after the factorisation was enqueued: W = L^-T on the second stream
+bool gpg_overlap_inverse_wwt(gpg_ctx* c, int B, const double* Abase, size_t a_stride, const double* dinv_base, int d_stride, double* Wbase,
+                             double* Mbase, int* info_base);   // Minv = -W W^T on the main stream, after W
 bool gpg_launch_tile128_inverse(gpg_ctx* c, double* W, double* Minv);   // Minv <- -(L L^T)^-1 by two dataflow launches
 bool gpg_launch_tile128_inverse_batch(gpg_ctx* c, int B, const double* Abase, size_t a_stride, const double* dinv_base, int d_stride,
                                       double* Wbase, double* Mbase, int* info_base);   // the same for B factors at once
