@@ -1721,6 +1721,13 @@ __global__ void __launch_bounds__(256) symmetrize_kernel(double* __restrict__ M,
 }
 
 // W (rows x Npad, rows a multiple of 64) <- W L^-T with the dataflow kernel; returns false if it does not apply.
+// abort word + ticket cleared and the exchange buffer filled with the sentinel: one launch instead of two fills
+__global__ void __launch_bounds__(256) vec_solve_prep_kernel(int* __restrict__ flags, unsigned* __restrict__ x, size_t nwords, unsigned pattern) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < 2) flags[i] = 0;
+  if (i < nwords) x[i] = pattern;
+}
+
 static bool launch_vec_solve(gpg_ctx* c, double* W, int ldw, int R, bool bwd) {
   const int Mt = c->Npad / 64;
   if (!ensure_tile_flags(c, 64)) return false;
@@ -1730,8 +1737,11 @@ static bool launch_vec_solve(gpg_ctx* c, double* W, int ldw, int R, bool bwd) {
     if (!gpg_dev_alloc(c, &c->vec_x, sizeof(double) * 4 * (size_t)c->Npad)) return false;
     c->vec_x_cols = c->Npad;
   }
-  (void)hipMemsetAsync(c->tile_flags, 0, 2 * sizeof(int), c->stream);                          // abort word, ticket
-  (void)hipMemsetD32Async((hipDeviceptr_t)c->vec_x, (int)(GPG_VEC_SENTINEL & 0xffffffffull), (size_t)2 * R * c->Npad, c->stream);
+  {
+    const size_t nwords = (size_t)2 * R * c->Npad;                                             // abort word, ticket; sentinel words
+    hipLaunchKernelGGL(vec_solve_prep_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, c->stream, c->tile_flags,
+                       reinterpret_cast<unsigned*>(c->vec_x), nwords, (unsigned)(GPG_VEC_SENTINEL & 0xffffffffull));
+  }
 #define GPG_VEC_LAUNCH(BWD, RR)                                                                                          \
   hipLaunchKernelGGL((vec_solve_kernel<BWD, RR>), dim3(persistent_grid(c, vec_solve_kernel<BWD, RR>, Mt)), dim3(256), 0,  \
                      c->stream, VecSolveArgs{c->A, c->ld, c->dinv, W, ldw, Mt, R, (unsigned long long*)c->vec_x, c->Npad,  \
