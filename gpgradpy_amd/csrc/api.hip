@@ -414,7 +414,7 @@ static int gpg_lkd_grad_once(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out, dou
   if (!c->gpartial) GPG_HIP_OK(c, hipMalloc(&c->gpartial, sizeof(double) * (size_t)nval * (nblk + 1)));
   c->zero_info_in_prep = true;
   // small matrix on the dataflow schedule: W = L^-T goes to the second stream right behind the factorisation (cholesky_dataflow.hip)
-  const bool overlap = c->Npad <= 4096 && gpg_overlap_inverse_begin(c, 1);
+  const bool overlap = c->Npad <= 12288 && gpg_overlap_inverse_begin(c, 1);   // (beyond: a failed factorisation should not cost two more sweeps)
   enqueue_lkd(c, hp, 0);                                   // factor + beta + r'K^-1 r + ln det (scal slot 0)
   c->chol_flags_override = nullptr;                        // (consumed by the 64-tile launch; cleared in case another schedule ran)
   if (overlap && !gpg_overlap_inverse_trinv(c, 1, c->A, 0, c->dinv, 0, c->Wfull, c->info)) { c->err = "overlapped inverse: launch refused"; return -2; }

@@ -733,7 +733,7 @@ __global__ void __launch_bounds__(256, 2) tile128_chol_kernel(TileCholArgs) {   
 __device__ __forceinline__ bool
 tile128_trinv_task(int tix, const double* __restrict__ A, int ld, const double* __restrict__ dinv, double* W, int ldw, int Mt,
                    const int* __restrict__ tasks, int* flags, int* ones, int* abort_word, int* ticket, int* info,
-                   const int* __restrict__ batch_of, size_t a_stride, size_t w_stride, int d_stride, int f_stride) {
+                   const int* __restrict__ batch_of, size_t a_stride, size_t w_stride, int d_stride, int f_stride, int* lflags, int lf_mt) {
   __shared__ int sh_kr;
   __shared__ int sh_ok;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -741,6 +741,10 @@ tile128_trinv_task(int tix, const double* __restrict__ A, int ld, const double* 
   const int l15 = lane & 15, l4 = lane >> 4;
   const int task = tasks[tix];
   const int tj = task & 0xffff, ti = task >> 16;          // row tile j of W, column tile i
+  // Overlapped with a 64-tile factorisation (gpg_overlap_inverse_*): column tile ti of W needs the 128 rows 128 ti .. of L up to the
+  // diagonal; they are final once the factorisation's diagonal tile (2 ti + 1, 2 ti + 1) is (its task consumed the rest of its row, and the
+  // tile row above went the same way before it).
+  if (lflags && !wg_wait_flag(lflags + (size_t)(2 * ti + 1) * lf_mt + (2 * ti + 1), abort_word, info, &sh_ok)) return false;
   if (batch_of) {   // batched launch: the factors of several matrices (restart rows) are inverted by one launch
     const int b = batch_of[tix];
     A += (size_t)b * a_stride;
@@ -820,6 +824,7 @@ tile128_trinv_task(int tix, const double* __restrict__ A, int ld, const double* 
 struct TrinvArgs {
   const double* A; int ld; const double* dinv; double* W; int ldw, Mt; const int* tasks; int ntask; int* flags; int* ones;
   int* abort_word; int* ticket; int* info; const int* batch_of; size_t a_stride, w_stride; int d_stride, f_stride;
+  int* lflags; int lf_mt;   // non-null: the (64-tile, lf_mt tile columns) factorisation of this ONE matrix may still be running
 };
 
 __global__ void __launch_bounds__(256, 2) tile128_trinv_kernel(TrinvArgs) {
@@ -832,7 +837,7 @@ __global__ void __launch_bounds__(256, 2) tile128_trinv_kernel(TrinvArgs) {
     GPG_KERNARGS(TrinvArgs, ap);
     if (tix >= ap->ntask) return;
     if (!tile128_trinv_task(tix, ap->A, ap->ld, ap->dinv, ap->W, ap->ldw, ap->Mt, ap->tasks, ap->flags, ap->ones, ap->abort_word,
-                            ap->ticket, ap->info, ap->batch_of, ap->a_stride, ap->w_stride, ap->d_stride, ap->f_stride))
+                            ap->ticket, ap->info, ap->batch_of, ap->a_stride, ap->w_stride, ap->d_stride, ap->f_stride, ap->lflags, ap->lf_mt))
       return;
     tix = g_next_ticket;
   }
@@ -1648,7 +1653,7 @@ static bool launch_tile128_inverse_batch(gpg_ctx* c, int B, const double* Abase,
     else
       hipLaunchKernelGGL(tile128_trinv_kernel, dim3(persistent_grid(c, tile128_trinv_kernel, tm.n)), dim3(256), 0, c->stream,
                          TrinvArgs{Abase, c->ld, dinv_base, Wbase, ldw, Mt, tasks1, tm.n, fl, ones, ones + 9, ones + 10, info_base,
-                                   B > 1 ? bof1 : nullptr, a_stride, w_stride, d_stride, (int)per});
+                                   B > 1 ? bof1 : nullptr, a_stride, w_stride, d_stride, (int)per, B == 1 ? lflags : nullptr, c->Npad / 64});
     if (phase == 1) return true;
   }
   if (small && B == 1) {   // one small matrix: -(W W^T) on 64-tiles too (task list cached under its own key)
@@ -1809,11 +1814,12 @@ static bool batch_uses_tile128(const gpg_ctx* c, int B) {
   return c->Npad > c->tail_cols || (c->Npad >= 2048 && (long)B * (c->Npad / 128) >= 320);
 }
 bool gpg_overlap_inverse_begin(gpg_ctx* c, int B) {
-  const bool small_inv = c->inv_tile64_cols > 0 && c->Npad <= c->inv_tile64_cols;
+  const bool small_inv = c->inv_tile64_cols > 0 && c->Npad <= c->inv_tile64_cols;   // W on 64-tiles; above (one matrix only): on 128-tiles
   const bool chol64 = B > 1 ? !batch_uses_tile128(c, B) : (c->tail_cols > 0 && c->Npad <= c->tail_cols);
-  if (!c->overlap_inverse || B < 1 || !small_inv || !chol64 || c->prof_mask != 0 || c->stream_upd == c->stream || !c->stream_upd) return false;
+  if (!c->overlap_inverse || B < 1 || (!small_inv && B > 1) || !chol64 || c->prof_mask != 0 || c->stream_upd == c->stream || !c->stream_upd)
+    return false;
   const size_t Mt64 = c->Npad / 64;
-  const size_t need = chol64_nflag(c, B) + flags_fill(Mt64 * Mt64 * B + 16);
+  const size_t need = chol64_nflag(c, B) + flags_fill(Mt64 * Mt64 * B + 16);           // (the 128-tile W needs a quarter of the second term)
   if (c->keep_flags_cap < need) {
     if (c->keep_flags) (void)hipFree(c->keep_flags);
     c->keep_flags = nullptr; c->keep_flags_cap = 0;

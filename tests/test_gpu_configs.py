@@ -507,7 +507,8 @@ def test_overlapped_inverse_equals_sequential(monkeypatch):
     the progress argument must hold with any number of resident workgroups (gpg_set_max_workgroups)."""
     import gpgradpy_amd
     from oracle import gp_oracle as orc
-    for n, d, kernel in ((30, 3, 'SqExp'), (200, 4, 'Ma5f2'), (450, 6, 'SqExp')):          # 2, 16 and 50 tile columns
+    # 2, 16 and 50 tile columns (W on 64 x 64 tiles), 78 (64-tile factorisation, W on 128 x 128 tiles)
+    for n, d, kernel in ((30, 3, 'SqExp'), (200, 4, 'Ma5f2'), (450, 6, 'SqExp'), (700, 6, 'SqExp')):
         X, f, g = orc.synthetic_design(n, d, seed=n)
         res = {}
         for mode in ('0', '1'):
@@ -516,7 +517,7 @@ def test_overlapped_inverse_equals_sequential(monkeypatch):
             GP.set_data(X, f, np.full(n, 1e-3), g, np.full((n, d), 1e-2))
             hp = GP.make_hp_class(theta=np.linspace(0.05, 0.3, d), varK=1.3)
             out = []
-            for cap in (0, 1, 3, 100):
+            for cap in ((0, 1, 3, 100) if n < 700 else (0, 7, 100)):
                 GP.set_max_workgroups(cap)
                 info, ok = GP.calc_lkd_all(hp, calc_grad=True)
                 assert ok and GP.factor_fallbacks() == 0
