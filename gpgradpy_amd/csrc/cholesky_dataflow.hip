@@ -843,6 +843,35 @@ __global__ void __launch_bounds__(256, 2) tile128_trinv_kernel(TrinvArgs) {
   }
 }
 
+// Frontier of a contraction over tile columns k of W that may still be in the making (W = L^-T running on the other stream): thread 0
+// advances kr from kdone while BOTH flag rows show column kr finished, waits (bounded) until at least one column is; result through sh.
+// Returns the new frontier, or -1 (timed out / aborted).  Whole workgroup; ends with an acquire.
+__device__ __forceinline__ int wg_wait_two_rows(int* fa, int* fb, int kdone, int kend, int* abort_word, int* info, int* sh) {
+  if (threadIdx.x == 0) {
+    int kr = kdone;
+    const unsigned long long t_wait = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+      while (kr < kend && __hip_atomic_load(fa + kr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 &&
+             __hip_atomic_load(fb + kr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+        ++kr;
+      if (kr > kdone) break;
+      if (__builtin_amdgcn_s_memrealtime() - t_wait > GPG_TILE_WAIT_TICKS || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicMax(info, GPG_INFO_INTERNAL);
+        kr = -1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    *sh = kr;
+  }
+  __syncthreads();
+  const int kr = *sh;
+  __syncthreads();
+  if (kr >= 0) GPG_ACQUIRE();
+  return kr;
+}
+
 // ------------------------------------------------------------------------------------------------
 // tile128_wwt_kernel: M = - W W^T, lower triangle (second N^3/3 sweep of the explicit inverse: -(L L^T)^-1 = -L^-T L^-1),
 // W = L^-T upper triangular: tile (a, b), a >= b:  M_ab = - sum_{k >= a} W_ak W_bk^T -- independent tiles, no flags;
@@ -853,8 +882,11 @@ __global__ void __launch_bounds__(256, 2) tile128_trinv_kernel(TrinvArgs) {
 // and the contraction over ALL tile columns when full_k != 0 (Sb0 == nullptr: Sb = Sa, the W W^T case).
 __global__ void __launch_bounds__(256, 2)
 tile128_wwt_kernel(const double* __restrict__ W0, int ldw, double* __restrict__ M0, int ldm, int Mt, const int* __restrict__ tasks,
-                   int ntask, int* ticket, const int* __restrict__ batch_of, size_t w_stride, const double* __restrict__ Sb0, int full_k) {
+                   int ntask, int* ticket, const int* __restrict__ batch_of, size_t w_stride, const double* __restrict__ Sb0, int full_k,
+                   int* wflags /* non-null (one matrix, W W^T): tile flags [row * Mt + column] of a W still in the making */, int* abort_word,
+                   int* info) {
   __shared__ int sh_tix;
+  __shared__ int sh_kr;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int wm = w & 1, wn = w >> 1;
   const int l15 = lane & 15, l4 = lane >> 4;
@@ -875,8 +907,20 @@ tile128_wwt_kernel(const double* __restrict__ W0, int ldw, double* __restrict__ 
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[ni][mi][r] = 0.0;
-    direct_tile_gemm_x2<GPG_MFMA_PF>(acc, W + r0 + wm * 64 + 2 * l15 + (ck + l4) * (size_t)ldw, ldw,
-                           Wb + c0 + wn * 64 + 2 * l15 + (ck + l4) * (size_t)ldw, ldw, 32 * (full_k ? Mt : Mt - ta));
+    if (!wflags) {
+      direct_tile_gemm_x2<GPG_MFMA_PF>(acc, W + r0 + wm * 64 + 2 * l15 + (ck + l4) * (size_t)ldw, ldw,
+                             Wb + c0 + wn * 64 + 2 * l15 + (ck + l4) * (size_t)ldw, ldw, 32 * (full_k ? Mt : Mt - ta));
+    } else {   // the same sum in the same order, in runs of the tile columns of W that are finished
+      int kdone = ta;
+      while (kdone < Mt) {
+        const int kr = wg_wait_two_rows(wflags + (size_t)ta * Mt, wflags + (size_t)tb * Mt, kdone, Mt, abort_word, info, &sh_kr);
+        if (kr < 0) return;
+        const size_t cc = 128 * (size_t)kdone;
+        direct_tile_gemm_x2<GPG_MFMA_PF>(acc, W + r0 + wm * 64 + 2 * l15 + (cc + l4) * (size_t)ldw, ldw,
+                               W + c0 + wn * 64 + 2 * l15 + (cc + l4) * (size_t)ldw, ldw, 32 * (kr - kdone));
+        kdone = kr;
+      }
+    }
     double* Cw = M + r0 + wm * 64 + 2 * l15 + (c0 + wn * 64 + 2 * l4) * (size_t)ldm;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
@@ -994,10 +1038,11 @@ rows_fwd_task(int tix, const double* __restrict__ A, int ld, const double* __res
 // tiles of a quarter of the work fill the slots and halve the longest task.  tasks[t] = a | b << 16, a >= b, longest first.
 __global__ void __launch_bounds__(256, 2)
 tile64_wwt_kernel(const double* __restrict__ W, int ldw, double* __restrict__ M, int ldm, int Mt, const int* __restrict__ tasks, int ntask,
-                  int* ticket) {
+                  int* ticket, int* wflags /* non-null: tile flags [row * Mt + column] of a W still in the making */, int* abort_word, int* info) {
   constexpr int KB = 16, SA = 80, BUF = KB * SA;
   __shared__ __attribute__((aligned(16))) double U[4 * BUF];
   __shared__ int sh_tix;
+  __shared__ int sh_kr;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l15 = lane & 15, l4 = lane >> 4, sp = tid & 31, sk = tid >> 5;
   for (int round = 0;; ++round) {
     const int tix = next_ticket(ticket, &sh_tix, round);
@@ -1010,8 +1055,21 @@ tile64_wwt_kernel(const double* __restrict__ W, int ldw, double* __restrict__ M,
     for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[ni][r] = 0.0;
-    wave_tile_gemm(acc, W + r0 + 2 * sp + (ck + sk) * (size_t)ldw, ldw, W + c0 + 2 * sp + (ck + sk) * (size_t)ldw, ldw, 4 * (Mt - ta), U,
-                   U + 2 * BUF, w, l15, l4, sp, sk);
+    if (!wflags) {
+      wave_tile_gemm(acc, W + r0 + 2 * sp + (ck + sk) * (size_t)ldw, ldw, W + c0 + 2 * sp + (ck + sk) * (size_t)ldw, ldw, 4 * (Mt - ta), U,
+                     U + 2 * BUF, w, l15, l4, sp, sk);
+    } else {   // the same sum in the same order, in runs of the tile columns of W that are finished
+      int kdone = ta;
+      while (kdone < Mt) {
+        const int kr = wg_wait_two_rows(wflags + (size_t)ta * Mt, wflags + (size_t)tb * Mt, kdone, Mt, abort_word, info, &sh_kr);
+        if (kr < 0) return;
+        const size_t cc = 64 * (size_t)kdone;
+        wave_tile_gemm(acc, W + r0 + 2 * sp + (cc + sk) * (size_t)ldw, ldw, W + c0 + 2 * sp + (cc + sk) * (size_t)ldw, ldw, 4 * (kr - kdone), U,
+                       U + 2 * BUF, w, l15, l4, sp, sk);
+        __syncthreads();                                  // staging buffers free for the next run
+        kdone = kr;
+      }
+    }
     double* Cw = M + r0 + 16 * w + l15 + (c0 + l4) * (size_t)ldm;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
@@ -1599,7 +1657,7 @@ static void launch_tile128_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a
 // (factor b at Abase + b a_stride with reciprocal pivots dinv_base + b d_stride, W / Minv of matrix b at + b Npad^2;
 // task lists interleaved tile column by tile column like the batched factorisation).  false: not applicable / no memory.
 // phase 0: both launches on c->stream; 1: W = L^-T only (flag buffer fbuf, factorisation flags lflags: gpg_overlap_inverse_trinv);
-// 2: -(W W^T) only (same fbuf).
+// 2: -(W W^T) only (same fbuf); 3: -(W W^T) only, consuming W by its flags while phase 1 is still running (one matrix).
 static bool launch_tile128_inverse_batch(gpg_ctx* c, int B, const double* Abase, size_t a_stride, const double* dinv_base, int d_stride,
                                          double* Wbase, double* Mbase, int* info_base, int phase = 0, int* fbuf = nullptr,
                                          int* lflags = nullptr, int lf_stride = 0) {
@@ -1642,7 +1700,7 @@ static bool launch_tile128_inverse_batch(gpg_ctx* c, int B, const double* Abase,
     fl = c->tile_flags;
   }
   int* ones = fl + per * B;
-  if (phase != 2) {
+  if (phase != 2 && phase != 3) {
     (void)hipMemsetAsync(fl, 0, sizeof(int) * flags_fill(nflag), c->stream);
     (void)hipMemsetD32Async((hipDeviceptr_t)ones, 1, 9, c->stream);
     for (int b = 0; b < B; ++b) gpg_launch_identity(c, Wbase + (size_t)b * w_stride, ldw);
@@ -1656,6 +1714,7 @@ static bool launch_tile128_inverse_batch(gpg_ctx* c, int B, const double* Abase,
                                    B > 1 ? bof1 : nullptr, a_stride, w_stride, d_stride, (int)per, B == 1 ? lflags : nullptr, c->Npad / 64});
     if (phase == 1) return true;
   }
+  const bool wflags_live = phase == 3;   // -(W W^T) of ONE matrix while W = L^-T is still running on the other stream (same tiling, flags in fl)
   if (small && B == 1) {   // one small matrix: -(W W^T) on 64-tiles too (task list cached under its own key)
     const unsigned long long key64 = (3ull << 61) | (1ull << 59) | (unsigned long long)Mt64;
     auto i64 = c->tilemaps.find(key64);
@@ -1670,12 +1729,13 @@ static bool launch_tile128_inverse_batch(gpg_ctx* c, int B, const double* Abase,
       i64 = c->tilemaps.emplace(key64, t64).first;
     }
     hipLaunchKernelGGL(tile64_wwt_kernel, dim3(persistent_grid(c, tile64_wwt_kernel, i64->second.n)), dim3(256), 0, c->stream,
-                       (const double*)Wbase, ldw, Mbase, ldw, Mt64, (const int*)i64->second.dev, i64->second.n, ones + 11);
+                       (const double*)Wbase, ldw, Mbase, ldw, Mt64, (const int*)i64->second.dev, i64->second.n, ones + 11,
+                       wflags_live ? fl : (int*)nullptr, ones + 9, info_base);
     return true;
   }
   hipLaunchKernelGGL(tile128_wwt_kernel, dim3(persistent_grid(c, tile128_wwt_kernel, n2)), dim3(256), 0, c->stream,
                      (const double*)Wbase, ldw, Mbase, ldw, Mt, tasks2, n2, ones + 11, B > 1 ? bof2 : (const int*)nullptr, w_stride,
-                     (const double*)nullptr, 0);
+                     (const double*)nullptr, 0, (wflags_live && !small && B == 1) ? fl : (int*)nullptr, ones + 9, info_base);
   return true;
 }
 
@@ -1844,6 +1904,8 @@ bool gpg_overlap_inverse_trinv(gpg_ctx* c, int B, const double* Abase, size_t a_
 }
 bool gpg_overlap_inverse_wwt(gpg_ctx* c, int B, const double* Abase, size_t a_stride, const double* dinv_base, int d_stride, double* Wbase,
                              double* Mbase, int* info_base) {
+  if (B == 1 && c->overlap_inverse >= 2)   // -(W W^T) too follows W tile column by tile column (its flags), on the main stream
+    return launch_tile128_inverse_batch(c, 1, Abase, a_stride, dinv_base, d_stride, Wbase, Mbase, info_base, 3, c->keep_flags + chol64_nflag(c, 1));
   (void)hipStreamWaitEvent(c->stream, c->ev_trinv, 0);
   return launch_tile128_inverse_batch(c, B, Abase, a_stride, dinv_base, d_stride, Wbase, Mbase, info_base, 2, c->keep_flags + chol64_nflag(c, B));
 }
@@ -1876,7 +1938,8 @@ bool gpg_launch_full_abt(gpg_ctx* c, const double* Sa, const double* Sb, double*
   if (!ensure_tile_flags(c, 16)) return false;
   (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * 16, c->stream);
   hipLaunchKernelGGL(tile128_wwt_kernel, dim3(persistent_grid(c, tile128_wwt_kernel, tm.n)), dim3(256), 0, c->stream, Sa, c->Npad, M,
-                     c->Npad, Mt, (const int*)tm.dev, tm.n, c->tile_flags, (const int*)nullptr, (size_t)0, Sb, 1);
+                     c->Npad, Mt, (const int*)tm.dev, tm.n, c->tile_flags, (const int*)nullptr, (size_t)0, Sb, 1, (int*)nullptr, (int*)nullptr,
+                     (int*)nullptr);
   return true;
 }
 bool gpg_launch_tile128_inverse_batch(gpg_ctx* c, int B, const double* Abase, size_t a_stride, const double* dinv_base, int d_stride,

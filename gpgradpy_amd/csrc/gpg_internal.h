@@ -72,7 +72,7 @@ struct gpg_ctx {
   // value + gradient of ONE small matrix: W = L^-T is launched on the second stream while the factorisation is still running and waits
   // for the factorisation's own diagonal-tile flags (gpg_overlap_inverse_* in cholesky_dataflow.hip).  Both launches keep their flags in
   // keep_flags, which nothing else clears meanwhile.
-  int overlap_inverse = 1;     // 0: off (env GPG_OVERLAP_INVERSE)
+  int overlap_inverse = 2;     // 0: off, 1: W = L^-T behind the factorisation, 2: -(W W^T) behind W as well (env GPG_OVERLAP_INVERSE)
   int* keep_flags = nullptr;
   size_t keep_flags_cap = 0;
   int* chol_flags_override = nullptr;   // launch_tile_chol: use this (large enough) buffer for the next launch and record ev_flags after clearing it

@@ -511,7 +511,7 @@ def test_overlapped_inverse_equals_sequential(monkeypatch):
     for n, d, kernel in ((30, 3, 'SqExp'), (200, 4, 'Ma5f2'), (450, 6, 'SqExp'), (700, 6, 'SqExp')):
         X, f, g = orc.synthetic_design(n, d, seed=n)
         res = {}
-        for mode in ('0', '1'):
+        for mode in ('0', '1', '2'):                               # sequential | W behind L | -(W W^T) behind W as well (the default)
             monkeypatch.setenv('GPG_OVERLAP_INVERSE', mode)
             GP = gpgradpy_amd.GaussianProcess(d, True, kernel, 'precon')
             GP.set_data(X, f, np.full(n, 1e-3), g, np.full((n, d), 1e-2))
@@ -526,5 +526,6 @@ def test_overlapped_inverse_equals_sequential(monkeypatch):
                 assert ln == out[0][0] and np.array_equal(gr, out[0][1])
             res[mode] = out[0]
             GP.close()
-        assert res['0'][0] == res['1'][0]
-        np.testing.assert_array_equal(res['0'][1], res['1'][1])
+        for mode in ('1', '2'):
+            assert res['0'][0] == res[mode][0]
+            np.testing.assert_array_equal(res['0'][1], res[mode][1])
