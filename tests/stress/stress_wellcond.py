@@ -83,7 +83,9 @@ while time.time() < t_end:
     wc = 'precon' if wellcond == 'precon' else 'base'
     GP.calc_lkd_all(hp)                                   # sets _etaK_last for this hp
     r = orc.calc_lkd(Xs, y, hp.theta, kern_o, True, wc, GP._etaK_last, nv, noisy, varK=hp.varK)
-    assert r.ok and abs(adj.ln_lkd - r.ln_lkd) <= 1e-6 * max(1.0, abs(r.ln_lkd)), (kernel, noise, wellcond, n, d, adj.ln_lkd, r.ln_lkd)
+    # (the absolute term: ln_lkd near zero is a difference of terms of size ~N, each good to ~1e-8 at cond ~1e10 -- tests/tolerances.py gives
+    # ln det 2e-6 + 1e-9 N; seed 63 met 1.1e-6 on a value of 0.78)
+    assert r.ok and abs(adj.ln_lkd - r.ln_lkd) <= 1e-6 * max(1.0, abs(r.ln_lkd)) + 4e-6, (kernel, noise, wellcond, n, d, adj.ln_lkd, r.ln_lkd)
     n_checks += 1
     n_cases += 1
     del GP
