@@ -414,7 +414,7 @@ static int gpg_lkd_grad_once(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out, dou
   if (!c->gpartial) GPG_HIP_OK(c, hipMalloc(&c->gpartial, sizeof(double) * (size_t)nval * (nblk + 1)));
   c->zero_info_in_prep = true;
   // small matrix on the dataflow schedule: W = L^-T goes to the second stream right behind the factorisation (cholesky_dataflow.hip)
-  const bool overlap = c->Npad <= 12288 && gpg_overlap_inverse_begin(c, 1);   // (beyond: a failed factorisation should not cost two more sweeps)
+  const bool overlap = c->Npad <= 32768 && gpg_overlap_inverse_begin(c, 1);
   enqueue_lkd(c, hp, 0);                                   // factor + beta + r'K^-1 r + ln det (scal slot 0)
   c->chol_flags_override = nullptr;                        // (consumed by the 64-tile launch; cleared in case another schedule ran)
   if (overlap && !gpg_overlap_inverse_trinv(c, 1, c->A, 0, c->dinv, 0, c->Wfull, c->info)) { c->err = "overlapped inverse: launch refused"; return -2; }
@@ -422,12 +422,13 @@ static int gpg_lkd_grad_once(gpg_ctx* c, const gpg_hp* hp, gpg_lkd_out* out, dou
   // Large matrices: look at the factorisation's info before spending two more N^3/3 sweeps on a failed factor.  Small ones
   // (the sweeps cost less than a host round trip is worth): everything is enqueued at once and judged at the end; the kernels
   // run to completion on whatever a failed factorisation left behind (their waits depend on flags, not on values).
-  const bool one_sync = c->Npad <= 2048 || overlap;
+  const bool one_sync = c->Npad <= 2048 || (overlap && c->Npad <= 12288);
   if (!one_sync) {
     GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
     GPG_HIP_OK(c, hipGetLastError());
     GPG_LAUNCH_OK(c);
     c->h_info[0] = (int)c->h_scal[7];
+    if (c->h_info[0] != 0 && overlap) gpg_overlap_inverse_cancel(c);   // W = L^-T is already running behind the factorisation: make it drain
     if (internal_failure(c, c->h_info, 1)) return -4;
     c->factor_valid = (c->h_info[0] == 0);
     finish_lkd(c, hp, c->h_scal, c->h_info[0], out);

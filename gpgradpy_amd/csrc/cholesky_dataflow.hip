@@ -744,7 +744,17 @@ tile128_trinv_task(int tix, const double* __restrict__ A, int ld, const double* 
   // Overlapped with a 64-tile factorisation (gpg_overlap_inverse_*): column tile ti of W needs the 128 rows 128 ti .. of L up to the
   // diagonal; they are final once the factorisation's diagonal tile (2 ti + 1, 2 ti + 1) is (its task consumed the rest of its row, and the
   // tile row above went the same way before it).
-  if (lflags && !wg_wait_flag(lflags + (size_t)(2 * ti + 1) * lf_mt + (2 * ti + 1), abort_word, info, &sh_ok)) return false;
+  // (lf_mt == 0: the factorisation runs on the same 128 x 128 tiling: its diagonal tile (ti, ti).)  The abort word is looked at FIRST, on
+  // every task: the host raises it when the factorisation it overlaps turns out to have failed (gpg_overlap_inverse_cancel), and the launch
+  // then drains within one task instead of inverting a broken factor.
+  if (lflags) {
+    int* const fl = lf_mt > 0 ? lflags + (size_t)(2 * ti + 1) * lf_mt + (2 * ti + 1) : lflags + (size_t)ti * Mt + ti;
+    if (tid == 0) sh_ok = __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+    __syncthreads();
+    const int go = sh_ok;
+    __syncthreads();
+    if (!go || !wg_wait_flag(fl, abort_word, info, &sh_ok)) return false;
+  }
   if (batch_of) {   // batched launch: the factors of several matrices (restart rows) are inverted by one launch
     const int b = batch_of[tix];
     A += (size_t)b * a_stride;
@@ -1611,13 +1621,20 @@ static void launch_tile128_chol(gpg_ctx* c) {
   const TileMap& tm = get_tile_tasks(c, Mt, Rt, false);
   if (!tm.dev) return;
   const size_t nflag = (size_t)Mt * Rt + 1 + 9 * (size_t)Mt + 8;   // tile flags, abort word, 4 + 4 piece flags and the L21 flag per diagonal tile, ticket words
-  if (!ensure_tile_flags(c, nflag)) return;
-  (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * flags_fill(nflag), c->stream);
+  int* fl = c->chol_flags_override;                        // overlapped inverse (gpg_overlap_inverse_begin): one-shot
+  c->chol_flags_override = nullptr;
+  const bool keep = fl != nullptr;
+  if (!keep) {
+    if (!ensure_tile_flags(c, nflag)) return;
+    fl = c->tile_flags;
+  }
+  (void)hipMemsetAsync(fl, 0, sizeof(int) * flags_fill(nflag), c->stream);
+  if (keep) (void)hipEventRecord(c->ev_flags, c->stream);
   const double m = (double)c->N;
   gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, m * m * m / 3.0);
-  int* abort_word = c->tile_flags + (size_t)Mt * Rt;
+  int* abort_word = fl + (size_t)Mt * Rt;
   hipLaunchKernelGGL(tile128_chol_kernel, dim3(persistent_grid(c, tile128_chol_kernel, tm.n)), dim3(256), 0, c->stream,
-                     TileCholArgs{c->A, c->ld, 0, Mt, tm.dev, tm.n, c->tile_flags, abort_word + 1, abort_word, c->tile_flags + (nflag - 8),
+                     TileCholArgs{c->A, c->ld, 0, Mt, tm.dev, tm.n, fl, abort_word + 1, abort_word, fl + (nflag - 8),
                                   c->dinv, c->info, c->N, nullptr, 0, 0, 0});
   gpg_prof_end(c);
 }
@@ -1711,7 +1728,7 @@ static bool launch_tile128_inverse_batch(gpg_ctx* c, int B, const double* Abase,
     else
       hipLaunchKernelGGL(tile128_trinv_kernel, dim3(persistent_grid(c, tile128_trinv_kernel, tm.n)), dim3(256), 0, c->stream,
                          TrinvArgs{Abase, c->ld, dinv_base, Wbase, ldw, Mt, tasks1, tm.n, fl, ones, ones + 9, ones + 10, info_base,
-                                   B > 1 ? bof1 : nullptr, a_stride, w_stride, d_stride, (int)per, B == 1 ? lflags : nullptr, c->Npad / 64});
+                                   B > 1 ? bof1 : nullptr, a_stride, w_stride, d_stride, (int)per, B == 1 ? lflags : nullptr, lf_stride /* 64-tile columns of the factorisation, 0: 128-tile */});
     if (phase == 1) return true;
   }
   const bool wflags_live = phase == 3;   // -(W W^T) of ONE matrix while W = L^-T is still running on the other stream (same tiling, flags in fl)
@@ -1862,11 +1879,19 @@ void gpg_launch_tile128_chol(gpg_ctx* c) {
 // of W is under way right after tile column j of L.  Progress: both grids are persistent and draw tickets; a W task waits only for
 // factorisation tasks (which never wait for W) and for W tasks with lower tickets, so whichever workgroups the hardware makes resident,
 // the factorisation advances, and behind it the inverse.  Bounded waits and the blocked fallback apply as everywhere.
+static bool single_uses_tile64(const gpg_ctx* c) { return c->tail_cols > 0 && c->Npad <= c->tail_cols; }
 static size_t chol64_per(const gpg_ctx* c) {
   const size_t Mt = c->Npad / 64, Rt = c->ld / 64;
   return Mt * Rt + 1 + 4 * Mt;
 }
-static size_t chol64_nflag(const gpg_ctx* c, int B) { return flags_fill(chol64_per(c) * B + 8); }
+// flag words of the factorisation launch that is overlapped: B matrices on 64-tiles, or ONE matrix on 128-tiles (large matrices)
+static size_t chol64_nflag(const gpg_ctx* c, int B) {
+  if (B == 1 && !single_uses_tile64(c)) {
+    const size_t Mt = c->Npad / 128, Rt = c->ld / 128;
+    return flags_fill(Mt * Rt + 1 + 9 * Mt + 8);
+  }
+  return flags_fill(chol64_per(c) * B + 8);
+}
 // Does a batch of B matrices go to the 128-tile factorisation kernel?  (gpg_launch_tile_chol_batch below decides with this.)
 static bool batch_uses_tile128(const gpg_ctx* c, int B) {
   if (c->tail_cols >= (1 << 30)) return false;
@@ -1875,8 +1900,10 @@ static bool batch_uses_tile128(const gpg_ctx* c, int B) {
 }
 bool gpg_overlap_inverse_begin(gpg_ctx* c, int B) {
   const bool small_inv = c->inv_tile64_cols > 0 && c->Npad <= c->inv_tile64_cols;   // W on 64-tiles; above (one matrix only): on 128-tiles
-  const bool chol64 = B > 1 ? !batch_uses_tile128(c, B) : (c->tail_cols > 0 && c->Npad <= c->tail_cols);
-  if (!c->overlap_inverse || B < 1 || (!small_inv && B > 1) || !chol64 || c->prof_mask != 0 || c->stream_upd == c->stream || !c->stream_upd)
+  // the factorisation must be one of the dataflow launches that take the flag override: B matrices on 64-tiles, one on 64- or 128-tiles
+  // (the 64-tile W reads 64-tile flags: it needs the 64-tile factorisation; the 128-tile W takes either)
+  const bool chol_ok = B > 1 ? !batch_uses_tile128(c, B) : (single_uses_tile64(c) || (c->chol_impl == 1 && !small_inv));
+  if (!c->overlap_inverse || B < 1 || (!small_inv && B > 1) || !chol_ok || c->prof_mask != 0 || c->stream_upd == c->stream || !c->stream_upd)
     return false;
   const size_t Mt64 = c->Npad / 64;
   const size_t need = chol64_nflag(c, B) + flags_fill(Mt64 * Mt64 * B + 16);           // (the 128-tile W needs a quarter of the second term)
@@ -1896,11 +1923,27 @@ bool gpg_overlap_inverse_trinv(gpg_ctx* c, int B, const double* Abase, size_t a_
   hipStream_t main_stream = c->stream;
   (void)hipStreamWaitEvent(c->stream_upd, c->ev_flags, 0);          // the factorisation's flags have been cleared
   c->stream = c->stream_upd;
+  // (last argument: per-matrix stride of the factorisation's flags for the batched 64-tile W; for the 128-tile W of one matrix the number of
+  // 64-tile columns of the factorisation, 0 when it ran on 128-tiles itself)
+  const bool small_inv = c->inv_tile64_cols > 0 && c->Npad <= c->inv_tile64_cols;
+  const int lf = small_inv ? (int)chol64_per(c) : (single_uses_tile64(c) ? c->Npad / 64 : 0);
   const bool ok = launch_tile128_inverse_batch(c, B, Abase, a_stride, dinv_base, d_stride, Wbase, nullptr, info_base, 1,
-                                               c->keep_flags + chol64_nflag(c, B), c->keep_flags, (int)chol64_per(c));
+                                               c->keep_flags + chol64_nflag(c, B), c->keep_flags, lf);
   (void)hipEventRecord(c->ev_trinv, c->stream_upd);
   c->stream = main_stream;
   return ok;
+}
+// The factorisation that W = L^-T overlaps has failed (large matrices: the host reads its info word before going on): raise the abort word
+// of the W launch; its tasks look at it first and the launch drains within one task.  One matrix.
+void gpg_overlap_inverse_cancel(gpg_ctx* c) {
+  const bool small_inv = c->inv_tile64_cols > 0 && c->Npad <= c->inv_tile64_cols;
+  const size_t Mt = small_inv ? c->Npad / 64 : c->Npad / 128;
+  int* ones = c->keep_flags + chol64_nflag(c, 1) + Mt * Mt;                            // layout of launch_tile128_inverse_batch: ... | 9 ones | abort | tickets
+  (void)hipMemsetD32Async((hipDeviceptr_t)(ones + 9), 1, 1, c->stream);
+  // wait until it has drained: workgroups that were inside a dependency wait report the abort through the info word like a timed-out
+  // wait, and the next call clears that word on the main stream -- nothing of this launch may write it afterwards
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipStreamSynchronize(c->stream_upd);
 }
 bool gpg_overlap_inverse_wwt(gpg_ctx* c, int B, const double* Abase, size_t a_stride, const double* dinv_base, int d_stride, double* Wbase,
                              double* Mbase, int* info_base) {

@@ -174,6 +174,7 @@ void gpg_launch_tile128_chol(gpg_ctx* c);
 bool gpg_overlap_inverse_begin(gpg_ctx* c, int B);          // eligible? then the next (batched) factorisation keeps its flags (call before enqueueing it)
 bool gpg_overlap_inverse_trinv(gpg_ctx* c, int B, const double* Abase, size_t a_stride, const double* dinv_base, int d_stride, double* Wbase,
                                int* info_base);             // after the factorisation was enqueued: W = L^-T on the second stream
+void gpg_overlap_inverse_cancel(gpg_ctx* c);                // the overlapped factorisation failed: make the W launch drain
 bool gpg_overlap_inverse_wwt(gpg_ctx* c, int B, const double* Abase, size_t a_stride, const double* dinv_base, int d_stride, double* Wbase,
                              double* Mbase, int* info_base);   // Minv = -W W^T on the main stream, after W
 bool gpg_launch_tile128_inverse(gpg_ctx* c, double* W, double* Minv);   // Minv <- -(L L^T)^-1 by two dataflow launches

@@ -529,3 +529,34 @@ def test_overlapped_inverse_equals_sequential(monkeypatch):
         for mode in ('1', '2'):
             assert res['0'][0] == res[mode][0]
             np.testing.assert_array_equal(res['0'][1], res[mode][1])
+
+
+def test_overlapped_inverse_is_cancelled_when_a_large_factorisation_fails():
+    """Above 12288 columns the host reads the factorisation's info word before it goes on (a failed factor should not cost two more
+    N^3/3 sweeps); W = L^-T is already running on the second stream by then, and is told to drain through its abort word.  The call must
+    report the failure, and the context must work afterwards (same value as the value-only call, gradient against central differences)."""
+    import time
+    import gpgradpy_amd
+    n, d = 1400, 8                                             # N = 12600 -> 12672 padded columns: 128-tile factorisation
+    X, f, g = _design(n, d)[:3]
+    GP = gpgradpy_amd.GaussianProcess(d, True, 'SqExp', 'precon')
+    GP.set_data(X, f, np.zeros(n), g, np.zeros((n, d)))
+    assert GP.n_data > 12288
+    hp_good = GP.make_hp_class(theta=np.full(d, 0.05))
+    info_g, ok = GP.calc_lkd_all(hp_good, calc_grad=True)
+    assert ok and GP.last_factor()[0] == 'tile128'
+    eta = GP._etaK
+    GP._etaK = GP._eta_Kgrad = 0.0
+    hp_bad = GP.make_hp_class(theta=np.full(d, 1e-9))          # all points alike, no nugget: not positive definite in fp64
+    t0 = time.perf_counter()
+    info_b, ok_b = GP.calc_lkd_all(hp_bad, calc_grad=True)
+    t_bad = time.perf_counter() - t0
+    assert not ok_b and info_b.ln_lkd is None
+    GP._etaK = GP._eta_Kgrad = eta
+    t0 = time.perf_counter()
+    info_2, ok2 = GP.calc_lkd_all(hp_good, calc_grad=True)
+    t_good = time.perf_counter() - t0
+    assert ok2 and info_2.ln_lkd == info_g.ln_lkd and np.array_equal(info_2.ln_lkd_grad, info_g.ln_lkd_grad)
+    assert GP.calc_lkd_all(hp_good)[0].ln_lkd == info_g.ln_lkd
+    assert t_bad < 0.8 * t_good, (t_bad, t_good)               # the two inverse sweeps were not run to the end
+    assert GP.factor_fallbacks() == 0
