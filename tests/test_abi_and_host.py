@@ -240,3 +240,19 @@ def test_lanczos_survives_exhausted_krylov_space_and_wide_spectra():
     ev, vec = _tridiag_eigh(np.array([1.0, 2.0, 3.0]), np.array([0.1, 0.2]))          # the largest pair only
     T = np.diag([1.0, 2.0, 3.0]) + np.diag([0.1, 0.2], 1) + np.diag([0.1, 0.2], -1)
     assert np.isclose(ev, np.linalg.eigvalsh(T)[-1], rtol=1e-14) and np.allclose(T @ vec, ev * vec, atol=1e-13)
+
+
+def test_bench_self_launch_starts_ranks_and_propagates_their_exit_code():
+    """`python3 bench.py --gpus 2` with no launcher: the parent starts two rank processes of itself before anything touches
+    the GPU.  Without a GPU every rank stops with bench.py's "no GPU" code 3 -- the parent must hand exactly that back (with a
+    GPU this is tests/test_gpu_dist.py::test_bench_starts_its_own_ranks)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: covered by the GPU test")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "cfg2", "--steps", "2",
+                        "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 3, (r.returncode, r.stderr[-1000:])
+    assert r.stderr.count("no GPU visible") == 2 and "rank(s) failed: [(0, 3), (1, 3)]" in r.stderr

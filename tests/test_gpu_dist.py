@@ -102,6 +102,47 @@ def test_bench_force_dist_runs_the_nccl_branch():
     assert line["value"] > 0
 
 
+def _bench_line(r):
+    assert r.returncode == 0, (r.returncode, r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_starts_its_own_ranks():
+    """`python3 bench.py --gpus 2` with NO launcher and no WORLD_SIZE (the shape of the driver's command): the parent,
+    which never touches the GPU, starts two fresh rank processes of itself, relays rank 0's single JSON line and
+    returns 0.  Two ranks on the box's one GPU, hence gloo; on an 8-GPU node the same code picks nccl (RCCL)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--config", "cfg2",
+                        "--steps", "8", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900)
+    line = _bench_line(r)
+    assert line["n_gpus"] == 2 and line["config"]["collective_backend"] == "gloo"
+    assert line["factor_fallbacks"] == 0
+    assert len(line["per_rank_ms"]) == 2 and line["value"] > 0 and line["steps"] == 8
+
+
+def test_bench_under_torch_distributed_run():
+    """The documented launcher form still works: WORLD_SIZE is set, so bench.py does not spawn anything itself."""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2",
+                        "--backend", "gloo", "--config", "cfg2", "--steps", "8", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900)
+    line = _bench_line(r)
+    assert line["n_gpus"] == 2 and line["factor_fallbacks"] == 0
+
+
+def test_bench_self_launch_reports_a_failing_rank():
+    """A rank that cannot run (nccl with more ranks than GPUs) makes the self-launching parent return non-zero."""
+    import torch
+    ndev = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ndev + 1), "--backend", "nccl",
+                        "--config", "cfg2", "--steps", "2", "--warmup", "0", "--no-cpu-baseline"], capture_output=True,
+                       text=True, env=env, timeout=600)
+    assert r.returncode != 0 and "rank(s) failed" in r.stderr
+
+
 def test_bench_refuses_more_ranks_than_gpus_under_nccl():
     import torch
     ndev = torch.cuda.device_count()
