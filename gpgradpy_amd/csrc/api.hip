@@ -100,7 +100,7 @@ static int check_hp(gpg_ctx* c, const gpg_hp* hp) {
 // Streams and pinned host blocks are the expensive part of creating / destroying a context (~1 ms each on this runtime; the device
 // allocations are ~0.1 ms each), and a Bayesian-optimisation loop makes a new context for every added point: a destroyed context
 // parks them here (per device, a handful at most) and the next gpg_create takes them over.
-struct ParkedHost { int device; hipStream_t stream, stream_upd; double* h_scal; int* h_info; double* h_pin; };
+struct ParkedHost { int device; hipStream_t stream, stream_upd, stream_inv; double* h_scal; int* h_info; double* h_pin; };
 static std::mutex g_park_mutex;
 static std::vector<ParkedHost> g_parked;
 constexpr int kScalSlotsDefault = 64;
@@ -212,17 +212,21 @@ int gpg_create(gpg_ctx** out, int device, int n_eval, int dim, int use_grad, int
     std::lock_guard<std::mutex> lock(g_park_mutex);
     for (size_t k = 0; k < g_parked.size(); ++k)
       if (g_parked[k].device == device) {
-        c->stream = g_parked[k].stream; c->stream_upd = g_parked[k].stream_upd;
+        c->stream = g_parked[k].stream; c->stream_upd = g_parked[k].stream_upd; c->stream_inv = g_parked[k].stream_inv;
         c->h_scal = g_parked[k].h_scal; c->h_info = g_parked[k].h_info; c->h_pin = g_parked[k].h_pin;
         g_parked.erase(g_parked.begin() + k);
         break;
       }
   }
   if (!c->stream) {
-    int prio_lo = 0, prio_hi = 0;
-    CREATE_OK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));   // numerically lowest = highest priority
-    CREATE_OK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_lo));
-    CREATE_OK(hipStreamCreateWithPriority(&c->stream_upd, hipStreamNonBlocking, prio_hi));
+    int prio_least = 0, prio_greatest = 0;
+    CREATE_OK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));   // numerically lowest = highest priority
+    // main stream in the middle of the range (the least priority when the range has two levels only), the look-ahead stream of the
+    // blocked schedule above it, the overlapped inverse -- which only ever WAITS for work of the main stream -- below or level with it
+    const int prio_main = prio_least - (prio_least - prio_greatest) / 2;
+    CREATE_OK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, prio_main));
+    CREATE_OK(hipStreamCreateWithPriority(&c->stream_upd, hipStreamNonBlocking, prio_greatest));
+    CREATE_OK(hipStreamCreateWithPriority(&c->stream_inv, hipStreamNonBlocking, prio_least));
   }
   c->ng = c->use_grad ? n_eval : 0;
   c->A_elems = (size_t)c->ld * c->Npad;
@@ -255,6 +259,7 @@ void gpg_destroy(gpg_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->stream_upd) (void)hipStreamSynchronize(c->stream_upd);
+  if (c->stream_inv) (void)hipStreamSynchronize(c->stream_inv);
   for (auto& pe : c->prof_pending) { (void)hipEventDestroy(pe.e0); (void)hipEventDestroy(pe.e1); }
   for (auto& ev : c->prof_pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
   ws_park(c);
@@ -267,10 +272,10 @@ void gpg_destroy(gpg_ctx* c) {
   if (c->info) (void)hipFree(c->info);
   if (c->gpos) (void)hipFree(c->gpos);
   bool parked = false;
-  if (c->stream && c->stream_upd && c->h_scal && c->h_info && c->scal_slots == kScalSlotsDefault) {
+  if (c->stream && c->stream_upd && c->stream_inv && c->h_scal && c->h_info && c->scal_slots == kScalSlotsDefault) {
     std::lock_guard<std::mutex> lock(g_park_mutex);
     if (g_parked.size() < kParkMax) {
-      g_parked.push_back(ParkedHost{c->device, c->stream, c->stream_upd, c->h_scal, c->h_info, c->h_pin});   // (both streams are idle: synchronised above)
+      g_parked.push_back(ParkedHost{c->device, c->stream, c->stream_upd, c->stream_inv, c->h_scal, c->h_info, c->h_pin});   // (the streams are idle: synchronised above)
       parked = true;
     }
   }
@@ -284,11 +289,13 @@ void gpg_destroy(gpg_ctx* c) {
   for (auto& kv : c->tilemaps) if (kv.second.dev) (void)hipFree(kv.second.dev);
   if (c->ev_flags) (void)hipEventDestroy(c->ev_flags);
   if (c->ev_trinv) (void)hipEventDestroy(c->ev_trinv);
+  if (c->ev_winit) (void)hipEventDestroy(c->ev_winit);
   if (c->keep_flags) (void)hipFree(c->keep_flags);
   for (auto e : c->ev_panel) (void)hipEventDestroy(e);
   for (auto e : c->ev_upd) (void)hipEventDestroy(e);
   if (!parked) {
     if (c->stream_upd) (void)hipStreamDestroy(c->stream_upd);
+    if (c->stream_inv) (void)hipStreamDestroy(c->stream_inv);
     if (c->stream) (void)hipStreamDestroy(c->stream);
   }
   delete c;
@@ -310,6 +317,7 @@ int gpg_set_grad_mask(gpg_ctx* c, const unsigned char* use_grad_pt) {
   c->Npad = ((c->N + GPG_TILE - 1) / GPG_TILE) * GPG_TILE;
   c->ld = c->Npad + c->R;                                        // never exceeds the allocation made for all gradients
   c->have_data = false;
+  c->alpha_valid = false;
   c->factor_valid = c->eval_ready = c->prep_valid = false;
   c->ws[0].factor_valid = c->ws[1].factor_valid = c->ws[0].prep_valid = c->ws[1].prep_valid = false;
   if (c->dense_tmp) { (void)hipFree(c->dense_tmp); c->dense_tmp = nullptr; }
@@ -337,6 +345,7 @@ int gpg_set_data(gpg_ctx* c, const double* x, const double* data_vec, const doub
     GPG_HIP_OK(c, hipStreamSynchronize(c->stream));
   }
   c->have_data = true;
+  c->alpha_valid = false;
   c->factor_valid = c->eval_ready = c->prep_valid = false;
   c->ws[0].factor_valid = c->ws[1].factor_valid = c->ws[0].prep_valid = c->ws[1].prep_valid = false;
   return 0;
@@ -364,6 +373,7 @@ static int internal_failure(gpg_ctx* c, const int* infos, int m) {
   for (int i = 0; i < m; ++i)
     if (infos[i] == GPG_INFO_INTERNAL) {
       c->err = "dataflow Cholesky: a dependency wait timed out (another dataflow launch on this device?)";
+      c->fail_kind = 1;
       c->factor_valid = false;
       if (c->ws_cur == 1) c->eval_ready = false;
       return -4;
@@ -376,6 +386,7 @@ static int internal_failure(gpg_ctx* c, const int* infos, int m) {
 static int solve_failure(gpg_ctx* c) {
   if (*c->h_info != GPG_INFO_INTERNAL) return 0;
   c->err = "dataflow triangular solve: a dependency wait timed out (another dataflow launch on this device?)";
+  c->fail_kind = 2;
   return -4;
 }
 
@@ -522,6 +533,7 @@ static int gpg_lkd_batch_once(gpg_ctx* c, int m, const double* hp_rows, int row_
   if (m < 1 || !hp_rows || !out || row_len < c->d + 3) { c->err = "bad batch arguments (row_len >= d + 3)"; return -1; }
   GPG_HIP_OK(c, hipSetDevice(c->device));
   GPG_WS(c, 0);
+  c->alpha_valid = false;                                  // the vectors of set 0 are redirected / rewritten by the groups
   int rc = ensure_scal(c, m);
   if (rc) return rc;
   if (m > c->items_cap) {
@@ -616,6 +628,7 @@ static int gpg_lkd_grad_batch_once(gpg_ctx* c, int m, const double* hp_rows, int
   if (m < 1 || !hp_rows || !out || !g_aa || !g_inv || row_len < c->d + 3) { c->err = "bad batch arguments (row_len >= d + 3)"; return -1; }
   GPG_HIP_OK(c, hipSetDevice(c->device));
   GPG_WS(c, 0);
+  c->alpha_valid = false;                                  // the vectors of set 0 are redirected / rewritten by the groups
   int rc = ensure_scal(c, m);
   if (rc) return rc;
   if (m > c->items_cap) {
@@ -803,12 +816,41 @@ static int gpg_setup_eval_once(gpg_ctx* c, const gpg_hp* hp, double beta, double
 }
 
 // Dataflow launches that share the GPU with another such launch (another process / context on the same device) can
-// starve each other: every wait inside them is bounded, the launch drains and reports GPG_INFO_INTERNAL.  The call
-// is then repeated once with the blocked schedule, which has no inter-workgroup waits, and the context stays on it
-// (gpg_set_factor_mode re-arms the dataflow schedule; gpg_factor_fallbacks counts the switches).
+// starve each other: every wait inside them is bounded, the launch drains and reports GPG_INFO_INTERNAL (-4 here).  What is
+// repeated, and what the context gives up, depends on WHAT timed out:
+//   * a call that had the inverse W = L^-T overlapped with its factorisation: once more without the overlap (and the context
+//     stops overlapping; gpg_overlap_fallbacks counts) -- the dataflow factorisation and solves stay;
+//   * a dataflow triangular solve (the factor is untouched): once more with the blocked sweeps, which the context keeps for its
+//     solves (gpg_solve_fallbacks counts) -- the dataflow factorisation stays;
+//   * the factorisation itself: once more with the blocked schedule, which has no inter-workgroup waits, and the context stays
+//     on it (gpg_factor_fallbacks counts).
+// gpg_set_factor_mode re-arms all three.  Before anything is repeated every stream of the context is drained: workgroups of a
+// timed-out launch may still be on their way out and write the info word or W.
+static void drain_streams(gpg_ctx* c) {
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->stream_inv) (void)hipStreamSynchronize(c->stream_inv);
+  if (c->stream_upd) (void)hipStreamSynchronize(c->stream_upd);
+  (void)hipGetLastError();
+}
 static int with_fallback(gpg_ctx* c, const std::function<int()>& f) {
+  if (c) { c->overlap_used = false; c->fail_kind = 0; }
   int rc = f();
+  if (rc == -4 && c && c->overlap_used) {
+    drain_streams(c);
+    c->overlap_inverse = 0;
+    c->overlap_fallbacks += 1;
+    c->overlap_used = false; c->fail_kind = 0;
+    rc = f();
+  }
+  if (rc == -4 && c && c->fail_kind == 2 && c->solve_dataflow) {
+    drain_streams(c);
+    c->solve_dataflow = 0;
+    c->solve_fallbacks += 1;
+    c->fail_kind = 0;
+    rc = f();
+  }
   if (rc == -4 && c && (c->chol_impl != 0 || c->tail_cols != 0)) {
+    drain_streams(c);
     c->chol_impl = 0;
     c->tail_cols = 0;
     c->factor_fallbacks += 1;
@@ -835,6 +877,8 @@ int gpg_setup_eval(gpg_ctx* c, const gpg_hp* hp, double beta, double* alpha_out)
   return with_fallback(c, [&] { return gpg_setup_eval_once(c, hp, beta, alpha_out); });
 }
 int gpg_factor_fallbacks(gpg_ctx* c) { return c ? c->factor_fallbacks : -1; }
+int gpg_overlap_fallbacks(gpg_ctx* c) { return c ? c->overlap_fallbacks : -1; }
+int gpg_solve_fallbacks(gpg_ctx* c) { return c ? c->solve_fallbacks : -1; }
 int gpg_last_factor(gpg_ctx* c, int* kernel, int* matrices) {
   if (!c) return -1;
   if (kernel) *kernel = c->last_factor_kernel;
@@ -1345,6 +1389,8 @@ int gpg_set_factor_mode(gpg_ctx* c, int mode) {
     case GPG_FACTOR_TILE128: c->chol_impl = 1; c->tail_cols = 0; break;
     default: c->err = "unknown factor mode"; return -1;
   }
+  c->solve_dataflow = 1;                                    // re-arm what a timed-out wait switched off (with_fallback)
+  if (c->overlap_inverse == 0 && c->overlap_fallbacks > 0) c->overlap_inverse = 2;
   return 0;
 }
 

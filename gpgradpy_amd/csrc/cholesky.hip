@@ -700,7 +700,7 @@ void gpg_cholesky(gpg_ctx* c) {
 // W (rows x Npad, leading dimension ldw, "RHS rows" layout) <- W L^-T using the factor in c->A.
 void gpg_forward_rows(gpg_ctx* c, double* W, int ldw, int rows, int valid) {
   // a few row tiles (posterior evaluation): latency-bound -> one dataflow launch, unless dataflow is switched off
-  if ((c->chol_impl != 0 || c->tail_cols != 0) && gpg_launch_rows_fwd(c, W, ldw, rows, valid)) return;
+  if (gpg_dataflow_solves(c) && gpg_launch_rows_fwd(c, W, ldw, rows, valid)) return;
   const int ld = c->ld, Npad = c->Npad, NB = c->nb_outer;
   const double* A = c->A;
   for (int k0 = 0; k0 < Npad; k0 += NB) {

@@ -1523,6 +1523,7 @@ static int persistent_grid(gpg_ctx* c, K kernel, long ntask) {
     it = c->occupancy.emplace(key, nb).first;
   }
   long cap = (long)it->second * (c->num_cus > 0 ? c->num_cus : 256);
+  if (c->grid_cap > 0 && c->grid_cap < cap) cap = c->grid_cap;                     // overlapped inverse: leaves slots to the launch it waits for
   if (c->max_workgroups > 0 && c->max_workgroups < cap) cap = c->max_workgroups;   // gpg_set_max_workgroups: tests of the progress argument
 #if defined(GPG_NO_PERSIST) || defined(GPG_TICKET_ONESHOT)
   return (int)ntask;
@@ -1721,6 +1722,9 @@ static bool launch_tile128_inverse_batch(gpg_ctx* c, int B, const double* Abase,
     (void)hipMemsetAsync(fl, 0, sizeof(int) * flags_fill(nflag), c->stream);
     (void)hipMemsetD32Async((hipDeviceptr_t)ones, 1, 9, c->stream);
     for (int b = 0; b < B; ++b) gpg_launch_identity(c, Wbase + (size_t)b * w_stride, ldw);
+    // overlapped inverse: from here on W's flags, abort word, tickets and identity are in place -- what -(W W^T) on the main stream,
+    // launched while this stream is still busy (phase 3), must not start before
+    if (phase == 1 && c->ev_winit) (void)hipEventRecord(c->ev_winit, c->stream);
     if (small)
       hipLaunchKernelGGL(tile64_trinv_kernel, dim3(persistent_grid(c, tile64_trinv_kernel, tm.n)), dim3(256), 0, c->stream,
                          Trinv64Args{Abase, c->ld, dinv_base, Wbase, ldw, Mt64, tasks1, tm.n, fl, ones + 9, ones + 10, info_base,
@@ -1874,11 +1878,13 @@ void gpg_launch_tile128_chol(gpg_ctx* c) {
 }
 // ---- value + gradient of ONE small matrix: W = L^-T overlapped with the factorisation ------------------------------------------------
 // The two chains (factorisation: one diagonal tile after the other; W = L^-T: one tile column after the other) are each latency-bound on
-// a small matrix and most of the chip idles through both.  The inverse's first launch goes to the context's second (lower-priority)
-// stream as soon as the factorisation has been enqueued; its tasks wait for the factorisation's diagonal-tile flags, so column tile j
-// of W is under way right after tile column j of L.  Progress: both grids are persistent and draw tickets; a W task waits only for
-// factorisation tasks (which never wait for W) and for W tasks with lower tickets, so whichever workgroups the hardware makes resident,
-// the factorisation advances, and behind it the inverse.  Bounded waits and the blocked fallback apply as everywhere.
+// a small matrix and most of the chip idles through both.  The inverse's first launch goes to the context's lowest-priority stream
+// (gpg_ctx::stream_inv) as soon as the factorisation has been enqueued; its tasks wait for the factorisation's diagonal-tile flags, so
+// column tile j of W is under way right after tile column j of L.  Progress: both grids are persistent and draw tickets; a W task waits
+// only for factorisation tasks (which never wait for W) and for W tasks with lower tickets.  The W launch becomes runnable as soon as
+// the factorisation's flags have been cleared -- possibly BEFORE the factorisation kernel is resident -- so its grid is capped at half
+// the co-resident capacity (gpg_ctx::grid_cap): whatever the dispatch order, the factorisation finds free slots, advances, and behind
+// it the inverse.  Bounded waits apply as everywhere; a timeout here repeats the call once without the overlap (api.hip).
 static bool single_uses_tile64(const gpg_ctx* c) { return c->tail_cols > 0 && c->Npad <= c->tail_cols; }
 static size_t chol64_per(const gpg_ctx* c) {
   const size_t Mt = c->Npad / 64, Rt = c->ld / 64;
@@ -1903,7 +1909,7 @@ bool gpg_overlap_inverse_begin(gpg_ctx* c, int B) {
   // the factorisation must be one of the dataflow launches that take the flag override: B matrices on 64-tiles, one on 64- or 128-tiles
   // (the 64-tile W reads 64-tile flags: it needs the 64-tile factorisation; the 128-tile W takes either)
   const bool chol_ok = B > 1 ? !batch_uses_tile128(c, B) : (single_uses_tile64(c) || (c->chol_impl == 1 && !small_inv));
-  if (!c->overlap_inverse || B < 1 || (!small_inv && B > 1) || !chol_ok || c->prof_mask != 0 || c->stream_upd == c->stream || !c->stream_upd)
+  if (!c->overlap_inverse || B < 1 || (!small_inv && B > 1) || !chol_ok || c->prof_mask != 0 || c->stream_inv == c->stream || !c->stream_inv)
     return false;
   const size_t Mt64 = c->Npad / 64;
   const size_t need = chol64_nflag(c, B) + flags_fill(Mt64 * Mt64 * B + 16);           // (the 128-tile W needs a quarter of the second term)
@@ -1915,22 +1921,26 @@ bool gpg_overlap_inverse_begin(gpg_ctx* c, int B) {
   }
   if (!c->ev_flags && hipEventCreateWithFlags(&c->ev_flags, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
   if (!c->ev_trinv && hipEventCreateWithFlags(&c->ev_trinv, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (!c->ev_winit && hipEventCreateWithFlags(&c->ev_winit, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
   c->chol_flags_override = c->keep_flags;
   return true;
 }
 bool gpg_overlap_inverse_trinv(gpg_ctx* c, int B, const double* Abase, size_t a_stride, const double* dinv_base, int d_stride, double* Wbase,
                                int* info_base) {
   hipStream_t main_stream = c->stream;
-  (void)hipStreamWaitEvent(c->stream_upd, c->ev_flags, 0);          // the factorisation's flags have been cleared
-  c->stream = c->stream_upd;
+  (void)hipStreamWaitEvent(c->stream_inv, c->ev_flags, 0);          // the factorisation's flags have been cleared
+  c->stream = c->stream_inv;
+  c->grid_cap = c->num_cus > 0 ? c->num_cus : 256;                 // one workgroup per compute unit: half of the two-per-CU capacity
+  c->overlap_used = true;
   // (last argument: per-matrix stride of the factorisation's flags for the batched 64-tile W; for the 128-tile W of one matrix the number of
   // 64-tile columns of the factorisation, 0 when it ran on 128-tiles itself)
   const bool small_inv = c->inv_tile64_cols > 0 && c->Npad <= c->inv_tile64_cols;
   const int lf = small_inv ? (int)chol64_per(c) : (single_uses_tile64(c) ? c->Npad / 64 : 0);
   const bool ok = launch_tile128_inverse_batch(c, B, Abase, a_stride, dinv_base, d_stride, Wbase, nullptr, info_base, 1,
                                                c->keep_flags + chol64_nflag(c, B), c->keep_flags, lf);
-  (void)hipEventRecord(c->ev_trinv, c->stream_upd);
+  (void)hipEventRecord(c->ev_trinv, c->stream_inv);
   c->stream = main_stream;
+  c->grid_cap = 0;
   return ok;
 }
 // The factorisation that W = L^-T overlaps has failed (large matrices: the host reads its info word before going on): raise the abort word
@@ -1943,12 +1953,16 @@ void gpg_overlap_inverse_cancel(gpg_ctx* c) {
   // wait until it has drained: workgroups that were inside a dependency wait report the abort through the info word like a timed-out
   // wait, and the next call clears that word on the main stream -- nothing of this launch may write it afterwards
   (void)hipStreamSynchronize(c->stream);
-  (void)hipStreamSynchronize(c->stream_upd);
+  (void)hipStreamSynchronize(c->stream_inv);
 }
 bool gpg_overlap_inverse_wwt(gpg_ctx* c, int B, const double* Abase, size_t a_stride, const double* dinv_base, int d_stride, double* Wbase,
                              double* Mbase, int* info_base) {
-  if (B == 1 && c->overlap_inverse >= 2)   // -(W W^T) too follows W tile column by tile column (its flags), on the main stream
+  if (B == 1 && c->overlap_inverse >= 2) {   // -(W W^T) too follows W tile column by tile column (its flags), on the main stream
+    // ... but not before W's flags / abort word / tickets have been cleared and W set to the identity on the other stream: keep_flags is
+    // reused across calls, its stale content reads "every tile of W is done"
+    (void)hipStreamWaitEvent(c->stream, c->ev_winit, 0);
     return launch_tile128_inverse_batch(c, 1, Abase, a_stride, dinv_base, d_stride, Wbase, Mbase, info_base, 3, c->keep_flags + chol64_nflag(c, 1));
+  }
   (void)hipStreamWaitEvent(c->stream, c->ev_trinv, 0);
   return launch_tile128_inverse_batch(c, B, Abase, a_stride, dinv_base, d_stride, Wbase, Mbase, info_base, 2, c->keep_flags + chol64_nflag(c, B));
 }

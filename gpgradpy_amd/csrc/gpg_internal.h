@@ -47,7 +47,8 @@ struct gpg_ws {
 struct gpg_ctx {
   int device = 0;
   hipStream_t stream = nullptr;      // main stream
-  hipStream_t stream_upd = nullptr;  // high-priority stream: look-ahead factorisation of the next diagonal block
+  hipStream_t stream_upd = nullptr;  // high-priority stream: look-ahead factorisation of the next diagonal block (blocked schedule)
+  hipStream_t stream_inv = nullptr;  // LOWEST-priority stream: the overlapped inverse W = L^-T, which waits for the factorisation on `stream`
   int lookahead = 1;
   int gemm_impl = 1;                 // 1: LDS-DMA ring kernel for the 128x128 updates, 0: register-staged kernel (A/B runs)
   std::vector<hipEvent_t> ev_panel, ev_upd;
@@ -77,6 +78,13 @@ struct gpg_ctx {
   size_t keep_flags_cap = 0;
   int* chol_flags_override = nullptr;   // launch_tile_chol: use this (large enough) buffer for the next launch and record ev_flags after clearing it
   hipEvent_t ev_flags = nullptr, ev_trinv = nullptr;
+  hipEvent_t ev_winit = nullptr;   // recorded on stream_inv after W's flags / abort word / tickets / identity are set and before its kernel starts
+  int grid_cap = 0;            // > 0: cap on the next persistent launches' grids (overlapped inverse: never every co-resident slot)
+  int overlap_fallbacks = 0;   // times a call with the overlapped inverse timed out and was repeated without the overlap
+  bool overlap_used = false;   // the call in progress launched the overlapped inverse
+  int fail_kind = 0;           // what the last -4 came from: 1 factorisation (or unknown), 2 a dataflow triangular solve
+  int solve_dataflow = 1;      // triangular solves as dataflow launches (0 after one of them timed out: blocked sweeps)
+  int solve_fallbacks = 0;
   int num_cus = 0;             // compute units of the device (grid of the persistent launches)
   bool alpha_valid = false;    // zvec of workspace set 0 holds p * alpha of the last gpg_lkd_grad (gpg_lkd_alpha)
   bool zero_info_in_prep = false;    // the next gpg_launch_prep also clears *c->info (consumed by it)
@@ -171,6 +179,8 @@ void gpg_launch_tile_chol(gpg_ctx* c, int c0);                          // dataf
 void gpg_launch_tile128_chol(gpg_ctx* c);
 // dataflow W <- W L^-T / Z <- Z L^-1 for a few 64-row tiles; rows >= valid must be zero (their substitution is skipped);
 // false: not applicable (caller falls back on the blocked sweep)
+// triangular solves as dataflow launches?  (off with the blocked factor mode, and after one of them timed out: api.hip with_fallback)
+static inline bool gpg_dataflow_solves(const gpg_ctx* c) { return c->solve_dataflow != 0 && (c->chol_impl != 0 || c->tail_cols != 0); }
 bool gpg_overlap_inverse_begin(gpg_ctx* c, int B);          // eligible? then the next (batched) factorisation keeps its flags (call before enqueueing it)
 bool gpg_overlap_inverse_trinv(gpg_ctx* c, int B, const double* Abase, size_t a_stride, const double* dinv_base, int d_stride, double* Wbase,
                                int* info_base);             // after the factorisation was enqueued: W = L^-T on the second stream

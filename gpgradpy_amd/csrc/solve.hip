@@ -555,7 +555,7 @@ void gpg_launch_lkd_reduce_batch(gpg_ctx* c, int slot0, int B, size_t v_stride, 
 
 void gpg_backward_solve(gpg_ctx* c) {
   const int Npad = c->Npad;
-  if (c->chol_impl != 0 || c->tail_cols != 0) {
+  if (gpg_dataflow_solves(c)) {
     // the vector rides as row 0 of a zeroed 64-row tile through the dataflow backward solve (one launch instead of
     // 2 Npad / 64 dependent ones)
     if (!c->vec_rows) (void)gpg_dev_alloc(c, &c->vec_rows, sizeof(double) * 64 * (size_t)c->vec_rows_cols);
@@ -582,7 +582,7 @@ void gpg_backward_solve(gpg_ctx* c) {
 void gpg_backward_rows(gpg_ctx* c, double* Z, int ldz, int nrhs, double* tbuf) {
   // one dataflow launch over the 64-row tiles that hold the nrhs rows (the other rows of a tile ride along)
   const int rows = ((nrhs + 63) / 64) * 64;
-  if (c->chol_impl != 0 || c->tail_cols != 0) {
+  if (gpg_dataflow_solves(c)) {
     if (gpg_launch_rows_bwd(c, Z, ldz, rows, nrhs)) return;
     // more row tiles than one dataflow launch takes: one launch per group of row tiles (rows are the fast index of Z)
     const int chunk = (c->rows_max_tasks / (c->Npad / 64)) * 64;
@@ -665,7 +665,7 @@ int gpg_factor_apply_dev(gpg_ctx* c, int op, double* v, double* out) {
   if (!c->vec_rows && !gpg_dev_alloc(c, &c->vec_rows, sizeof(double) * 64 * (size_t)c->vec_rows_cols)) return -2;
   hipLaunchKernelGGL(vec_rows_load_kernel, dim3((unsigned)((64 * (size_t)Npad + 255) / 256)), dim3(256), 0, c->stream, c->vec_rows, v, 1,
                      Npad);                                                       // row 0 of the carrier <- v
-  if (c->chol_impl != 0 || c->tail_cols != 0) {
+  if (gpg_dataflow_solves(c)) {
     if (!gpg_launch_rows_fwd(c, c->vec_rows, 64, 64, 1) || !gpg_launch_rows_bwd(c, c->vec_rows, 64, 64, 1)) return -2;
   } else {
     gpg_forward_rows(c, c->vec_rows, 64, 64, 1);

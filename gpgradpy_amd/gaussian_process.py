@@ -1366,6 +1366,14 @@ class GaussianProcess(HparaOptz):
         repeated with the blocked schedule; the context stays on 'blocked' until set_factor_mode is called."""
         return int(self._lib.gpg_factor_fallbacks(self._ctx)) if self._ctx else 0
 
+    def overlap_fallbacks(self):
+        """How often a value + gradient call with the overlapped inverse timed out and was repeated without the overlap."""
+        return int(self._lib.gpg_overlap_fallbacks(self._ctx)) if self._ctx else 0
+
+    def solve_fallbacks(self):
+        """How often a dataflow triangular solve timed out and the call was repeated with the blocked sweeps."""
+        return int(self._lib.gpg_solve_fallbacks(self._ctx)) if self._ctx else 0
+
     def _lkd_grad_central_differences(self, hp_vals, rel_step=1e-4):
         """d ln_lkd / d hp_k for the optimised hyperparameters (hp_info_optz_lkd order, derivatives with respect to the
         hyperparameter VALUES like CalcLkd.py:170-177, not their log10) by central differences of the device likelihood;

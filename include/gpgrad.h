@@ -298,6 +298,12 @@ int gpg_set_factor_mode(gpg_ctx* ctx, int mode);
  * blocked schedule and keeps the context on it until gpg_set_factor_mode is called again.  Returns how often that
  * happened (results are unaffected; rc -4 is only returned if the blocked repeat fails too). */
 int gpg_factor_fallbacks(gpg_ctx* ctx);
+/* The same bounded waits guard the overlapped inverse of gpg_lkd_grad / gpg_lkd_grad_batch (W = L^-T launched behind the
+ * factorisation it waits for) and the dataflow triangular solves.  A timeout there does NOT cost the dataflow factorisation:
+ * the call is repeated once without the overlap (the context stops overlapping), respectively with the blocked solve sweeps
+ * (the context keeps them for its solves), until gpg_set_factor_mode re-arms both.  These return how often each happened. */
+int gpg_overlap_fallbacks(gpg_ctx* ctx);
+int gpg_solve_fallbacks(gpg_ctx* ctx);
 /* Schedule of the most recent factorisation launch (for logs / bench): *kernel = 0 blocked, 1 dataflow with 64 x 64
  * tiles, 2 dataflow with 128 x 128 tiles; *matrices = how many matrices that launch factorised.  Either may be NULL. */
 int gpg_last_factor(gpg_ctx* ctx, int* kernel, int* matrices);
