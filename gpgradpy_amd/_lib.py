@@ -9,6 +9,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgpgrad_hip.so")
+if os.environ.get("GPG_LIB"):   # A/B measurements only (tools/build_variant.sh): another build of the SAME HIP library
+    LIB_PATH = os.path.join(_HERE, os.path.basename(os.environ["GPG_LIB"]))
 
 GPG_KERNEL = {"SqExp": 0, "Ma5f2": 1, "RatQu": 2}
 GPG_WELLCOND = {"base": 0, "precon": 1}

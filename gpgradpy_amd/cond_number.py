@@ -33,56 +33,73 @@ def _tridiag_eigh(alpha, beta):
     return ev[-1], evec[:, -1]
 
 
-def lanczos_largest(apply, n, k_max=120, rtol=1e-9, seed=0, want_vector=False):
+def lanczos_largest(apply, n, k_max=120, rtol=1e-9, seed=0, want_vector=False, k_cap=None, max_restarts=12):
     """Largest eigenvalue (and, on request, its unit eigenvector) of the symmetric positive definite operator
-    `apply` (n -> n)."""
-    k_max = min(k_max, n)
-    Q = np.zeros((k_max + 1, n))
-    q = np.random.default_rng(seed).standard_normal(n)
-    Q[0] = q / np.linalg.norm(q)
-    alpha, beta = [], []
-    theta = np.nan
-    ritz = None
-    hist = []
+    `apply` (n -> n).
 
-    def done(theta, ritz, j):
+    The Krylov basis starts with room for `k_max` vectors and GROWS (doubling, up to `k_cap`, default 8 k_max) while the
+    largest Ritz pair has not met its residual bound; when the cap is reached the iteration RESTARTS from the Ritz vector
+    (the Rayleigh quotient of the new start vector is the Ritz value reached so far, so the estimate never falls back),
+    up to `max_restarts` times.  Only if all of that is exhausted the value is returned with a LanczosNotConverged warning
+    (it is a lower bound then) -- the reference stores np.linalg.cond, an exact value, in this place (Kernel.py:239-245)."""
+    k_max = max(1, min(k_max, n))
+    k_cap = n if k_cap is None and 8 * k_max >= n else min(n, k_cap or 8 * k_max)
+    k_cap = max(k_cap, k_max)
+    q0 = np.random.default_rng(seed).standard_normal(n)
+    theta, ritz, Q, res = np.nan, None, None, np.inf
+
+    def done(theta, ritz, Q):
         if not want_vector:
             return theta
         v = Q[0].copy() if ritz is None else Q[:len(ritz)].T @ ritz
         return theta, v / np.linalg.norm(v)
-    for j in range(k_max):
-        w = apply(Q[j])
-        a = float(Q[j] @ w)
-        alpha.append(a)
-        w = w - a * Q[j] - (beta[-1] * Q[j - 1] if j > 0 else 0.0)
-        for _ in range(2):                                   # full reorthogonalisation, twice
-            w -= Q[:j + 1].T @ (Q[:j + 1] @ w)
-        b = float(np.linalg.norm(w))
-        if j >= 1 and (j < 24 or j % 4 == 3 or j + 1 >= k_max):      # the convergence tests: every step at first, then every fourth
-            theta, ritz = _tridiag_eigh(np.array(alpha), np.array(beta))
-            if b * abs(ritz[-1]) <= rtol * abs(theta):       # residual bound of the largest Ritz pair
-                return done(theta, ritz, j)
-            # a cluster at the top of the spectrum (K^-1 of a matrix whose small eigenvalues sit on the nugget): the residual of ONE
-            # Ritz vector stays large while the Ritz VALUE -- second order in that residual -- has long settled; any vector of the
-            # cluster's invariant subspace serves the gradient formula as well as the one a dense eigensolver would pick
-            old = [t for (jj, t) in hist if jj <= j - 6]
-            hist.append((j, theta))
-            if j >= 12 and old and abs(theta - old[-1]) <= 1e-13 * abs(theta):
-                return done(theta, ritz, j)
-        elif j == 0:
-            theta = a
-        if b <= 1e-300 or b <= 4e-16 * abs(theta) or not np.isfinite(b):   # invariant subspace (what is left of w is rounding): the Ritz
-            return done(theta, ritz, j)                                      # values are exact; nothing to normalise a next vector from
-        if j + 1 >= k_max:
-            if k_max < n:                                    # (k_max = n is the full Krylov space: exact up to rounding)
-                res = b * abs(ritz[-1]) / abs(theta) if ritz is not None else np.inf
-                warnings.warn(f'Lanczos: largest Ritz value not converged after {k_max} steps '
-                              f'(relative residual bound {res:.2e} > {rtol:.1e}); the condition number is a lower bound',
-                              LanczosNotConverged, stacklevel=2)
-            return done(theta, ritz, j)
-        beta.append(b)
-        Q[j + 1] = w / b
-    return done(theta, ritz, k_max)
+
+    for restart in range(max_restarts + 1):
+        rows = k_max + 1
+        Q = np.zeros((rows, n))
+        Q[0] = q0 / np.linalg.norm(q0)
+        alpha, beta, hist = [], [], []
+        ritz = None
+        for j in range(k_cap):
+            w = apply(Q[j])
+            a = float(Q[j] @ w)
+            alpha.append(a)
+            w = w - a * Q[j] - (beta[-1] * Q[j - 1] if j > 0 else 0.0)
+            for _ in range(2):                                   # full reorthogonalisation, twice
+                w -= Q[:j + 1].T @ (Q[:j + 1] @ w)
+            b = float(np.linalg.norm(w))
+            if j >= 1 and (j < 24 or j % 4 == 3 or j + 1 >= k_cap):      # the convergence tests: every step at first, then every fourth
+                theta, ritz = _tridiag_eigh(np.array(alpha), np.array(beta))
+                res = b * abs(ritz[-1]) / abs(theta)
+                if res <= rtol:                                  # residual bound of the largest Ritz pair
+                    return done(theta, ritz, Q)
+                # a cluster at the top of the spectrum (K^-1 of a matrix whose small eigenvalues sit on the nugget): the residual of ONE
+                # Ritz vector stays large while the Ritz VALUE -- second order in that residual -- has long settled; any vector of the
+                # cluster's invariant subspace serves the gradient formula as well as the one a dense eigensolver would pick
+                old = [t for (jj, t) in hist if jj <= j - 6]
+                hist.append((j, theta))
+                if j >= 12 and old and abs(theta - old[-1]) <= 1e-13 * abs(theta):
+                    return done(theta, ritz, Q)
+            elif j == 0:
+                theta = a
+            if b <= 1e-300 or b <= 4e-16 * abs(theta) or not np.isfinite(b):   # invariant subspace (what is left of w is rounding): the Ritz
+                return done(theta, ritz, Q)                                      # values are exact; nothing to normalise a next vector from
+            if j + 1 >= k_cap:
+                break
+            if j + 2 > rows:                                     # grow the basis
+                rows = min(k_cap + 1, 2 * rows)
+                Q = np.vstack((Q, np.zeros((rows - Q.shape[0], n))))
+            beta.append(b)
+            Q[j + 1] = w / b
+        if k_cap >= n:                                           # the full Krylov space: exact up to rounding
+            return done(theta, ritz, Q)
+        if ritz is None:
+            break
+        q0 = Q[:len(ritz)].T @ ritz                              # restart from the Ritz vector
+    warnings.warn(f'Lanczos: largest Ritz value not converged after {max_restarts + 1} runs of {k_cap} steps '
+                  f'(relative residual bound {res:.2e} > {rtol:.1e}); the condition number is a lower bound',
+                  LanczosNotConverged, stacklevel=2)
+    return done(theta, ritz, Q)
 
 
 def cond_from_factor(apply_mat, apply_inv, n, want_vectors=False):

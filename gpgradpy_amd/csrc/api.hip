@@ -195,6 +195,7 @@ int gpg_create(gpg_ctx** out, int device, int n_eval, int dim, int use_grad, int
   // matrices (shorter dependency chain), 128-tile kernel above; chol_impl 0 = blocked right-looking (A/B runs)
   c->chol_impl = 1;
   if (const char* e = getenv("GPG_OVERLAP_INVERSE")) c->overlap_inverse = atoi(e);   // diagnostic override (A/B runs)
+  if (const char* e = getenv("GPG_PAIR")) c->pair_mode = atoi(e);                    // diagnostic override (A/B runs)
   if (const char* e = getenv("GPG_ROWS_MAX_TASKS")) { const int v = atoi(e); if (v >= 64) c->rows_max_tasks = v; }   // diagnostic override
   c->tail_cols = 12288;
 #define CREATE_OK(call)                                                              \

@@ -161,9 +161,13 @@ __device__ __forceinline__ int potrf64_wave(const double* src, int sld, double (
 // in the one-wave version) -- and all but the last four of them run AHEAD, during the pivot chain of the previous sub-block (waves
 // 1 .. 3 are idle then): what stays between two pivot phases is a rank-16 update.  Two workgroup barriers per sub-block; the return
 // value is that of wave 0 (other waves return 0).
+// tid_in: index of the calling thread inside its 256-thread team (default: threadIdx.x; the pair kernel runs two teams per workgroup,
+// whose barriers -- __syncthreads, all 512 threads -- coincide because both teams execute the same sequence).
 __device__ __forceinline__ int potrf64_wg(const double* src, int sld, double (*St)[64], double* __restrict__ blk, int ld,
-                                          double* __restrict__ dinv, int* piece_flags = nullptr) {
-  const int w = threadIdx.x >> 6, i = threadIdx.x & 63, l15 = i & 15, l4 = i >> 4;
+                                          double* __restrict__ dinv, int* piece_flags = nullptr, int tid_in = -1) {
+  const int tid_team = tid_in < 0 ? (int)threadIdx.x : tid_in;
+  const int w = __builtin_amdgcn_readfirstlane(tid_team >> 6);   // wave-uniform by construction; said so, or the wave roles below become divergent branches
+  const int i = tid_team & 63, l15 = i & 15, l4 = i >> 4;
   int bad = 0;
   double myinv = 0.0;
   d4 pre;                                                  // tile R = w of the NEXT sub-block's panel, updated with every sub-block before the current one
@@ -315,6 +319,11 @@ __device__ __forceinline__ void wave_tile_gemm(d4 (&acc)[4], const double* ga, i
 #undef GPG_PS_COMPUTE
 }
 
+// (Round 3 tried column steps on the UNSCALED row against a column-scaled image -- y_m -= y_j (L_mj / L_jj), reciprocal pivots applied
+// once per piece: two dependent hops per column instead of five.  tools/subst_probe: the 64 column steps of a block cost 211 cycles
+// each either way -- the steps are bound by their ~21 fp64 instructions at ~10 cycles, not by the chain -- and beside an MFMA wave they
+// cost the same while the MFMA wave drops from 64 to 96 cycles per instruction.  +2 % for one chain-bound 64-tile matrix, -2 % for
+// batched 128-tile launches (one more FMA per row and step), and the two kernels would no longer agree bit for bit: not adopted.)
 // quad-row substitution x <- x L^-T of one matrix row spread over a lane quad (see trsm64_kernel): x[m] is
 // column 4m + q; Ls is the LDS image Ls[j][q][m] = L[4m + q][j], sdinv the reciprocal pivots.
 #define GPG_QUAD_SUBST(x, Ls, sdinv, q)                                                      \
@@ -522,13 +531,14 @@ __device__ unsigned long long* g_stamp_buf;
 // current diagonal block.  Ends with a workgroup barrier.
 __device__ __forceinline__ void panel_solve_rows64(const double* __restrict__ L, int ldl, const double* __restrict__ dinv,
                                                    double* X, int ldx, int rows, int nb, double* U, double (*Ls)[4][18],
-                                                   double* sdinv) {
+                                                   double* sdinv, int tid_in = -1) {
   constexpr int KB = 16, SA = 80;                     // SA: +128 B pad keeps ds_read_b64 conflict-free
   constexpr int BUF = KB * SA;                        // doubles per staging buffer
   double* const sA = U;
   double* const sB = U + 2 * BUF;
 
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = tid_in < 0 ? (int)threadIdx.x : tid_in, lane = tid & 63;   // thread inside its 256-thread team
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, l4 = lane >> 4;
   // MFMA-side row of this lane, substitution-side row of this lane (both inside the wave's 16 rows)
   int rowc = 16 * w + l15;
@@ -653,63 +663,110 @@ __device__ __forceinline__ int wg_wait_flag(int* flag, int* abort_word, int* inf
 // straight in the quad layout; block 1 first takes its update X1 L21^T on MFMA (two 64-row passes through
 // the LDS tile).  U: 4 * 16 * 80 doubles, Ls / sdinv: diagonal-block image.  Ends with a workgroup barrier.
 
-// direct_tile_gemm_x2: the MFMA loop of gemm_direct_kernel as a device function, with 16-byte fragment loads:
-// acc (wave tile 64 x 64) -= A[64 x 4 nstep] B[64 x 4 nstep]^T, operand fragments straight from global memory,
-// PF k-steps ahead, no LDS, no barrier; nstep a positive multiple of PF + 1.  Lane lane&15 = t owns the two
-// adjacent rows 2t, 2t+1 of each 32-row group of its 64-row slices, so one global_load_dwordx4 feeds two MFMA
-// operand blocks: 4 load instructions per k-step instead of 8 (the texture-address unit handles ~4 lanes per
-// clock whatever the access width; measured +1.5 %).  acc[2p + e][2g + m][r] of lane (t, l4) <-> tile row 32 g + 2 t + m, tile column
-// 32 p + 2 (4 r + l4) + e.  pa / pb: slice + 2 t, k = l4.
-typedef double gpg_d2v __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ double2 gpg_nt_load2(const double* p) {
-  const gpg_d2v v = __builtin_nontemporal_load(reinterpret_cast<const gpg_d2v*>(p));
-  double2 r; r.x = v.x; r.y = v.y; return r;
+// direct_tile_gemm_acc: the MFMA loop of the dataflow kernels, operand fragments straight from global memory:
+// acc (wave tile 64 x 64) += A[64 x 4 nstep] B[64 x 4 nstep]^T, PF k-steps ahead, no LDS; nstep a positive multiple of UN.
+// Lane lane&15 = t owns the two adjacent rows 2t, 2t+1 of each 32-row group of its 64-row slices, so one global_load_dwordx4 feeds two
+// MFMA operand blocks: 4 load instructions per k-step.  acc[2p + e][2g + m][r] of lane (t, l4) <-> tile row 32 g + 2 t + m, tile column
+// 32 p + 2 (4 r + l4) + e.
+// Round 3: the loop body is MFMA + loads + scalar arithmetic only.
+//  * The SIGN lives outside: callers that need C - A B^T negate their accumulators once before and once after the loop instead of
+//    negating the A fragments of every k-step (a v_xor + v_mov per fragment: 8 VALU instructions per 16 MFMAs).  -(fma(a, b, -c)) and
+//    fma(-a, b, c) round identically (round-to-nearest is symmetric), so every result keeps its bits.
+//  * The operand ADDRESSES are a wave-uniform base (ua / ub, advanced by scalar adds) plus a constant 32-bit lane offset (la / lb,
+//    bytes): global_load ... v_off, s[base] instead of two 64-bit VALU pointer increments per k-step.
+// VALU instructions of one wave take issue slots from the MFMAs of BOTH waves of its SIMD (tools/subst_probe: a wave of fp64 VALU work
+// slows its SIMD partner's MFMA stream from 64 to 96 cycles per instruction).
+#ifndef GPG_KSYNC
+#define GPG_KSYNC 16       // k-steps between two workgroup barriers inside the MFMA loop (0: none; a multiple of PF + 1)
+#endif
+// the barriers of direct_tile_gemm_acc<PF, MI, KS> over nstep k-steps, for a wave that has no MFMA work in this run
+template <int PF, int KS = GPG_KSYNC>
+__device__ __forceinline__ void direct_tile_sync_only(int nstep) {
+  if (KS > 0)
+    for (int s0 = 0; s0 < nstep; s0 += (KS > 0 ? KS : 1)) __builtin_amdgcn_s_barrier();
+}
+// acc <- -acc (before and after a run of direct_tile_gemm_acc that is to SUBTRACT the product)
+__device__ __forceinline__ void direct_tile_negate(d4 (&acc)[4][4]) {
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[ni][mi][r] = -acc[ni][mi][r];
 }
 // MI = 4: all 64 rows of the wave tile; MI = 2: only its first 32-row group (acc[.][0], acc[.][1]) -- the right-hand-side tile row of
 // the factorisation carries two real rows.
-template <int PF, int MI = 4>
-__device__ __forceinline__ void direct_tile_gemm_x2(d4 (&acc)[4][4], const double* pa, int lda, const double* pb, int ldb,
-                                                    int nstep) {
-  const size_t sa = (size_t)4 * lda, sb = (size_t)4 * ldb;
-  double2 fa0[PF + 1], fa1[PF + 1], fb0[PF + 1], fb1[PF + 1];
-#ifdef GPG_NT_LOADS   // A/B builds: non-temporal hint on the operand stream
-#define GPG_DX_LD(p) gpg_nt_load2(p)
-#else
-#define GPG_DX_LD(p) (*reinterpret_cast<const double2*>(p))
+#ifndef GPG_UNROLL_KSTEPS
+#define GPG_UNROLL_KSTEPS 32
 #endif
+template <int PF, int MI = 4, int KS = GPG_KSYNC, int UN = GPG_UNROLL_KSTEPS>
+__device__ __forceinline__ void direct_tile_gemm_acc(d4 (&acc)[4][4], const double* ua_d, unsigned la, int lda, const double* ub_d,
+                                                     unsigned lb, int ldb, int nstep) {
+  const size_t sa = (size_t)4 * lda * sizeof(double), sb = (size_t)4 * ldb * sizeof(double);   // bytes per k-step
+  const char* ua = reinterpret_cast<const char*>(ua_d);
+  const char* ub = reinterpret_cast<const char*>(ub_d);
+  double2 fa0[PF + 1], fa1[PF + 1], fb0[PF + 1], fb1[PF + 1];
+#define GPG_DX_LD(u, l, x) (reinterpret_cast<const double2*>((u) + (size_t)(l))[(x) / 16])
 #define GPG_DX_LOAD(set)                                                              \
   {                                                                                   \
-    fa0[set] = GPG_DX_LD(pa);                                                         \
-    if (MI == 4) fa1[set] = GPG_DX_LD(pa + 32);                                       \
-    fb0[set] = GPG_DX_LD(pb);                                                         \
-    fb1[set] = GPG_DX_LD(pb + 32);                                                    \
-    pa += sa;                                                                         \
-    pb += sb;                                                                         \
+    fa0[set] = GPG_DX_LD(ua, la, 0);                                                  \
+    if (MI == 4) fa1[set] = GPG_DX_LD(ua, la, 256);                                   \
+    fb0[set] = GPG_DX_LD(ub, lb, 0);                                                  \
+    fb1[set] = GPG_DX_LD(ub, lb, 256);                                                \
   }
 #define GPG_DX_MFMA(set)                                                              \
   {                                                                                   \
-    const double fm[4] = {-fa0[set].x, -fa0[set].y, MI == 4 ? -fa1[set].x : 0.0, MI == 4 ? -fa1[set].y : 0.0}; \
+    const double fm[4] = {fa0[set].x, fa0[set].y, MI == 4 ? fa1[set].x : 0.0, MI == 4 ? fa1[set].y : 0.0}; \
     const double fn[4] = {fb0[set].x, fb0[set].y, fb1[set].x, fb1[set].y};            \
     _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                   \
       _Pragma("unroll") for (int mi = 0; mi < MI; ++mi)                                \
         acc[ni][mi] = __builtin_amdgcn_mfma_f64_16x16x4f64(fn[ni], fm[mi], acc[ni][mi], 0, 0, 0); \
   }
+  static_assert(((PF + 1) & PF) == 0 && UN % (PF + 1) == 0 && (KS == 0 || UN % KS == 0), "PF + 1 a power of two dividing UN; KS divides UN");
+  // Software pipeline, UN k-steps (one 128-column tile column by default) of straight-line code per trip of the loop.  EVERY k-step
+  // issues its loads, unconditionally: the operand pointers simply stop advancing at the last k-step of the run, so the PF stages
+  // past the end re-read that k-step (vector-L1 hits, values never used).  With that the number of loads in flight is the same on
+  // every path into every k-step and the compiler's s_waitcnt insertion is exact (vmcnt(4 PF): only the newest PF stages stay in
+  // flight).  Rounds 1 and 2 ran `for (4 k-steps) { if (more) load; mfma }`: that loop's header merges predecessors with different
+  // numbers of loads in flight, the pessimistic merge is vmcnt(0), and every wave drained its whole prefetch queue once per four
+  // k-steps (found in the ISA in round 3).  The advance is scalar arithmetic (s_cselect + s_add).
+#define GPG_DX_ADVANCE(li)                                                            \
+  {                                                                                   \
+    const size_t more = (li) + 1 < nstep ? ~(size_t)0 : (size_t)0;                    \
+    ua += sa & more;                                                                  \
+    ub += sb & more;                                                                  \
+  }
 #pragma unroll
-  for (int s = 0; s < PF; ++s) GPG_DX_LOAD(s)
-  for (int s0 = 0; s0 < nstep; s0 += PF + 1) {
+  for (int s = 0; s < PF; ++s) { GPG_DX_LOAD(s) GPG_DX_ADVANCE(s) }
+  for (int s0 = 0; s0 < nstep; s0 += UN) {
 #pragma unroll
-    for (int u = 0; u <= PF; ++u) {
-      if (((PF + 1) & PF) != 0 && s0 + u >= nstep) break;   // prefetch depths whose period does not divide the 32 k-steps of a tile column
-      if (s0 + u + PF < nstep) GPG_DX_LOAD((u + PF) % (PF + 1))
+    for (int u = 0; u < UN; ++u) {
+      GPG_DX_LOAD((u + PF) % (PF + 1))
+      GPG_DX_ADVANCE(s0 + u + PF)
       __builtin_amdgcn_sched_barrier(0);
-      GPG_DX_MFMA(u)
+      GPG_DX_MFMA(u % (PF + 1))
       __builtin_amdgcn_sched_barrier(0);
+      // Keep the waves of the workgroup within KS k-steps of each other: the waves that read the same operand slice only meet in
+      // the 32-KB vector L1 if they ask for it within a k-step or two (PMC, round 3, profiles/r03k_*: without this the L1 absorbs
+      // about half of the second wave's reads; with it L2 requests fall by 17 %, memory traffic by 10 %, the launch gains 1.2 %).
+      // Plain s_barrier: no counter is drained, the loads in flight stay in flight.  Every wave of the workgroup must come through
+      // here the same number of times (waves without MFMA work in a run call direct_tile_sync_only).
+      if (KS > 0 && u % (KS > 0 ? KS : 1) == (KS > 0 ? KS : 1) - 1) __builtin_amdgcn_s_barrier();
     }
   }
+#undef GPG_DX_ADVANCE
 #undef GPG_DX_LOAD
 #undef GPG_DX_LD
 #undef GPG_DX_MFMA
 }
 
+
+// the former interface (per-lane pointers, acc -= A B^T) for the diagnostic programs under tools/
+template <int PF, int MI = 4, int KS = GPG_KSYNC>
+__device__ __forceinline__ void direct_tile_gemm_x2(d4 (&acc)[4][4], const double* pa, int lda, const double* pb, int ldb, int nstep) {
+  direct_tile_negate(acc);
+  direct_tile_gemm_acc<PF, MI, KS, 16>(acc, pa, 0u, lda, pb, 0u, ldb, nstep);   // (the probes run 16 and 512 k-steps)
+  direct_tile_negate(acc);
+}
 
 }  // namespace

@@ -53,36 +53,8 @@ __global__ void __launch_bounds__(256) trsm64_kernel(const double* __restrict__ 
   double x[16];
 #pragma unroll
   for (int m = 0; m < 16; ++m) x[m] = Xr[(size_t)(4 * m) * ldx];
-  // software pipeline: the L values of step j+1 are read from LDS while step j computes; the
-  // sched_barrier keeps the compiler from hoisting every read to the top (register blow-up).
-  double lv[2][16];
-#pragma unroll
-  for (int m = 0; m < 16; ++m) lv[0][m] = Ls[0][q][m];
-#define GPG_TRSM_STEP(QJ)                                                                   \
-  {                                                                                         \
-    constexpr int cur = QJ & 1, nxt = cur ^ 1;                                               \
-    const int j = 4 * mj + QJ;                                                              \
-    const int jn = j + 1 < 64 ? j + 1 : 63;                                                 \
-    const int m0n = (j + 1) >> 2;                                                           \
-    _Pragma("unroll") for (int m = 0; m < 16; ++m) if (m >= m0n) lv[nxt][m] = Ls[jn][q][m]; \
-    const double xs = x[mj] * sdinv[j];                                                     \
-    x[mj] = (q == QJ) ? xs : x[mj];                                                         \
-    const double xj = quad_bcast<QJ>(x[mj]);                                                \
-    if (QJ < 3) {                                                                           \
-      const double t = x[mj] - xj * lv[cur][mj];                                            \
-      x[mj] = (q > QJ) ? t : x[mj];                                                         \
-    }                                                                                       \
-    _Pragma("unroll") for (int m = mj + 1; m < 16; ++m) x[m] -= xj * lv[cur][m];            \
-    __builtin_amdgcn_sched_barrier(0);                                                      \
-  }
-#pragma unroll
-  for (int mj = 0; mj < 16; ++mj) {
-    GPG_TRSM_STEP(0)
-    GPG_TRSM_STEP(1)
-    GPG_TRSM_STEP(2)
-    GPG_TRSM_STEP(3)
-  }
-#undef GPG_TRSM_STEP
+  // the quad-row substitution of chol_device.h (the L values of step j + 1 are read from LDS while step j computes)
+  GPG_QUAD_SUBST(x, Ls, sdinv, q)
   if (active) {
 #pragma unroll
     for (int m = 0; m < 16; ++m) Xr[(size_t)(4 * m) * ldx] = x[m];

@@ -3,8 +3,18 @@
 // tile_chol_kernel: 64 x 64 tiles (small matrices), tile128_chol_kernel: 128 x 128 tiles.
 #include "chol_device.h"
 
+// tools/tile_probe A/B only (WRONG results): every task reads its B operand from tile row 0 -- what would the launch gain if the row
+// panel L_j,0:j cost no memory traffic at all (upper bound of any operand-sharing scheme)?  -DGPG_FAKE_B
+#ifdef GPG_FAKE_B
+#define GPG_FAKE_B_ROW(cj) ((size_t)0 * (cj))
+#else
+#define GPG_FAKE_B_ROW(cj) (cj)
+#endif
 #ifndef GPG_MFMA_PF
-#define GPG_MFMA_PF 3      // k-steps of operand fragments in flight ahead of the MFMAs (16 VGPRs each)
+#define GPG_MFMA_PF 1      // k-steps of operand fragments in flight ahead of the MFMAs (16 VGPRs each); PF + 1 a power of two.
+                           // Round 3, with exact waits in the loop (direct_tile_gemm_acc): 1 is as fast as 3 on ten cfg3 matrices per launch
+                           // (299.9 / 299.2 ms) and faster on short contractions (4608 columns x 16: 10.85 / 11.02 ms; 9216 x 1: 7.7 / 8.1) --
+                           // the second wave of the SIMD covers the latency, and a shallower queue keeps the shared slices in the 32-KB L1
 #endif
 
 namespace {
@@ -31,7 +41,7 @@ __device__ __forceinline__ int next_ticket(int* ticket, int* sh, int round) {
   __syncthreads();
   if (threadIdx.x == 0) *sh = GPG_TICKET_FETCH(ticket);
   __syncthreads();
-  return *sh;
+  return __builtin_amdgcn_readfirstlane(*sh);   // the same word for every lane: said so, or every address derived from the task is per-lane arithmetic
 #endif
 }
 
@@ -371,7 +381,7 @@ __global__ void __launch_bounds__(256, 2) tile_chol_kernel(TileCholArgs) {
     GPG_KERNARGS(TileCholArgs, ap);
     if (tix >= ap->ntask) return;
     if (!__builtin_amdgcn_readfirstlane(tile_chol_task_call(tix, (unsigned long long)ap))) return;   // aborted: every workgroup drains
-    tix = g_next_ticket;                                    // written before the barrier of the publish step
+    tix = __builtin_amdgcn_readfirstlane(g_next_ticket);                                    // written before the barrier of the publish step
   }
 }
 
@@ -397,8 +407,12 @@ __global__ void __launch_bounds__(256, 2) tile_chol_kernel(TileCholArgs) {
 #ifdef GPG_STAMP
 __shared__ unsigned long long* t128_fo;      // finalisation record of the running task (thread 0 writes and reads it)
 #define GPG_FS2(k) if (threadIdx.x == 0 && t128_fo) t128_fo[k] = __builtin_amdgcn_s_memrealtime();
+// piece-level record (third region of the stamp buffer, 16 words per task): per piece S of column block 0 -- after the flag wait,
+// after the image is in LDS (barrier), after the 16 column steps
+#define GPG_FS3(k) if (threadIdx.x == 0 && t128_fo) (g_stamp_buf + (size_t)GPG_STAMP_MAX * 16 + 2 * (t128_fo - (g_stamp_buf + (size_t)GPG_STAMP_MAX * 8)))[k] = __builtin_amdgcn_s_memrealtime();
 #else
 #define GPG_FS2(k)
+#define GPG_FS3(k)
 #endif
 __device__ __forceinline__ int tile_solve_rows128(const double* L, int ldl, const double* dinv, double* X, int ldx, double* U,
                                                   double (*Ls)[4][18], double* sdinv, int* pa, int* flag_c, int* pb,
@@ -422,14 +436,17 @@ __device__ __forceinline__ int tile_solve_rows128(const double* L, int ldl, cons
 #define GPG_T128_PIECE(FL, LP, DOFF, S)                                                      \
   {                                                                                         \
     if (!wg_wait_flag((FL) + (S), abort_word, info, sh)) return 0;                           \
+    if ((DOFF) == 0) { GPG_FS3(3 * (S)) }                                                    \
     _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                          \
       const int t = tid + 256 * u, jj = 16 * (S) + (t >> 6), k = t & 63;                     \
       Ls[jj][k & 3][k >> 2] = (LP)[k + (size_t)jj * ldl];                                    \
     }                                                                                       \
     if (tid < 16) sdinv[16 * (S) + tid] = dinv[(DOFF) + 16 * (S) + tid];                     \
     __syncthreads();                                                                        \
+    if ((DOFF) == 0) { GPG_FS3(3 * (S) + 1) }                                                \
     GPG_QUAD_SUBST2_PIECE(x0, x1, Ls, sdinv, q, S)                                           \
     _Pragma("unroll") for (int m = 0; m < 16; ++m) { asm volatile("" : "+v"(x0[m])); asm volatile("" : "+v"(x1[m])); } \
+    if ((DOFF) == 0) { GPG_FS3(3 * (S) + 2) }                                                \
   }
   GPG_T128_PIECE(pa, L, 0, 0)
   GPG_T128_PIECE(pa, L, 0, 1)
@@ -573,7 +590,7 @@ tile128_chol_task(int tix, double* A, int ld, int Mt, const int* __restrict__ ta
                   int* ticket, double* __restrict__ dinv, int* __restrict__ info, int N, const int* __restrict__ batch_of, size_t a_stride,
                   int d_stride, int f_stride) {
   __shared__ int sh_kr;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w & 1, wn = w >> 1;
   const int l15 = lane & 15, l4 = lane >> 4;
   const int task = tasks[tix];
@@ -594,7 +611,7 @@ tile128_chol_task(int tix, double* A, int ld, int Mt, const int* __restrict__ ta
   const unsigned long long tk_start = __builtin_amdgcn_s_memrealtime();
   unsigned long long tk_spin = 0, tk_gemm = 0, tk_runs = 0;
 #endif
-  // accumulator layout of direct_tile_gemm_x2: acc[2p + e][2g + m][r] <-> row 32 g + 2 l15 + m, column 32 p + 2 (4 r + l4) + e
+  // accumulator layout of direct_tile_gemm_acc: acc[2p + e][2g + m][r] <-> row 32 g + 2 l15 + m, column 32 p + 2 (4 r + l4) + e
   d4 acc[4][4];
   double* Cw = A + r0 + wm * 64 + 2 * l15 + (cj + wn * 64 + 2 * l4) * (size_t)ld;
 #pragma unroll
@@ -610,6 +627,8 @@ tile128_chol_task(int tix, double* A, int ld, int Mt, const int* __restrict__ ta
 
   // ---- (1) left-looking accumulation ----------------------------------------------------------------------------
   GPG_PRIO_ACC(ti - tj)
+  direct_tile_negate(acc);                                   // the loop ADDS the products to -A_ij (direct_tile_gemm_acc); sign restored below
+  const unsigned lane_off = (unsigned)(2 * l15 + l4 * ld) * 8u;   // bytes: this lane's rows 2 t, 2 t + 1 of column l4 of a k-step
   int kdone = 0;
   while (kdone < tj) {
     GPG_TR(q0)
@@ -632,18 +651,20 @@ tile128_chol_task(int tix, double* A, int ld, int Mt, const int* __restrict__ ta
       sh_kr = kr;
     }
     __syncthreads();
-    const int kr = sh_kr;
+    const int kr = __builtin_amdgcn_readfirstlane(sh_kr);
     if (kr < 0) return false;
     GPG_ACQUIRE();
     GPG_TR(q1)
     const size_t ck = 128 * (size_t)kdone;
     if (ti < Mt) {
       if (!(ti == tj && wm == 0 && wn == 1))   // diagonal tile: the block above the diagonal is never stored
-        direct_tile_gemm_x2<GPG_MFMA_PF>(acc, A + r0 + wm * 64 + 2 * l15 + (ck + l4) * (size_t)ld, ld,
-                               A + cj + wn * 64 + 2 * l15 + (ck + l4) * (size_t)ld, ld, 32 * (kr - kdone));
+        direct_tile_gemm_acc<GPG_MFMA_PF>(acc, A + r0 + wm * 64 + ck * (size_t)ld, lane_off, ld,
+                                A + GPG_FAKE_B_ROW(cj) + wn * 64 + ck * (size_t)ld, lane_off, ld, 32 * (kr - kdone));
+      else direct_tile_sync_only<GPG_MFMA_PF>(32 * (kr - kdone));
     } else if (wm == 0)   // right-hand-side tile row (prep_rows_kernel): rows 0 and 1 are real, the other 126 zero -- an eighth of the MFMAs
-      direct_tile_gemm_x2<GPG_MFMA_PF, 2>(acc, A + r0 + 2 * l15 + (ck + l4) * (size_t)ld, ld,
-                                A + cj + wn * 64 + 2 * l15 + (ck + l4) * (size_t)ld, ld, 32 * (kr - kdone));
+      direct_tile_gemm_acc<GPG_MFMA_PF, 2>(acc, A + r0 + ck * (size_t)ld, lane_off, ld,
+                                 A + cj + wn * 64 + ck * (size_t)ld, lane_off, ld, 32 * (kr - kdone));
+    else direct_tile_sync_only<GPG_MFMA_PF>(32 * (kr - kdone));
     __syncthreads();   // sh_kr may be rewritten
     GPG_TR(q2)
 #ifdef GPG_STAMP
@@ -656,6 +677,7 @@ tile128_chol_task(int tix, double* A, int ld, int Mt, const int* __restrict__ ta
   const unsigned long long tk_fin0 = __builtin_amdgcn_s_memrealtime();
 #endif
   GPG_PRIO_FIN(ti - tj)
+  direct_tile_negate(acc);
   // ---- (2) the updated tile goes back to memory; the finalisation works on it in place.  Diagonal tile: the
   //      top-left 64 x 64 block goes straight into the LDS tile its own wave factors next, the strictly upper
   //      block is dropped. ---------------------------------------------------------------------------------------
@@ -710,7 +732,347 @@ __global__ void __launch_bounds__(256, 2) tile128_chol_kernel(TileCholArgs) {   
     if (!tile128_chol_task(tix, ap->A, ap->ld, ap->Mt, ap->tasks, ap->flags, ap->pieces, ap->abort_word, ap->ticket, ap->dinv, ap->info,
                            ap->N, ap->batch_of, ap->a_stride, ap->d_stride, ap->f_stride))
       return;                                             // aborted: every workgroup drains
-    tix = g_next_ticket;
+    tix = __builtin_amdgcn_readfirstlane(g_next_ticket);
+  }
+}
+
+
+
+// ------------------------------------------------------------------------------------------------
+// pair128_chol_kernel (round 3): the same dataflow factorisation for BATCHED launches, 512 threads = two 256-thread teams per
+// workgroup, ONE workgroup per compute unit.  A task is a PAIR of 128 x 128 tiles of one tile column j that go through the same
+// control flow: team h owns tile (i_h, j) of matrix b_h.  Ordinary pairs are two consecutive rows of one matrix: both teams then
+// read the SAME row panel L_j,0:j as their B operand, k-step by k-step in lock step (the workgroup barrier of the MFMA loop,
+// GPG_PAIR_KSYNC k-steps apart), so it crosses the L2 -> L1 path once per pair: the operand stream of a 256 x 128 footprint, 25 %
+// fewer bytes than two independent 128 x 128 tiles.  Diagonal tiles pair with the diagonal tile of the NEXT matrix of the batch
+// (same j, same barrier sequence, different data); what is left over in a tile column pairs with the next matrix's leftover,
+// and a tile without any partner is simply given to both teams (identical instruction streams on identical data: the duplicate
+// stores write identical values).  Every barrier is a full-workgroup barrier: the two teams never diverge in control flow, and
+// every decision that depends on flags (how far the next MFMA run goes, which 16-column piece of L_jj is final) is taken by
+// thread 0 for both tiles at once.  Flags, early flags, ticket order and the progress argument are those of tile128_chol_kernel:
+// a pair waits only for tiles of earlier tile columns and for the diagonal tiles of its own column, which precede it in the list.
+// What it gives up: with one workgroup per CU the finalisation of a pair is not overlapped with another workgroup's MFMA loop.
+// ------------------------------------------------------------------------------------------------
+#ifndef GPG_PAIR_KSYNC
+#define GPG_PAIR_KSYNC 8
+#endif
+__shared__ __attribute__((aligned(16))) double p128_U[2][4 * 16 * 80];    // per team: staging / transposition tile of the finalisation
+__shared__ __attribute__((aligned(16))) double p128_Ls[2][64][4][18];     // per team: diagonal-block image / potrf scratch
+__shared__ double p128_sdinv[2][64];
+__shared__ int p128_sh_ok;            // result of the joint flag waits: ONE word for both teams (a function-local __shared__ would be one per template instance)
+
+// Both flags up?  Thread 0 of the workgroup polls; 0 = timed out / aborted (both matrices are marked).
+__device__ __forceinline__ int wg_wait_flag2(int* fa, int* fb, int* abort_word, int* info_a, int* info_b, int* sh) {
+  if (threadIdx.x == 0) {
+    int ok = 1;
+    const unsigned long long t_wait = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(fa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 ||
+           __hip_atomic_load(fb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+      if (__builtin_amdgcn_s_memrealtime() - t_wait > GPG_TILE_WAIT_TICKS || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicMax(info_a, GPG_INFO_INTERNAL);
+        atomicMax(info_b, GPG_INFO_INTERNAL);
+        ok = 0;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    *sh = ok;
+  }
+  __syncthreads();
+  const int ok = *sh;
+  __syncthreads();
+  if (ok) GPG_ACQUIRE();
+  return ok;
+}
+
+// tile_solve_rows128 for the two teams of a pair: team-local row tile X against ITS matrix's diagonal tile L (the same tile for an
+// ordinary pair), every wait taken for both teams at once.  pa / pb / flag_c: [2] early-flag pointers of the two teams' matrices.
+__device__ __forceinline__ int pair_solve_rows128(const double* L, int ldl, const double* dinv, double* X, int ldx, double* U,
+                                                  double (*Ls)[4][18], double* sdinv, int* pa0, int* pa1, int* fc0, int* fc1, int* pb0,
+                                                  int* pb1, int* abort_word, int* info0, int* info1, int* sh, int tid) {
+  constexpr int SA = 80, BUF = 16 * SA;
+  const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int q = tid & 3, rr = tid >> 2;
+  const int sp = tid & 31, sk = tid >> 5;
+  double x0[16], x1[16];
+  {
+    const double* Xr = X + rr + (size_t)q * ldx;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      x0[m] = Xr[(size_t)(4 * m) * ldx];
+      x1[m] = Xr[64 + (size_t)(4 * m) * ldx];
+    }
+  }
+#define GPG_P128_PIECE(FL, LP, DOFF, S)                                                      \
+  {                                                                                         \
+    if (!wg_wait_flag2(FL##0 + (S), FL##1 + (S), abort_word, info0, info1, sh)) return 0;    \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                          \
+      const int t = tid + 256 * u, jj = 16 * (S) + (t >> 6), k = t & 63;                     \
+      Ls[jj][k & 3][k >> 2] = (LP)[k + (size_t)jj * ldl];                                    \
+    }                                                                                       \
+    if (tid < 16) sdinv[16 * (S) + tid] = dinv[(DOFF) + 16 * (S) + tid];                     \
+    __syncthreads();                                                                        \
+    GPG_QUAD_SUBST2_PIECE(x0, x1, Ls, sdinv, q, S)                                           \
+    _Pragma("unroll") for (int m = 0; m < 16; ++m) { asm volatile("" : "+v"(x0[m])); asm volatile("" : "+v"(x1[m])); } \
+  }
+  GPG_P128_PIECE(pa, L, 0, 0)
+  GPG_P128_PIECE(pa, L, 0, 1)
+  GPG_P128_PIECE(pa, L, 0, 2)
+  GPG_P128_PIECE(pa, L, 0, 3)
+  {
+    double* Xr = X + rr + (size_t)q * ldx;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      GPG_ST(&Xr[(size_t)(4 * m) * ldx], x0[m]);
+      GPG_ST(&Xr[64 + (size_t)(4 * m) * ldx], x1[m]);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // X1 of this team in memory before the barrier inside the wait
+  if (!wg_wait_flag2(fc0, fc1, abort_word, info0, info1, sh)) return 0;
+#pragma unroll
+  for (int hh = 0; hh < 2; ++hh) {
+    d4 acc[4];
+    const double* Cw = X + 64 * hh + 16 * w + l15 + (size_t)(64 + l4) * ldx;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[ni][r] = Cw[(size_t)(ni * 16 + 4 * r) * ldx];
+    wave_tile_gemm(acc, X + 64 * hh + 2 * sp + (size_t)sk * ldx, ldx, L + 64 + 2 * sp + (size_t)sk * ldl, ldl, 4, U, U + 2 * BUF,
+                   w, l15, l4, sp, sk);
+    __syncthreads();
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) U[(ni * 16 + 4 * r + l4) * SA + 16 * w + l15] = acc[ni][r];
+    __syncthreads();
+    const double* Tr = U + q * SA + rr;
+    if (hh == 0) {
+#pragma unroll
+      for (int m = 0; m < 16; ++m) x0[m] = Tr[(4 * m) * SA];
+    } else {
+#pragma unroll
+      for (int m = 0; m < 16; ++m) x1[m] = Tr[(4 * m) * SA];
+    }
+    __syncthreads();
+  }
+  {
+    const double* L22 = L + 64 + (size_t)64 * ldl;
+    GPG_P128_PIECE(pb, L22, 64, 0)
+    GPG_P128_PIECE(pb, L22, 64, 1)
+    GPG_P128_PIECE(pb, L22, 64, 2)
+    GPG_P128_PIECE(pb, L22, 64, 3)
+  }
+#undef GPG_P128_PIECE
+  {
+    double* Xr = X + rr + (size_t)(64 + q) * ldx;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      GPG_ST(&Xr[(size_t)(4 * m) * ldx], x0[m]);
+      GPG_ST(&Xr[64 + (size_t)(4 * m) * ldx], x1[m]);
+    }
+  }
+  __syncthreads();
+  return 1;
+}
+
+// Finalisation of a pair whose updated tiles sit in memory (diagonal tiles: top-left block in the team's LDS tile), out of line like
+// tile128_finalize.  A / dinv: this thread's team; pa0 / pa1, ...: early flags and info words of the two teams' matrices (uniform).
+// One instance per team (H): the team's LDS arrays must be addressed statically -- through a pointer selected at run time the compiler
+// pre-loads the substitution's L image and spills it (2.3 KB of scratch against 0.4 KB) -- and both instances issue the same barriers.
+template <int H>
+__device__ __noinline__ int pair128_finalize(double* A, int ld, size_t r0, size_t cj, int is_diag, int* pa0, int* pa1, int* pb0, int* pb1,
+                                             int* fc0, int* fc1, int* abort_word, double* dinv, int* info0, int* info1, int N) {
+  constexpr int SA = 80;
+  constexpr int h = H;
+  const int tid = threadIdx.x & 255, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, l4 = lane >> 4;
+  double* const U = p128_U[H];
+  double (*const Ls)[4][18] = p128_Ls[H];
+  double* const sdinv = p128_sdinv[H];
+  if (is_diag) {
+    double* blk = A + cj + cj * (size_t)ld;
+    double (*St)[64] = reinterpret_cast<double(*)[64]>(&Ls[0][0][0]);
+    __syncthreads();
+    {
+      const int bad = potrf64_wg(U, SA, St, blk, ld, dinv + cj, h ? pa1 : pa0, tid);
+      if (w == 0 && bad && lane == 0 && (int)cj + bad - 1 < N) atomicCAS(h ? info1 : info0, 0, (int)cj + bad);
+    }
+    __syncthreads();
+    panel_solve_rows64(blk, ld, dinv + cj, blk + 64, ld, 64, 64, U, Ls, sdinv, tid);
+    GPG_RELEASE();
+    __syncthreads();
+    if (tid == 0) GPG_FLAG_UP(h ? fc1 : fc0);
+    const int sp = tid & 31, sk = tid >> 5;
+    d4 a2[4];
+    const double* C2 = blk + 64 + 16 * w + l15 + (size_t)(64 + l4) * ld;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a2[ni][r] = C2[(size_t)(ni * 16 + 4 * r) * ld];
+    const double* g21 = blk + 64 + 2 * sp + (size_t)sk * ld;
+    wave_tile_gemm(a2, g21, ld, g21, ld, 4, U, U + 2 * 16 * SA, w, l15, l4, sp, sk);
+    __syncthreads();
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) U[(ni * 16 + 4 * r + l4) * SA + 16 * w + l15] = a2[ni][r];
+    __syncthreads();
+    {
+      const int bad = potrf64_wg(U, SA, St, blk + 64 + (size_t)64 * ld, ld, dinv + cj + 64, h ? pb1 : pb0, tid);
+      if (w == 0 && bad && lane == 0 && (int)cj + 64 + bad - 1 < N) atomicCAS(h ? info1 : info0, 0, (int)cj + 64 + bad);
+    }
+    return 1;
+  }
+  const double* Ljj = A + cj + cj * (size_t)ld;
+  double* X = A + r0 + cj * (size_t)ld;
+  return pair_solve_rows128(Ljj, ld, dinv + cj, X, ld, U, Ls, sdinv, pa0, pa1, fc0, fc1, pb0, pb1, abort_word, info0, info1, &p128_sh_ok, tid);
+}
+
+__device__ __forceinline__ bool
+pair128_chol_task(int tix, double* Abase, int ld, int Mt, const int* __restrict__ tasks, int* flags_base, int* early_base, int* abort_word,
+                  int* ticket, double* __restrict__ dinv_base, int* __restrict__ info_base, int N, const int* __restrict__ batch_of,
+                  size_t a_stride, int d_stride, int f_stride) {
+  __shared__ int sh_kr;
+  const int tid = threadIdx.x, h = __builtin_amdgcn_readfirstlane(tid >> 8), t = tid & 255, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = w & 1, wn = w >> 1;
+  const int l15 = lane & 15, l4 = lane >> 4;
+  // both teams' assignments (uniform values; [h] selects this thread's)
+  const int task0 = tasks[2 * tix], task1 = tasks[2 * tix + 1];
+  const int b0 = batch_of[2 * tix], b1 = batch_of[2 * tix + 1];
+  const int tj = task0 >> 16;                                   // common tile column; both tiles diagonal or both below the diagonal
+  const int ti0 = task0 & 0xffff, ti1 = task1 & 0xffff;
+  const int ti = h ? ti1 : ti0, b = h ? b1 : b0;
+  double* const A = Abase + (size_t)b * a_stride;
+  double* const dinv = dinv_base + (size_t)b * d_stride;
+  int* const fl0 = flags_base + (size_t)b0 * f_stride;
+  int* const fl1 = flags_base + (size_t)b1 * f_stride;
+  int* const ea0 = early_base + (size_t)b0 * f_stride;
+  int* const ea1 = early_base + (size_t)b1 * f_stride;
+  int* const info0 = info_base + b0;
+  int* const info1 = info_base + b1;
+  const size_t r0 = 128 * (size_t)ti, cj = 128 * (size_t)tj;
+
+  d4 acc[4][4];
+  double* Cw = A + r0 + wm * 64 + 2 * l15 + (cj + wn * 64 + 2 * l4) * (size_t)ld;
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const double2 v = *reinterpret_cast<const double2*>(Cw + 32 * g + (size_t)(32 * (ni >> 1) + 8 * r + (ni & 1)) * ld);
+        acc[ni][2 * g][r] = v.x;
+        acc[ni][2 * g + 1][r] = v.y;
+      }
+
+  // ---- (1) left-looking accumulation: runs as far as the flags of BOTH tiles' rows (and of tile row j of both matrices) allow ----
+  direct_tile_negate(acc);                                   // the loop adds the products to -A_ij; sign restored below
+  const unsigned lane_off = (unsigned)(2 * l15 + l4 * ld) * 8u;
+  int kdone = 0;
+  while (kdone < tj) {
+    if (tid == 0) {
+      int kr = kdone;
+      int* const fi0 = fl0 + (size_t)ti0 * Mt; int* const fj0 = fl0 + (size_t)tj * Mt;
+      int* const fi1 = fl1 + (size_t)ti1 * Mt; int* const fj1 = fl1 + (size_t)tj * Mt;
+      const unsigned long long t_wait = __builtin_amdgcn_s_memrealtime();
+      for (;;) {
+        while (kr < tj && __hip_atomic_load(fi0 + kr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 &&
+               __hip_atomic_load(fj0 + kr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 &&
+               __hip_atomic_load(fi1 + kr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 &&
+               __hip_atomic_load(fj1 + kr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
+          ++kr;
+        if (kr > kdone) break;
+        if (__builtin_amdgcn_s_memrealtime() - t_wait > GPG_TILE_WAIT_TICKS || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+          __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          atomicMax(info0, GPG_INFO_INTERNAL);
+          atomicMax(info1, GPG_INFO_INTERNAL);
+          kr = -1;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+      }
+      sh_kr = kr;
+    }
+    __syncthreads();
+    const int kr = __builtin_amdgcn_readfirstlane(sh_kr);
+    if (kr < 0) return false;
+    GPG_ACQUIRE();
+    const size_t ck = 128 * (size_t)kdone;
+    const int nstep = 32 * (kr - kdone);
+    if (ti < Mt) {
+      if (!(ti == tj && wm == 0 && wn == 1))
+        direct_tile_gemm_acc<GPG_MFMA_PF, 4, GPG_PAIR_KSYNC>(acc, A + r0 + wm * 64 + ck * (size_t)ld, lane_off, ld,
+                                                            A + cj + wn * 64 + ck * (size_t)ld, lane_off, ld, nstep);
+      else direct_tile_sync_only<GPG_MFMA_PF, GPG_PAIR_KSYNC>(nstep);
+    } else if (wm == 0)
+      direct_tile_gemm_acc<GPG_MFMA_PF, 2, GPG_PAIR_KSYNC>(acc, A + r0 + ck * (size_t)ld, lane_off, ld,
+                                                          A + cj + wn * 64 + ck * (size_t)ld, lane_off, ld, nstep);
+    else direct_tile_sync_only<GPG_MFMA_PF, GPG_PAIR_KSYNC>(nstep);
+    __syncthreads();
+    kdone = kr;
+  }
+
+  // ---- (2) the updated tiles go back to memory (diagonal tiles: top-left block into the team's LDS tile) -------------------------
+  direct_tile_negate(acc);
+  if (ti == tj && w == 0) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          (h ? p128_U[1] : p128_U[0])[(32 * (ni >> 1) + 8 * r + 2 * l4 + (ni & 1)) * 80 + 32 * (mi >> 1) + 2 * l15 + (mi & 1)] = acc[ni][mi][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  } else if (!(ti == tj && wm == 0)) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          double2 v;
+          v.x = acc[ni][2 * g][r];
+          v.y = acc[ni][2 * g + 1][r];
+          *reinterpret_cast<double2*>(Cw + 32 * g + (size_t)(32 * (ni >> 1) + 8 * r + (ni & 1)) * ld) = v;
+        }
+  }
+  if (ti0 != tj) __syncthreads();
+  if ((h ? pair128_finalize<1>(A, ld, r0, cj, ti0 == tj, ea0 + 4 * tj, ea1 + 4 * tj, ea0 + 4 * Mt + 4 * tj, ea1 + 4 * Mt + 4 * tj, ea0 + 8 * Mt + tj,
+                                ea1 + 8 * Mt + tj, abort_word, dinv, info0, info1, N)
+         : pair128_finalize<0>(A, ld, r0, cj, ti0 == tj, ea0 + 4 * tj, ea1 + 4 * tj, ea0 + 4 * Mt + 4 * tj, ea1 + 4 * Mt + 4 * tj, ea0 + 8 * Mt + tj,
+                               ea1 + 8 * Mt + tj, abort_word, dinv, info0, info1, N)) == 0) return false;
+  // ---- (3) publish both tiles (and fetch the next ticket) --------------------------------------------------------------------------
+  {
+    int nxt_ = 0;
+    if (tid == 0) nxt_ = GPG_TICKET_FETCH(ticket);
+    GPG_RELEASE();
+    if (tid == 0) g_next_ticket = nxt_;
+    __syncthreads();
+    if (tid == 0) {
+      GPG_FLAG_UP(fl0 + (size_t)ti0 * Mt + tj);
+      GPG_FLAG_UP(fl1 + (size_t)ti1 * Mt + tj);
+    }
+  }
+  return true;
+}
+
+__global__ void __launch_bounds__(512, 1) pair128_chol_kernel(TileCholArgs) {   // tasks: two ints per task, batch_of: two per task
+  int tix;
+  {
+    GPG_KERNARGS(TileCholArgs, ap);
+    tix = next_ticket(ap->ticket, &g_next_ticket, 0);
+  }
+  for (;;) {
+    GPG_KERNARGS(TileCholArgs, ap);
+    if (tix >= ap->ntask) return;
+    if (!pair128_chol_task(tix, ap->A, ap->ld, ap->Mt, ap->tasks, ap->flags, ap->pieces, ap->abort_word, ap->ticket, ap->dinv, ap->info,
+                           ap->N, ap->batch_of, ap->a_stride, ap->d_stride, ap->f_stride))
+      return;
+    tix = __builtin_amdgcn_readfirstlane(g_next_ticket);
   }
 }
 
@@ -736,7 +1098,7 @@ tile128_trinv_task(int tix, const double* __restrict__ A, int ld, const double* 
                    const int* __restrict__ batch_of, size_t a_stride, size_t w_stride, int d_stride, int f_stride, int* lflags, int lf_mt) {
   __shared__ int sh_kr;
   __shared__ int sh_ok;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w & 1, wn = w >> 1;
   const int l15 = lane & 15, l4 = lane >> 4;
   const int task = tasks[tix];
@@ -778,6 +1140,8 @@ tile128_trinv_task(int tix, const double* __restrict__ A, int ld, const double* 
         acc[ni][2 * g][r] = v.x;
         acc[ni][2 * g + 1][r] = v.y;
       }
+  direct_tile_negate(acc);                                   // the loop adds the products to -W_ji (direct_tile_gemm_acc); sign restored below
+  const unsigned lane_off_w = (unsigned)(2 * l15 + l4 * ldw) * 8u, lane_off_l = (unsigned)(2 * l15 + l4 * ld) * 8u;
   int kdone = tj;
   while (kdone < ti) {
     if (tid == 0) {
@@ -798,15 +1162,16 @@ tile128_trinv_task(int tix, const double* __restrict__ A, int ld, const double* 
       sh_kr = kr;
     }
     __syncthreads();
-    const int kr = sh_kr;
+    const int kr = __builtin_amdgcn_readfirstlane(sh_kr);
     if (kr < 0) return false;
     GPG_ACQUIRE();
     const size_t ck = 128 * (size_t)kdone;
-    direct_tile_gemm_x2<GPG_MFMA_PF>(acc, W + r0 + wm * 64 + 2 * l15 + (ck + l4) * (size_t)ldw, ldw,
-                           A + ci + wn * 64 + 2 * l15 + (ck + l4) * (size_t)ld, ld, 32 * (kr - kdone));
+    direct_tile_gemm_acc<GPG_MFMA_PF>(acc, W + r0 + wm * 64 + ck * (size_t)ldw, lane_off_w, ldw,
+                            A + ci + wn * 64 + ck * (size_t)ld, lane_off_l, ld, 32 * (kr - kdone));
     __syncthreads();   // sh_kr may be rewritten
     kdone = kr;
   }
+  direct_tile_negate(acc);
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
@@ -849,7 +1214,7 @@ __global__ void __launch_bounds__(256, 2) tile128_trinv_kernel(TrinvArgs) {
     if (!tile128_trinv_task(tix, ap->A, ap->ld, ap->dinv, ap->W, ap->ldw, ap->Mt, ap->tasks, ap->flags, ap->ones, ap->abort_word,
                             ap->ticket, ap->info, ap->batch_of, ap->a_stride, ap->w_stride, ap->d_stride, ap->f_stride, ap->lflags, ap->lf_mt))
       return;
-    tix = g_next_ticket;
+    tix = __builtin_amdgcn_readfirstlane(g_next_ticket);
   }
 }
 
@@ -897,7 +1262,7 @@ tile128_wwt_kernel(const double* __restrict__ W0, int ldw, double* __restrict__ 
                    int* info) {
   __shared__ int sh_tix;
   __shared__ int sh_kr;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w & 1, wn = w >> 1;
   const int l15 = lane & 15, l4 = lane >> 4;
   for (int round = 0;; ++round) {
@@ -917,20 +1282,22 @@ tile128_wwt_kernel(const double* __restrict__ W0, int ldw, double* __restrict__ 
       for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[ni][mi][r] = 0.0;
+    const unsigned lane_off = (unsigned)(2 * l15 + l4 * ldw) * 8u;
     if (!wflags) {
-      direct_tile_gemm_x2<GPG_MFMA_PF>(acc, W + r0 + wm * 64 + 2 * l15 + (ck + l4) * (size_t)ldw, ldw,
-                             Wb + c0 + wn * 64 + 2 * l15 + (ck + l4) * (size_t)ldw, ldw, 32 * (full_k ? Mt : Mt - ta));
+      direct_tile_gemm_acc<GPG_MFMA_PF>(acc, W + r0 + wm * 64 + ck * (size_t)ldw, lane_off, ldw,
+                              Wb + c0 + wn * 64 + ck * (size_t)ldw, lane_off, ldw, 32 * (full_k ? Mt : Mt - ta));
     } else {   // the same sum in the same order, in runs of the tile columns of W that are finished
       int kdone = ta;
       while (kdone < Mt) {
         const int kr = wg_wait_two_rows(wflags + (size_t)ta * Mt, wflags + (size_t)tb * Mt, kdone, Mt, abort_word, info, &sh_kr);
         if (kr < 0) return;
         const size_t cc = 128 * (size_t)kdone;
-        direct_tile_gemm_x2<GPG_MFMA_PF>(acc, W + r0 + wm * 64 + 2 * l15 + (cc + l4) * (size_t)ldw, ldw,
-                               W + c0 + wn * 64 + 2 * l15 + (cc + l4) * (size_t)ldw, ldw, 32 * (kr - kdone));
+        direct_tile_gemm_acc<GPG_MFMA_PF>(acc, W + r0 + wm * 64 + cc * (size_t)ldw, lane_off, ldw,
+                                W + c0 + wn * 64 + cc * (size_t)ldw, lane_off, ldw, 32 * (kr - kdone));
         kdone = kr;
       }
     }
+    direct_tile_negate(acc);                               // M = - Sa Sb^T: the loop accumulated + Sa Sb^T
     double* Cw = M + r0 + wm * 64 + 2 * l15 + (c0 + wn * 64 + 2 * l4) * (size_t)ldm;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni)
@@ -1008,7 +1375,7 @@ rows_fwd_task(int tix, const double* __restrict__ A, int ld, const double* __res
       sh_kr = kr;
     }
     __syncthreads();
-    const int kr = sh_kr;
+    const int kr = __builtin_amdgcn_readfirstlane(sh_kr);
     if (kr < 0) return false;
     GPG_ACQUIRE();
     const size_t ck = 64 * (size_t)kdone;
@@ -1182,7 +1549,7 @@ tile64_trinv_task(int tix, const double* __restrict__ A, int ld, const double* _
       sh_kr = kr;
     }
     __syncthreads();
-    const int kr = sh_kr;
+    const int kr = __builtin_amdgcn_readfirstlane(sh_kr);
     if (kr < 0) return false;
     GPG_ACQUIRE();
     const size_t ck = 64 * (size_t)kdone;
@@ -1226,7 +1593,7 @@ __global__ void __launch_bounds__(256, 2) tile64_trinv_kernel(Trinv64Args) {
     if (!tile64_trinv_task(tix, ap->A, ap->ld, ap->dinv, ap->W, ap->ldw, ap->Mt, ap->tasks, ap->flags, ap->abort_word, ap->ticket,
                            ap->info, ap->batch_of, ap->a_stride, ap->w_stride, ap->d_stride, ap->f_stride, ap->lflags, ap->lf_stride))
       return;
-    tix = g_next_ticket;
+    tix = __builtin_amdgcn_readfirstlane(g_next_ticket);
   }
 }
 
@@ -1292,7 +1659,7 @@ rows_bwd_task(int tix, const double* __restrict__ A, int ld, const double* __res
       sh_kr = kr;
     }
     __syncthreads();
-    const int kr = sh_kr;
+    const int kr = __builtin_amdgcn_readfirstlane(sh_kr);
     if (kr < 0) return false;
     GPG_ACQUIRE();
     const size_t ck = 64 * (size_t)kr;                             // contraction rows [64 kr, 64 khi)
@@ -1514,12 +1881,12 @@ const TileMap& get_tile_tasks(gpg_ctx* c, int Mt, int Rt, bool fuse) {
 // per task.  More would only queue behind the resident ones, fewer would leave slots empty; neither affects
 // correctness (ticket order, see tile_chol_kernel).
 template <typename K>
-static int persistent_grid(gpg_ctx* c, K kernel, long ntask) {
+static int persistent_grid(gpg_ctx* c, K kernel, long ntask, int block = 256) {
   const void* key = reinterpret_cast<const void*>(kernel);
   auto it = c->occupancy.find(key);
   if (it == c->occupancy.end()) {
     int nb = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 1; }
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 1; }
     it = c->occupancy.emplace(key, nb).first;
   }
   long cap = (long)it->second * (c->num_cus > 0 ? c->num_cus : 256);
@@ -1640,33 +2007,70 @@ static void launch_tile128_chol(gpg_ctx* c) {
   gpg_prof_end(c);
 }
 
+// Task list of pair128_chol_kernel for B >= 2 matrices: per tile column j first the diagonal tiles (paired over the matrices), then each
+// matrix's tiles below the diagonal in pairs of consecutive rows, then what was left over (at most one ordinary tile per matrix, paired
+// over the matrices) and the right-hand-side tile rows (light tasks: paired with each other).  A tile without a partner is listed
+// twice (both teams do it).  Every task waits only for tasks of earlier tile columns and for the diagonal tiles of its own column.
+static void build_pair_tasks(int Mt, int Rt, int B, std::vector<int>& list, std::vector<int>& bof) {
+  auto emit = [&](int ba, int ia, int bb, int ib, int j) {
+    list.push_back(ia | (j << 16)); list.push_back(ib | (j << 16));
+    bof.push_back(ba); bof.push_back(bb);
+  };
+  for (int j = 0; j < Mt; ++j) {
+    for (int b = 0; b < B; b += 2) emit(b, j, b + 1 < B ? b + 1 : b, j, j);
+    std::vector<std::pair<int, int>> left;
+    for (int b = 0; b < B; ++b) {
+      int i = j + 1;
+      for (; i + 1 < Mt; i += 2) emit(b, i, b, i + 1, j);
+      if (i < Mt) left.emplace_back(b, i);
+    }
+    for (size_t k = 0; k < left.size(); k += 2) {
+      const auto& a = left[k];
+      const auto& bb = k + 1 < left.size() ? left[k + 1] : left[k];
+      emit(a.first, a.second, bb.first, bb.second, j);
+    }
+    for (int i = Mt; i < Rt; ++i)                               // right-hand-side tile rows (one per matrix with R = 128)
+      for (int b = 0; b < B; b += 2) emit(b, i, b + 1 < B ? b + 1 : b, i, j);
+  }
+}
+
 // The same for B matrices at once (see launch_tile_chol_batch): at the two ends of a factorisation the dependency
 // chain leaves most of the chip idle, and a second matrix fills it.
 static void launch_tile128_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a_stride, double* dinv_base, int d_stride,
                                       int* info_base) {
   const int Mt = c->Npad / 128, Rt = c->ld / 128;
-  const unsigned long long key = (2ull << 62) | (1ull << 61) | ((unsigned long long)(c->task_order & 1) << 60) | ((unsigned long long)B << 40) | ((unsigned long long)Mt << 20) | (unsigned)Rt;
+  // pair128_chol_kernel (512-thread workgroups, two tiles of a tile column each): same speed as tile128_chol_kernel from ~16k columns
+  // on (ten cfg3 matrices 298.6 / 297.4 ms) with a quarter less memory traffic (87 against 120 GB per matrix), slower below (2560
+  // columns x 64: 9.2 / 8.8 ms: the finalisations of a pair are not hidden behind another workgroup's MFMA loop)
+  const bool pair = B >= 2 && (c->pair_mode == 1 || (c->pair_mode == 2 && c->Npad >= 16384));
+  const unsigned long long key = (2ull << 62) | (1ull << 61) | ((unsigned long long)(c->task_order & 1) << 60) | ((unsigned long long)(pair ? 1 : 0) << 59) |
+                                 ((unsigned long long)B << 40) | ((unsigned long long)Mt << 20) | (unsigned)Rt;
   auto it = c->tilemaps.find(key);
   if (it == c->tilemaps.end()) {
     std::vector<int> list, bof;
-    for_each_chol_task(Mt, Rt, B, c->task_order, [&](int b, int i, int j) { list.push_back(i | (j << 16)); bof.push_back(b); });
+    if (pair) build_pair_tasks(Mt, Rt, B, list, bof);
+    else for_each_chol_task(Mt, Rt, B, c->task_order, [&](int b, int i, int j) { list.push_back(i | (j << 16)); bof.push_back(b); });
     TileMap tm;
-    tm.n = (int)list.size();
+    tm.n = (int)(pair ? list.size() / 2 : list.size());
     if (!gpg_dev_alloc(c, &tm.dev, sizeof(int) * 2 * list.size())) return;
     (void)hipMemcpy(tm.dev, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice);
     (void)hipMemcpy(tm.dev + list.size(), bof.data(), sizeof(int) * bof.size(), hipMemcpyHostToDevice);
     it = c->tilemaps.emplace(key, tm).first;
   }
   const TileMap& tm = it->second;
+  const size_t nlist = pair ? 2 * (size_t)tm.n : (size_t)tm.n;
   const size_t per = (size_t)Mt * Rt + 1 + 9 * (size_t)Mt, nflag = per * B + 8;   // + the ticket words of the launch
   if (!ensure_tile_flags(c, nflag)) return;
   (void)hipMemsetAsync(c->tile_flags, 0, sizeof(int) * flags_fill(nflag), c->stream);
   const double m = (double)c->N;
   gpg_prof_begin(c, GPG_PROF_GEMM_TRAIL, B * m * m * m / 3.0);
   int* abort_word = c->tile_flags + (size_t)Mt * Rt;
-  hipLaunchKernelGGL(tile128_chol_kernel, dim3(persistent_grid(c, tile128_chol_kernel, tm.n)), dim3(256), 0, c->stream,
-                     TileCholArgs{Abase, c->ld, 0, Mt, tm.dev, tm.n, c->tile_flags, abort_word + 1, abort_word, c->tile_flags + (nflag - 8),
-                                  dinv_base, info_base, c->N, tm.dev + tm.n, a_stride, d_stride, (int)per});
+  const TileCholArgs args{Abase, c->ld, 0, Mt, tm.dev, tm.n, c->tile_flags, abort_word + 1, abort_word, c->tile_flags + (nflag - 8),
+                          dinv_base, info_base, c->N, tm.dev + nlist, a_stride, d_stride, (int)per};
+  if (pair)
+    hipLaunchKernelGGL(pair128_chol_kernel, dim3(persistent_grid(c, pair128_chol_kernel, tm.n, 512)), dim3(512), 0, c->stream, args);
+  else
+    hipLaunchKernelGGL(tile128_chol_kernel, dim3(persistent_grid(c, tile128_chol_kernel, tm.n)), dim3(256), 0, c->stream, args);
   gpg_prof_end(c);
 }
 

@@ -90,6 +90,8 @@ struct gpg_ctx {
   bool zero_info_in_prep = false;    // the next gpg_launch_prep also clears *c->info (consumed by it)
   int fuse_subdiag_max_tiles = 48;   // ... up to this many 64-column tile columns (3072 matrix columns)
   int fuse_subdiag = 1;        // 64-tile factorisation: diagonal tasks own the sub-diagonal tile below the previous diagonal tile (tile_chol_task)
+  int pair_mode = 2;           // batched 128-tile launches (B >= 2) by pair128_chol_kernel (two tiles of a tile column per 512-thread workgroup):
+                               // 0 never, 1 always, 2 from 16384 padded columns on (env GPG_PAIR)
   int task_order = 0;          // ticket order of the dataflow factorisation (for_each_chol_task in cholesky_dataflow.hip)
   double grad_eta = -1.0;      // >= 0: nugget the hyperparameter derivatives are formed with instead of hp->eta (gpg_set_gradient_nugget)
   int max_workgroups = 0;      // > 0: cap on the grid of every persistent launch (gpg_set_max_workgroups; 0 = co-resident capacity)

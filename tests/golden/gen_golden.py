@@ -84,6 +84,10 @@ def make_case(GaussianProcess, name, n, d, kernel, noise, use_grad=True, wellcon
         std_g = 1e-1 * (1 + rng.uniform(0, 1, (n, d)))
         f = f + std_f * rng.standard_normal(n)
         g = g + std_g * rng.standard_normal((n, d))
+    elif noise == 'known_cfg5':   # BASELINE cfg5: constant known noise levels, data left as they are
+        std_f = np.full(n, 1e-2)
+        std_g = np.full((n, d), 1e-1)
+        noise = 'known'
     elif noise == 'unknown':
         std_f = None
         std_g = None

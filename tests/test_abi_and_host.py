@@ -148,13 +148,46 @@ def test_lanczos_reports_non_convergence():
     A = (Q * np.linspace(1.0, 1.0001, 200)) @ Q.T               # clustered spectrum: five steps cannot resolve the top
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
-        lanczos_largest(lambda v: A @ v, 200, k_max=5)
+        lanczos_largest(lambda v: A @ v, 200, k_max=5, k_cap=5, max_restarts=0)
     assert any(issubclass(x.category, LanczosNotConverged) for x in w)
     B = (Q * np.linspace(1.0, 100.0, 200)) @ Q.T
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         lam = lanczos_largest(lambda v: B @ v, 200)
     assert not w and abs(lam - 100.0) < 1e-6
+
+
+def test_lanczos_continues_until_converged():
+    """What the first 120 steps do not resolve is continued (larger basis, then restarts from the Ritz vector) instead of being
+    handed back as a lower bound with a warning: the reference stores np.linalg.cond, an exact value (Kernel.py:239-245)."""
+    import warnings
+    from gpgradpy_amd.cond_number import lanczos_largest
+    rng = np.random.default_rng(2)
+    n = 3000
+    # K^-1 of a preconditioned covariance matrix: most eigenvalues packed below the top, which is only slightly separated
+    lam = np.concatenate((np.linspace(1.0, 0.999, 40) ** 2 * 1e10, 10.0 ** rng.uniform(0, 9.9, n - 40)))
+    lam[0] = 1.0003e10
+    H = rng.standard_normal((n, 3))
+    H, _ = np.linalg.qr(H)
+
+    def apply(v):                                               # diag(lam) in a rotated basis (three Householder reflections)
+        w = v.copy()
+        for k in range(3):
+            w -= 2.0 * H[:, k] * (H[:, k] @ w)
+        w = lam * w
+        for k in (2, 1, 0):
+            w -= 2.0 * H[:, k] * (H[:, k] @ w)
+        return w
+    with warnings.catch_warnings(record=True) as w120:
+        warnings.simplefilter("always")
+        lanczos_largest(apply, n, k_cap=120, max_restarts=0)
+    assert w120, "the case must be one that 120 steps do not resolve"
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        val, vec = lanczos_largest(apply, n, want_vector=True)
+    assert not w, [str(x.message) for x in w]
+    assert abs(val - lam.max()) <= 1e-9 * lam.max()
+    assert np.linalg.norm(apply(vec) - val * vec) <= 1e-6 * val
 
 
 def test_rtensor_init_is_built_on_demand():

@@ -108,6 +108,56 @@ def test_cfg3_full_size_against_oracle():
     assert abs(fd - info_g.ln_lkd_grad[k]) <= 2e-3 * abs(fd), (fd, info_g.ln_lkd_grad[k])
 
 
+def test_cfg5_combination_at_tile_scale_against_oracle():
+    """BASELINE configs[4]'s own combination -- Matern-5/2 + known noise on f and grad f (varK a hyperparameter) + d = 16 -- at
+    n = 1000 (N = 17000: the 128-tile kernel, D = 16 assembly instantiation, noisy likelihood) against ONE evaluation of the CPU
+    oracle, inputs from bench.make_workload(1000, 16, "cfg5").  (The same combination at n = 120 is pinned by the reference itself:
+    cfg5_combo_n120_d16.npz through the generic golden tests; N = 68000 runs by properties in test_gpu_parity.py.)
+    Reference: KernelMatern5f2.py:352-450, CalcLkd.py:185-251."""
+    import bench
+    import gpgradpy_amd
+    from oracle import gp_oracle as orc
+    n, d = 1000, 16
+    X, f, g, hp_table = bench.make_workload(n, d, "cfg5")
+    row = hp_table[0]
+    theta, varK = 10.0 ** row[:d], 10.0 ** row[d]
+    std_f, std_g = np.full(n, 1e-2), np.full((n, d), 1e-1)
+    GP = gpgradpy_amd.GaussianProcess(d, True, "Ma5f2", "precon")
+    GP.set_data(X, f, std_f, g, std_g)
+    hp = GP.make_hp_class(theta=theta, varK=varK)
+    info, ok = GP.calc_lkd_all(hp)
+    assert ok and GP.last_factor()[0] == "tile128" and GP.n_data == 17000
+    y = orc.make_data_vec(f, g)
+    N = y.size
+    nv = orc.calc_noise_vec(n, d, True, std_f, std_g, None, None)
+    r = orc.calc_lkd(X, y, theta, "Ma5f2", True, "precon", GP._etaK, nv, True, varK=varK)
+    assert r.ok
+    ref = dict(hp_beta=r.hp_beta, hp_varK=varK, ln_det_Kmat=r.ln_det_Kmat, ln_lkd=r.ln_lkd)
+    tol.check_scalars(info.hp_beta[0], info.hp_varK, info.ln_det_Kmat, info.ln_lkd, ref, N, True)
+    # the batched entry point (what bench.py --config cfg5 times) gives the same number for this row
+    ln = GP.calc_lkd_batch(hp_table[:2])
+    assert abs(ln[0] - r.ln_lkd) <= tol.LN_LKD_RTOL * abs(r.ln_lkd)
+    # posterior: the model's matrix is the EVALUATION-time one (the reference builds it with varK := 1 before the noise is divided by
+    # it, Kernel.py:196-197,218 -- not the likelihood's matrix when the data are noisy): alpha against the oracle's model, its
+    # residual through the oracle's factor of that matrix, mu / sig at 8 points
+    hp2 = GP.optz_closed_form_hp(hp)
+    GP.set_hpara("set", 0, hp_vals=hp2)
+    alpha = GP.invKernEta_fdiff
+    res = y.copy()
+    res[:n] -= hp2.beta[0]
+    m = orc.setup_eval_model(X, y, theta, "Ma5f2", True, "precon", GP._etaK, nv, r.hp_beta, hp2.varK)
+    Lo = np.tril(m.chofac[0]) if m.chofac[1] else np.triu(m.chofac[0]).T
+    rel = np.linalg.norm(Lo @ (Lo.T @ alpha) - res) / (np.linalg.norm(Lo, "fro") ** 2 * np.linalg.norm(alpha))   # ||L L^T||_F <= ||L||_F^2
+    assert rel <= tol.ALPHA_RESIDUAL, rel
+    assert np.linalg.norm(alpha - m.alpha) <= tol.ALPHA_NORMWISE * np.linalg.norm(m.alpha)
+    xq = np.random.default_rng(5).uniform(-2, 2, (8, d))
+    mu_o, sig_o = orc.eval_model(m, xq)
+    mu, sig = GP.eval_model(xq)[:2]
+    np.testing.assert_allclose(mu, mu_o, rtol=tol.MU_RTOL, atol=tol.MU_ATOL_SCALE * max(1.0, np.abs(mu_o).max()))
+    np.testing.assert_allclose(sig, sig_o, rtol=tol.SIG_RTOL, atol=tol.SIG_ATOL_SCALE * np.sqrt(hp2.varK))
+    assert GP.factor_fallbacks() == 0
+
+
 def test_likelihood_calls_do_not_disturb_the_posterior():
     """The reference keeps KernEta_chofac / invKernEta_fdiff across later calc_lkd_all calls (GpEvalModel.py:17-57; BO
     loops interleave them).  Every kind of likelihood call between setup_eval_model and eval_model must leave the

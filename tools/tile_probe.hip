@@ -32,6 +32,7 @@ int main(int argc, char** argv) {
   if (getenv("GPG_PROBE_MAX_WG")) c.max_workgroups = atoi(getenv("GPG_PROBE_MAX_WG"));   // cap on the persistent grid (e.g. 256 = one workgroup per CU)
   c.num_cus = 256;
   if (getenv("GPG_PROBE_ORDER")) c.task_order = atoi(getenv("GPG_PROBE_ORDER"));
+  if (getenv("GPG_PAIR")) c.pair_mode = atoi(getenv("GPG_PAIR"));
   if (getenv("GPG_PROBE_FUSE")) { c.fuse_subdiag = atoi(getenv("GPG_PROBE_FUSE")); c.fuse_subdiag_max_tiles = 1 << 20; }
   hipMalloc(&c.A, sizeof(double) * (size_t)c.ld * n);
   hipMalloc(&c.dinv, sizeof(double) * n);
@@ -39,8 +40,8 @@ int main(int argc, char** argv) {
   hipMemset(c.info, 0, sizeof(int));
 #ifdef GPG_STAMP
   unsigned long long* dbuf = nullptr;
-  if (hipMalloc(&dbuf, GPG_STAMP_MAX * 16 * 8) != hipSuccess || dbuf == nullptr) { printf("stamp buffer alloc failed\n"); return 1; }
-  hipMemset(dbuf, 0, GPG_STAMP_MAX * 16 * 8);
+  if (hipMalloc(&dbuf, GPG_STAMP_MAX * 32 * 8) != hipSuccess || dbuf == nullptr) { printf("stamp buffer alloc failed\n"); return 1; }
+  hipMemset(dbuf, 0, GPG_STAMP_MAX * 32 * 8);
   if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &dbuf, sizeof(dbuf)) != hipSuccess) { printf("symbol copy failed\n"); return 1; }
   hipDeviceSynchronize();
 #endif
@@ -70,11 +71,11 @@ int main(int argc, char** argv) {
   printf("n=%d impl=%d: %.3f ms, %.2f TFLOP/s (n^3/3), info=%d abort=%d\n", n, impl, best, (double)B * n * n * n / 3.0 / best * 1e-9, info, ab);
 #ifdef GPG_STAMP
   {
-    std::vector<unsigned long long> hb(GPG_STAMP_MAX * 16);
+    std::vector<unsigned long long> hb(GPG_STAMP_MAX * 32);
     hipMemcpy(hb.data(), dbuf, hb.size() * 8, hipMemcpyDeviceToHost);
     FILE* f = fopen(argc > 4 ? argv[4] : "../gpurun_out/tile_timeline.csv", "w");
     if (f) {
-      fprintf(f, "block,ti,tj,start,end,spin_cyc,gemm_cyc,runs,fin0,f0,f1,f2,f3,f4,wg,f5,f6,f7\n");
+      fprintf(f, "block,ti,tj,start,end,spin_cyc,gemm_cyc,runs,fin0,f0,f1,f2,f3,f4,wg,f5,f6,f7,p0w,p0i,p0s,p1w,p1i,p1s,p2w,p2i,p2s,p3w,p3i,p3s\n");
       unsigned long long t0 = ~0ull;
       for (int b = 0; b < GPG_STAMP_MAX; ++b) if (hb[b * 8 + 1] && hb[b * 8] < t0) t0 = hb[b * 8];
       for (int b = 0; b < GPG_STAMP_MAX; ++b) {
@@ -82,6 +83,10 @@ int main(int argc, char** argv) {
         if (o[1] == 0) continue;
         const unsigned long long* g = &hb[(size_t)GPG_STAMP_MAX * 8 + (size_t)b * 8];
         fprintf(f, "%d,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu\n", b, o[6] & 0xffff, o[6] >> 16, o[0] - t0, o[1] - t0, o[2], o[3], o[4], o[5] - t0, g[0] - t0, g[1] - t0, g[2] - t0, g[3] - t0, g[4] ? g[4] - t0 : 0ull, o[7], g[5] ? g[5] - t0 : 0ull, g[6] ? g[6] - t0 : 0ull, g[7] ? g[7] - t0 : 0ull);
+        const unsigned long long* pz = &hb[(size_t)GPG_STAMP_MAX * 16 + (size_t)b * 16];
+        fseek(f, -1, SEEK_CUR);
+        for (int k = 0; k < 12; ++k) fprintf(f, ",%llu", pz[k] ? pz[k] - t0 : 0ull);
+        fprintf(f, "\n");
       }
       fclose(f);
     }
