@@ -302,7 +302,9 @@ def main():
     DOM_KERNELS = {
         "blocked": "gemm_dma_kernel<4> (trailing update C -= A_p A_p^T of the blocked schedule, 128x128 tiles)",
         "tile64": "tile_chol_kernel (whole Cholesky as one dataflow launch, 64x64 tiles, left-looking)",
-        "tile128": "tile128_chol_kernel (whole Cholesky as one dataflow launch, 128x128 tiles, left-looking)"}
+        "tile128": "tile128_chol_kernel (whole Cholesky as one dataflow launch, 128x128 tiles, left-looking)",
+        "pair128": "pair128_chol_kernel (whole Cholesky of the batch as one dataflow launch, 128x128 tiles in pairs per 512-thread "
+                   "workgroup, left-looking)"}
 
     # global restart table of the run: rank r's block is rows [8r, 8r+8) of the 64-row table (BASELINE cfg4: 8 per GPU),
     # cycled when steps > 8; shard_rows(world * k, world, r) hands rank r exactly its block

@@ -20,7 +20,7 @@ PROF_NCAT = len(PROF_CATS)
 # every symbol include/gpgrad.h declares
 ABI_SYMBOLS = (
     "gpg_create", "gpg_destroy", "gpg_last_error", "gpg_set_grad_mask", "gpg_set_data", "gpg_lkd", "gpg_lkd_grad", "gpg_lkd_batch", "gpg_lkd_grad_batch",
-    "gpg_setup_eval", "gpg_predict", "gpg_predict_grad", "gpg_predict_var", "gpg_predict_hess", "gpg_get_matrix", "gpg_kern_rtensor", "gpg_kern_rtensor_grad_hp", "gpg_kern_rtensor_hess_x", "gpg_factor_apply", "gpg_dcov_quadform", "gpg_cond_fro", "gpg_set_noise", "gpg_abs_rowsum", "gpg_set_gradient_nugget", "gpg_lkd_alpha", "gpg_prof_enable", "gpg_prof_read", "gpg_set_panel", "gpg_set_lookahead", "gpg_set_factor_mode", "gpg_factor_fallbacks", "gpg_overlap_fallbacks", "gpg_solve_fallbacks", "gpg_last_factor", "gpg_set_batch", "gpg_reserve_batch", "gpg_set_max_workgroups",
+    "gpg_setup_eval", "gpg_predict", "gpg_predict_grad", "gpg_predict_var", "gpg_predict_hess", "gpg_get_matrix", "gpg_kern_rtensor", "gpg_kern_rtensor_grad_hp", "gpg_kern_rtensor_hess_x", "gpg_factor_apply", "gpg_dcov_quadform", "gpg_cond_fro", "gpg_set_noise", "gpg_abs_rowsum", "gpg_set_gradient_nugget", "gpg_lkd_alpha", "gpg_prof_enable", "gpg_prof_read", "gpg_set_panel", "gpg_set_lookahead", "gpg_set_factor_mode", "gpg_set_pair_mode", "gpg_factor_fallbacks", "gpg_overlap_fallbacks", "gpg_solve_fallbacks", "gpg_last_factor", "gpg_set_batch", "gpg_reserve_batch", "gpg_set_max_workgroups",
     "gpg_device_info", "gpg_multi_create", "gpg_multi_destroy", "gpg_multi_last_error", "gpg_multi_count", "gpg_multi_set_data",
     "gpg_multi_lkd_batch",
 )
@@ -124,6 +124,8 @@ def load():
     lib.gpg_cond_fro.restype = C.c_int
     lib.gpg_factor_fallbacks.argtypes = [vp]
     lib.gpg_factor_fallbacks.restype = C.c_int
+    lib.gpg_set_pair_mode.argtypes = [vp, C.c_int]
+    lib.gpg_set_pair_mode.restype = C.c_int
     for name in ("gpg_overlap_fallbacks", "gpg_solve_fallbacks"):
         getattr(lib, name).argtypes = [vp]
         getattr(lib, name).restype = C.c_int

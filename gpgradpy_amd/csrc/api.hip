@@ -1395,6 +1395,13 @@ int gpg_set_factor_mode(gpg_ctx* c, int mode) {
   return 0;
 }
 
+int gpg_set_pair_mode(gpg_ctx* c, int mode) {
+  if (!c) return -1;
+  if (mode < 0 || mode > 2) { c->err = "pair mode must be 0, 1 or 2"; return -1; }
+  c->pair_mode = mode;
+  return 0;
+}
+
 int gpg_reserve_batch(gpg_ctx* c, int rows) {
   if (!c) return -1;
   if (!c->have_data) { c->err = "gpg_set_data must be called first"; return -1; }

@@ -323,7 +323,10 @@ __device__ __forceinline__ void wave_tile_gemm(d4 (&acc)[4], const double* ga, i
 // once per piece: two dependent hops per column instead of five.  tools/subst_probe: the 64 column steps of a block cost 211 cycles
 // each either way -- the steps are bound by their ~21 fp64 instructions at ~10 cycles, not by the chain -- and beside an MFMA wave they
 // cost the same while the MFMA wave drops from 64 to 96 cycles per instruction.  +2 % for one chain-bound 64-tile matrix, -2 % for
-// batched 128-tile launches (one more FMA per row and step), and the two kernels would no longer agree bit for bit: not adopted.)
+// batched 128-tile launches (one more FMA per row and step), and the two kernels would no longer agree bit for bit: not adopted.
+// Also tried: the per-lane selects moved onto the multipliers (x *= owner ? dv : 1.0; x -= xj * (below ? L : 0.0): exact, 12 instead
+// of 16 non-FMA instructions per step) with the next step's L values read through a running LDS pointer (one v_add per step instead of
+// one per read): 283 instead of 212 cycles per step in tools/subst_probe, nothing in the kernels.)
 // quad-row substitution x <- x L^-T of one matrix row spread over a lane quad (see trsm64_kernel): x[m] is
 // column 4m + q; Ls is the LDS image Ls[j][q][m] = L[4m + q][j], sdinv the reciprocal pivots.
 #define GPG_QUAD_SUBST(x, Ls, sdinv, q)                                                      \

@@ -516,79 +516,328 @@ __device__ __forceinline__ int tile_solve_rows128(const double* L, int ldl, cons
 __shared__ __attribute__((aligned(16))) double t128_U[4 * 16 * 80];   // staging / transposition tile of the finalisation
 __shared__ __attribute__((aligned(16))) double t128_Ls[64][4][18];    // diagonal-block image / potrf scratch
 __shared__ double t128_sdinv[64];
+__shared__ int t128_sh_ok;
 
-__device__ __noinline__ int tile128_finalize(double* A, int ld, size_t r0, size_t cj, int is_diag, int* pa, int* pb,
-                                             int* flag_c, int* abort_word, double* dinv, int* info, int N, int tix) {
-  constexpr int SA = 80;
-  double* const U = t128_U;
-  double (*const Ls)[4][18] = t128_Ls;
-  double* const sdinv = t128_sdinv;
-  __shared__ int sh_ok;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int l15 = lane & 15, l4 = lane >> 4;
-#ifdef GPG_STAMP
-  unsigned long long* fo = (g_stamp_buf != nullptr && tix < GPG_STAMP_MAX) ? g_stamp_buf + (size_t)GPG_STAMP_MAX * 8 + (size_t)tix * 8 : nullptr;
-#define GPG_FS(k) if (tid == 0 && fo) fo[k] = __builtin_amdgcn_s_memrealtime();
-#else
-#define GPG_FS(k)
-#endif
-  GPG_FS(0)
-#ifdef GPG_STAMP
-  if (tid == 0) t128_fo = is_diag ? nullptr : fo;
-#endif
-  if (is_diag) {
-    double* blk = A + cj + cj * (size_t)ld;
-    double (*St)[64] = reinterpret_cast<double(*)[64]>(&Ls[0][0][0]);   // potrf scratch over the Ls region
-    __syncthreads();   // A11 was left in the LDS tile by wave 0; the other waves' stores of A21 / A22 are drained below
-    {
-      const int bad = potrf64_wg(U, SA, St, blk, ld, dinv + cj, pa);   // L11 published in 16-column pieces pa[0..3]
-      if (w == 0 && bad && lane == 0 && (int)cj + bad - 1 < N) atomicCAS(info, 0, (int)cj + bad);
+// LDS of pair128_chol_kernel (512 threads = two teams; defined here because fin128_offdiag serves both 128-tile kernels)
+__shared__ __attribute__((aligned(16))) double p128_U[2][4 * 16 * 80];    // per team: staging / transposition tile of the finalisation
+__shared__ __attribute__((aligned(16))) double p128_Ls[2][64][4][18];     // per team: diagonal-block image / potrf scratch
+__shared__ double p128_sdinv[2][64];
+__shared__ int p128_sh_ok;            // result of the joint flag waits: ONE word for both teams (a function-local __shared__ would be one per template instance)
+
+// Both flags up?  Thread 0 of the workgroup polls; 0 = timed out / aborted (both matrices are marked).
+__device__ __forceinline__ int wg_wait_flag2(int* fa, int* fb, int* abort_word, int* info_a, int* info_b, int* sh) {
+  if (threadIdx.x == 0) {
+    int ok = 1;
+    const unsigned long long t_wait = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(fa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 ||
+           __hip_atomic_load(fb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+      if (__builtin_amdgcn_s_memrealtime() - t_wait > GPG_TILE_WAIT_TICKS || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+        __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        atomicMax(info_a, GPG_INFO_INTERNAL);
+        atomicMax(info_b, GPG_INFO_INTERNAL);
+        ok = 0;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
     }
-    __syncthreads();   // also drains the other waves' stores of A21 / A22
-    GPG_FS(1)
-    // L21 = A21 L11^-T
-    panel_solve_rows64(blk, ld, dinv + cj, blk + 64, ld, 64, 64, U, Ls, sdinv);
-    GPG_RELEASE();   // L21 is final (every thread stored part of it; the solve ended with a barrier)
-    __syncthreads();
-    if (tid == 0) GPG_FLAG_UP(flag_c);
-    GPG_FS(2)
-    // A22 -= L21 L21^T on MFMA, then factor it from the LDS tile
-    const int sp = tid & 31, sk = tid >> 5;
-    d4 a2[4];
-    const double* C2 = blk + 64 + 16 * w + l15 + (size_t)(64 + l4) * ld;
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) a2[ni][r] = C2[(size_t)(ni * 16 + 4 * r) * ld];
-    const double* g21 = blk + 64 + 2 * sp + (size_t)sk * ld;
-    wave_tile_gemm(a2, g21, ld, g21, ld, 4, U, U + 2 * 16 * SA, w, l15, l4, sp, sk);
-    __syncthreads();
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) U[(ni * 16 + 4 * r + l4) * SA + 16 * w + l15] = a2[ni][r];
-    __syncthreads();
-    GPG_FS(3)
-    {
-      const int bad = potrf64_wg(U, SA, St, blk + 64 + (size_t)64 * ld, ld, dinv + cj + 64, pb);   // L22: pb[0..3]
-      if (w == 0 && bad && lane == 0 && (int)cj + 64 + bad - 1 < N) atomicCAS(info, 0, (int)cj + 64 + bad);
-    }
-    GPG_FS(4)
-    return 1;
+    *sh = ok;
   }
-  GPG_FS(1)
-  const double* Ljj = A + cj + cj * (size_t)ld;
-  double* X = A + r0 + cj * (size_t)ld;
-  if (!tile_solve_rows128(Ljj, ld, dinv + cj, X, ld, U, Ls, sdinv, pa, flag_c, pb, abort_word, info, &sh_ok)) return 0;
-  GPG_FS(2)
-  GPG_FS(3)
+  __syncthreads();
+  const int ok = *sh;
+  __syncthreads();
+  if (ok) GPG_ACQUIRE();
+  return ok;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fin128_offdiag (round 3): finalisation X <- X L_jj^-T of an off-diagonal 128 x 128 tile of the factorisation, for both 128-tile
+// kernels (SET 0 / 1: the two teams of pair128_chol_kernel, SET 2: tile128_chol_kernel; one instance each, because a team's LDS arrays
+// must be addressed statically).  What the timeline of round 3 showed (tools/timeline_pieces.py, 64 matrices of 2560 columns): of
+// ~100 us per task only ~40 are the 128 column steps; 34 us are the tile going to memory and coming back in the quad layout (store,
+// s_waitcnt, barrier, 32 loads), 42 us are eight times (flag poll, two barriers, a dependent load of 16 columns of L_jj, a barrier).
+//  * Column block 0 reaches this function THROUGH LDS: wave (wm, 0) of the team has written its 64 x 64 accumulator block as
+//    [column][row] -- rows 0..63 into U (row stride 80), rows 64..127 into the region of the L image viewed as [64][72]
+//    (fin128_handoff_block0) -- and every thread takes its two rows in the quad layout from there.  Column block 1 (waves (wm, 1))
+//    went to memory as before and is read back for its MFMA update much later.
+//  * When the diagonal tile is COMPLETE on entry (its tile flag; the rule in batched launches) there is one check instead of nine
+//    waits: the image of L11 is loaded in one piece, the 64 column steps run without a barrier, the raw L22 is fetched into registers
+//    while block 1 takes its update.  Otherwise the piecewise path of rounds 1 / 2 runs (16 columns at a time behind the diagonal
+//    task's early flags).  Both paths do the same arithmetic in the same order.
+// done0 / done1: tile flags of the diagonal tiles of the two teams' matrices (the same word twice for SET 2), every other flag
+// argument likewise.  Returns 0 if a wait timed out.
+// ------------------------------------------------------------------------------------------------
+template <int SET> __device__ __forceinline__ double* fin128_U() { if constexpr (SET == 2) return t128_U; else return p128_U[SET]; }
+template <int SET> __device__ __forceinline__ double (*fin128_Ls())[4][18] { if constexpr (SET == 2) return t128_Ls; else return p128_Ls[SET]; }
+template <int SET> __device__ __forceinline__ double* fin128_sdinv() { if constexpr (SET == 2) return t128_sdinv; else return p128_sdinv[SET]; }
+template <int SET> __device__ __forceinline__ int* fin128_sh() { if constexpr (SET == 2) return &t128_sh_ok; else return &p128_sh_ok; }
+// the caller's side of the LDS hand-over (inlined into the task: the accumulators are in its registers)
+template <int SET>
+__device__ __forceinline__ void fin128_handoff_block0(const d4 (&acc)[4][4], int wm, int l15, int l4) {
+  double* const U = fin128_U<SET>();
+  double* const L2 = &fin128_Ls<SET>()[0][0][0];
+#define GPG_F128_HAND(dst, stride)                                                           \
+  _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                           \
+    _Pragma("unroll") for (int g = 0; g < 2; ++g)                                            \
+      _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                        \
+        double2 v;                                                                          \
+        v.x = acc[ni][2 * g][r];                                                            \
+        v.y = acc[ni][2 * g + 1][r];                                                        \
+        *reinterpret_cast<double2*>((dst) + (32 * (ni >> 1) + 8 * r + 2 * l4 + (ni & 1)) * (stride) + 32 * g + 2 * l15) = v; \
+      }
+  if (wm == 0) { GPG_F128_HAND(U, 80) } else { GPG_F128_HAND(L2, 72) }
+#undef GPG_F128_HAND
+}
+// Called with the ticket and the kernel's argument segment only: everything else is re-derived here by scalar loads.  What a task
+// keeps alive across its MFMA loop is spilled, and every spill reload after the loop is a memory round trip under full load (the
+// timeline of the first version of this function showed ~35 us of them in front of the call).
+template <int SET>
+__device__ __noinline__ int fin128_offdiag(int tix_v, unsigned long long kernarg_bits) {
+  constexpr int SA = 80, S2 = 72, BUF = 16 * SA;
+  GPG_KERNARGS_FROM(TileCholArgs, ap, kernarg_bits);
+  const int tix = __builtin_amdgcn_readfirstlane(tix_v);
+  const int Mt = ap->Mt, ld = ap->ld;
+  int task, b0, b1;
+  if constexpr (SET == 2) {
+    task = ap->tasks[tix];
+    b0 = b1 = ap->batch_of ? ap->batch_of[tix] : 0;
+  } else {
+    task = ap->tasks[2 * tix + SET];
+    b0 = ap->batch_of[2 * tix];
+    b1 = ap->batch_of[2 * tix + 1];
+  }
+  const int ti = task & 0xffff, tj = task >> 16, b = SET == 1 ? b1 : b0;
+  double* const A = ap->A + (size_t)b * ap->a_stride;
+  double* const dinv_m = ap->dinv + (size_t)b * ap->d_stride;
+  int* const info0 = ap->info + b0;
+  int* const info1 = ap->info + b1;
+  int* const fl0 = ap->flags + (size_t)b0 * ap->f_stride;
+  int* const fl1 = ap->flags + (size_t)b1 * ap->f_stride;
+  int* const ea0 = ap->pieces + (size_t)b0 * ap->f_stride;
+  int* const ea1 = ap->pieces + (size_t)b1 * ap->f_stride;
+  int* const pa0 = ea0 + 4 * tj; int* const pa1 = ea1 + 4 * tj;
+  int* const pb0 = ea0 + 4 * Mt + 4 * tj; int* const pb1 = ea1 + 4 * Mt + 4 * tj;
+  int* const fc0 = ea0 + 8 * Mt + tj; int* const fc1 = ea1 + 8 * Mt + tj;
+  int* const done0 = fl0 + (size_t)tj * Mt + tj; int* const done1 = fl1 + (size_t)tj * Mt + tj;
+  int* const abort_word = ap->abort_word;
+  const size_t r0 = 128 * (size_t)ti, cj = 128 * (size_t)tj;
+  double* const U = fin128_U<SET>();
+  double (*const Ls)[4][18] = fin128_Ls<SET>();
+  double* const sdinv = fin128_sdinv<SET>();
+  int* const sh = fin128_sh<SET>();
+  const int tid = SET == 2 ? (int)threadIdx.x : (int)(threadIdx.x & 255), lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int q = tid & 3, rr = tid >> 2;
+  const int sp = tid & 31, sk = tid >> 5;
+  const double* const L = A + cj + cj * (size_t)ld;            // the diagonal tile of this team's matrix
+  const double* const dinv = dinv_m + cj;
+  double* const X = A + r0 + cj * (size_t)ld;
+  const int ldl = ld, ldx = ld;
+#ifdef GPG_STAMP
+#define GPG_FS4(k) if (SET == 2 && threadIdx.x == 0 && t128_fo) t128_fo[k] = __builtin_amdgcn_s_memrealtime();
+#else
+#define GPG_FS4(k)
+#endif
+  GPG_FS4(0)
+  if (threadIdx.x == 0)
+    *sh = __hip_atomic_load(done0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 &&
+          __hip_atomic_load(done1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+  __syncthreads();                                             // the hand-over is in LDS, the verdict on the diagonal tile in *sh
+  const int fast = *sh;
+  GPG_FS4(1)
+#ifdef GPG_STAMP
+  if (SET == 2 && threadIdx.x == 0 && t128_fo) t128_fo[7] = fast ? 2 : 1;
+#endif
+  double x0[16], x1[16];
+  {
+    const double* T0 = U + q * SA + rr;
+    const double* T1 = &fin128_Ls<SET>()[0][0][0] + q * S2 + rr;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      x0[m] = T0[(4 * m) * SA];
+      x1[m] = T1[(4 * m) * S2];
+    }
+  }
+  // column block 1 after its update: T2 -= X1 L21^T for the two row halves, each transposed through the LDS tile into x0 / x1
+#define GPG_F128_UPDATE()                                                                    \
+  _Pragma("unroll") for (int hh = 0; hh < 2; ++hh) {                                          \
+    d4 acc[4];                                                                              \
+    const double* Cw = X + 64 * hh + 16 * w + l15 + (size_t)(64 + l4) * ldx;                 \
+    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                         \
+      _Pragma("unroll") for (int r = 0; r < 4; ++r) acc[ni][r] = Cw[(size_t)(ni * 16 + 4 * r) * ldx]; \
+    wave_tile_gemm(acc, X + 64 * hh + 2 * sp + (size_t)sk * ldx, ldx, L + 64 + 2 * sp + (size_t)sk * ldl, ldl, 4, U, U + 2 * BUF, \
+                   w, l15, l4, sp, sk);                                                     \
+    __syncthreads();                                                                        \
+    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                         \
+      _Pragma("unroll") for (int r = 0; r < 4; ++r) U[(ni * 16 + 4 * r + l4) * SA + 16 * w + l15] = acc[ni][r]; \
+    __syncthreads();                                                                        \
+    const double* Tr = U + q * SA + rr;                                                     \
+    if (hh == 0) { _Pragma("unroll") for (int m = 0; m < 16; ++m) x0[m] = Tr[(4 * m) * SA]; } \
+    else { _Pragma("unroll") for (int m = 0; m < 16; ++m) x1[m] = Tr[(4 * m) * SA]; }        \
+    __syncthreads();                                                                        \
+  }
+#define GPG_F128_STORE(COL0)                                                                 \
+  {                                                                                         \
+    double* Xr = X + rr + (size_t)((COL0) + q) * ldx;                                        \
+    _Pragma("unroll") for (int m = 0; m < 16; ++m) {                                         \
+      GPG_ST(&Xr[(size_t)(4 * m) * ldx], x0[m]);                                             \
+      GPG_ST(&Xr[64 + (size_t)(4 * m) * ldx], x1[m]);                                        \
+    }                                                                                       \
+  }
+  if (fast) {
+    GPG_ACQUIRE();
+    double li[16];                                             // raw 64 x 64 block of L, 16 entries per thread
+#define GPG_F128_RAW(LP)                                                                     \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                         \
+      const int t = tid + 256 * i;                                                          \
+      li[i] = (LP)[(t & 63) + (size_t)(t >> 6) * ldl];                                       \
+    }
+#define GPG_F128_IMAGE(DOFF)                                                                 \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                         \
+      const int t = tid + 256 * i, jj = t >> 6, k = t & 63;                                  \
+      Ls[jj][k & 3][k >> 2] = li[i];                                                        \
+    }                                                                                       \
+    if (tid < 64) sdinv[tid] = dinv[(DOFF) + tid];
+    GPG_F128_RAW(L)
+    __syncthreads();                                           // every thread has taken its x1 out of the image region
+    GPG_F128_IMAGE(0)
+    __syncthreads();
+    GPG_FS4(2)
+    GPG_QUAD_SUBST2(x0, x1, Ls, sdinv, q)
+    GPG_FS4(3)
+    GPG_F128_STORE(0)
+    GPG_F128_RAW(L + 64 + (size_t)64 * ldl)                    // L22, in flight through the update of block 1
+    __syncthreads();                                           // X1 in memory (vmcnt(0) of every wave precedes the barrier); image of L11 no longer read
+    GPG_FS4(4)
+    GPG_F128_UPDATE()
+    GPG_FS4(5)
+    GPG_F128_IMAGE(64)
+    __syncthreads();
+    GPG_QUAD_SUBST2(x0, x1, Ls, sdinv, q)
+    GPG_FS4(6)
+    GPG_F128_STORE(64)
+    __syncthreads();
+    return 1;
+#undef GPG_F128_RAW
+#undef GPG_F128_IMAGE
+  }
+  __syncthreads();                                             // x1 is out of the image region, *sh may be rewritten
+  // piecewise: L11 / L22 arrive in four 16-column pieces each while the diagonal task is still at work
+#define GPG_F128_PIECE(FL, LP, DOFF, S)                                                      \
+  {                                                                                         \
+    if (!wg_wait_flag2(FL##0 + (S), FL##1 + (S), abort_word, info0, info1, sh)) return 0;    \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                          \
+      const int t = tid + 256 * u, jj = 16 * (S) + (t >> 6), k = t & 63;                     \
+      Ls[jj][k & 3][k >> 2] = (LP)[k + (size_t)jj * ldl];                                    \
+    }                                                                                       \
+    if (tid < 16) sdinv[16 * (S) + tid] = dinv[(DOFF) + 16 * (S) + tid];                     \
+    __syncthreads();                                                                        \
+    GPG_QUAD_SUBST2_PIECE(x0, x1, Ls, sdinv, q, S)                                           \
+    _Pragma("unroll") for (int m = 0; m < 16; ++m) { asm volatile("" : "+v"(x0[m])); asm volatile("" : "+v"(x1[m])); } \
+  }
+  GPG_F128_PIECE(pa, L, 0, 0)
+  GPG_F128_PIECE(pa, L, 0, 1)
+  GPG_F128_PIECE(pa, L, 0, 2)
+  GPG_F128_PIECE(pa, L, 0, 3)
+  GPG_F128_STORE(0)
+  if (!wg_wait_flag2(fc0, fc1, abort_word, info0, info1, sh)) return 0;   // barrier inside: X1 in memory, L21 final
+  GPG_F128_UPDATE()
+  {
+    const double* L22 = L + 64 + (size_t)64 * ldl;
+    GPG_F128_PIECE(pb, L22, 64, 0)
+    GPG_F128_PIECE(pb, L22, 64, 1)
+    GPG_F128_PIECE(pb, L22, 64, 2)
+    GPG_F128_PIECE(pb, L22, 64, 3)
+  }
+  GPG_F128_STORE(64)
+  __syncthreads();
   return 1;
+#undef GPG_F128_PIECE
+#undef GPG_F128_UPDATE
+#undef GPG_F128_STORE
+}
+
+
+// fin128_diag: finalisation of a DIAGONAL 128 x 128 tile (both 128-tile kernels; SET as in fin128_offdiag).  On entry the top-left
+// 64 x 64 block sits in the team's LDS tile (written by wave 0 of the team), A21 / A22 in memory:
+//     L11 = chol(A11) (potrf64_wg; published in four 16-column pieces, early flags pa), L21 = A21 L11^-T (flag_c),
+//     A22 -= L21 L21^T on MFMA, L22 = chol(A22) (pieces pb).
+// Arguments as for fin128_offdiag: the ticket and the kernel's argument segment.
+template <int SET>
+__device__ __noinline__ int fin128_diag(int tix_v, unsigned long long kernarg_bits) {
+  constexpr int SA = 80;
+  GPG_KERNARGS_FROM(TileCholArgs, ap, kernarg_bits);
+  const int tix = __builtin_amdgcn_readfirstlane(tix_v);
+  const int Mt = ap->Mt, ld = ap->ld, N = ap->N;
+  int task, b;
+  if constexpr (SET == 2) {
+    task = ap->tasks[tix];
+    b = ap->batch_of ? ap->batch_of[tix] : 0;
+  } else {
+    task = ap->tasks[2 * tix + SET];
+    b = ap->batch_of[2 * tix + SET];
+  }
+  const int tj = task >> 16;
+  double* const A = ap->A + (size_t)b * ap->a_stride;
+  double* const dinv = ap->dinv + (size_t)b * ap->d_stride;
+  int* const info = ap->info + b;
+  int* const early = ap->pieces + (size_t)b * ap->f_stride;
+  int* const pa = early + 4 * tj;
+  int* const pb = early + 4 * Mt + 4 * tj;
+  int* const flag_c = early + 8 * Mt + tj;
+  const size_t cj = 128 * (size_t)tj;
+  double* const U = fin128_U<SET>();
+  double (*const Ls)[4][18] = fin128_Ls<SET>();
+  double* const sdinv = fin128_sdinv<SET>();
+  const int tid = SET == 2 ? (int)threadIdx.x : (int)(threadIdx.x & 255), lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, l4 = lane >> 4;
+  double* blk = A + cj + cj * (size_t)ld;
+  double (*St)[64] = reinterpret_cast<double(*)[64]>(&Ls[0][0][0]);   // potrf scratch over the image region
+  __syncthreads();   // A11 was left in the LDS tile by wave 0; the other waves' stores of A21 / A22 are drained below
+  {
+    const int bad = potrf64_wg(U, SA, St, blk, ld, dinv + cj, pa, tid);   // L11 published in 16-column pieces pa[0..3]
+    if (w == 0 && bad && lane == 0 && (int)cj + bad - 1 < N) atomicCAS(info, 0, (int)cj + bad);
+  }
+  __syncthreads();   // also drains the other waves' stores of A21 / A22
+  panel_solve_rows64(blk, ld, dinv + cj, blk + 64, ld, 64, 64, U, Ls, sdinv, tid);   // L21 = A21 L11^-T
+  GPG_RELEASE();     // L21 is final (every thread stored part of it; the solve ended with a barrier)
+  __syncthreads();
+  if (tid == 0) GPG_FLAG_UP(flag_c);
+  const int sp = tid & 31, sk = tid >> 5;
+  d4 a2[4];
+  const double* C2 = blk + 64 + 16 * w + l15 + (size_t)(64 + l4) * ld;
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) a2[ni][r] = C2[(size_t)(ni * 16 + 4 * r) * ld];
+  const double* g21 = blk + 64 + 2 * sp + (size_t)sk * ld;
+  wave_tile_gemm(a2, g21, ld, g21, ld, 4, U, U + 2 * 16 * SA, w, l15, l4, sp, sk);
+  __syncthreads();
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) U[(ni * 16 + 4 * r + l4) * SA + 16 * w + l15] = a2[ni][r];
+  __syncthreads();
+  {
+    const int bad = potrf64_wg(U, SA, St, blk + 64 + (size_t)64 * ld, ld, dinv + cj + 64, pb, tid);   // L22: pb[0..3]
+    if (w == 0 && bad && lane == 0 && (int)cj + 64 + bad - 1 < N) atomicCAS(info, 0, (int)cj + 64 + bad);
+  }
+  return 1;
+}
+
+// ONE call site per task: with a call in each branch of `diagonal ? ... : ...` (and an early return after each) the compiler lays the two
+// branches out one after the other, the accumulators of the second stay live across the call of the first, and all 240 live VGPRs
+// are saved to scratch and reloaded around it (seen in the ISA, round 3).
+template <int SET>
+__device__ __noinline__ int fin128_task(int tix_v, unsigned long long kernarg_bits, int is_diag) {
+  return __builtin_amdgcn_readfirstlane(is_diag) ? fin128_diag<SET>(tix_v, kernarg_bits) : fin128_offdiag<SET>(tix_v, kernarg_bits);
 }
 
 __device__ __forceinline__ bool
 tile128_chol_task(int tix, double* A, int ld, int Mt, const int* __restrict__ tasks, int* flags, int* early /* pa | pb | flag_c */, int* abort_word,
                   int* ticket, double* __restrict__ dinv, int* __restrict__ info, int N, const int* __restrict__ batch_of, size_t a_stride,
-                  int d_stride, int f_stride) {
+                  int d_stride, int f_stride, unsigned long long kbits) {
   __shared__ int sh_kr;
   const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w & 1, wn = w >> 1;
@@ -678,34 +927,63 @@ tile128_chol_task(int tix, double* A, int ld, int Mt, const int* __restrict__ ta
 #endif
   GPG_PRIO_FIN(ti - tj)
   direct_tile_negate(acc);
-  // ---- (2) the updated tile goes back to memory; the finalisation works on it in place.  Diagonal tile: the
-  //      top-left 64 x 64 block goes straight into the LDS tile its own wave factors next, the strictly upper
-  //      block is dropped. ---------------------------------------------------------------------------------------
-  if (ti == tj && w == 0) {
+  // (the store addresses are formed HERE: derived from Cw before the loop, the compiler keeps all 32 of them alive across the MFMA
+  // loop, spilled, and reloads them one memory round trip at a time)
+  double* Cs = Cw;
+  asm volatile("" : "+v"(Cs));
+  // (likewise the lane indices: every LDS / memory address below is a pure function of the lane, i.e. invariant over the kernel's
+  // task loop -- hoisted out of it, ~130 of them stay alive through every MFMA loop and every call, in scratch)
+  int l15s = l15, l4s = l4;
+  asm volatile("" : "+v"(l15s), "+v"(l4s));
+  // ---- (2) Diagonal tile: the top-left 64 x 64 block goes straight into the LDS tile its own wave factors next, the strictly
+  //      upper block is dropped, the rest goes to memory and is finalised in place (fin128_diag).  Tile below the diagonal:
+  //      column block 0 is handed to fin128_offdiag through LDS, column block 1 goes to memory. -----------------------------------
+  if (ti == tj) {
+    if (w == 0) {
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
+      for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          t128_U[(32 * (ni >> 1) + 8 * r + 2 * l4 + (ni & 1)) * 80 + 32 * (mi >> 1) + 2 * l15 + (mi & 1)] = acc[ni][mi][r];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  } else if (!(ti == tj && wm == 0)) {
+          for (int r = 0; r < 4; ++r)
+            t128_U[(32 * (ni >> 1) + 8 * r + 2 * l4s + (ni & 1)) * 80 + 32 * (mi >> 1) + 2 * l15s + (mi & 1)] = acc[ni][mi][r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else if (wm != 0) {
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
+      for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-      for (int g = 0; g < 2; ++g)
+        for (int g = 0; g < 2; ++g)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          double2 v;
-          v.x = acc[ni][2 * g][r];
-          v.y = acc[ni][2 * g + 1][r];
-          *reinterpret_cast<double2*>(Cw + 32 * g + (size_t)(32 * (ni >> 1) + 8 * r + (ni & 1)) * ld) = v;
-        }
+          for (int r = 0; r < 4; ++r) {
+            double2 v;
+            v.x = acc[ni][2 * g][r];
+            v.y = acc[ni][2 * g + 1][r];
+            *reinterpret_cast<double2*>(Cs + 32 * g + (size_t)(32 * (ni >> 1) + 8 * r + (ni & 1)) * ld) = v;
+          }
+    }
+#ifdef GPG_STAMP
+    if (tid == 0) t128_fo = nullptr;
+#endif
+  } else {
+    if (wn == 0) fin128_handoff_block0<2>(acc, wm, l15s, l4s);
+    else {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            double2 v;
+            v.x = acc[ni][2 * g][r];
+            v.y = acc[ni][2 * g + 1][r];
+            *reinterpret_cast<double2*>(Cs + 32 * g + (size_t)(32 * (ni >> 1) + 8 * r + (ni & 1)) * ld) = v;
+          }
+    }
+#ifdef GPG_STAMP
+    if (tid == 0) t128_fo = (g_stamp_buf != nullptr && tix < GPG_STAMP_MAX) ? g_stamp_buf + (size_t)GPG_STAMP_MAX * 8 + (size_t)tix * 8 : nullptr;
+#endif
   }
-  if (ti != tj) __syncthreads();
-  if (tile128_finalize(A, ld, r0, cj, ti == tj, early + 4 * tj, early + 4 * Mt + 4 * tj, early + 8 * Mt + tj, abort_word, dinv, info,
-                       N, tix) == 0) return false;
+  if (fin128_task<2>(tix, kbits, ti == tj) == 0) return false;
   // ---- (3) publish (and fetch the next ticket) --------------------------------------------------------------------
   GPG_PUBLISH_AND_NEXT(ticket, frow_i + tj)
 #ifdef GPG_STAMP
@@ -730,7 +1008,7 @@ __global__ void __launch_bounds__(256, 2) tile128_chol_kernel(TileCholArgs) {   
     // inlined here (its MFMA loop wants every VGPR: a separate function would save / restore ~100 callee-saved registers
     // through scratch per task); re-reading the arguments per iteration keeps them out of the loop-carried SGPRs
     if (!tile128_chol_task(tix, ap->A, ap->ld, ap->Mt, ap->tasks, ap->flags, ap->pieces, ap->abort_word, ap->ticket, ap->dinv, ap->info,
-                           ap->N, ap->batch_of, ap->a_stride, ap->d_stride, ap->f_stride))
+                           ap->N, ap->batch_of, ap->a_stride, ap->d_stride, ap->f_stride, (unsigned long long)ap))
       return;                                             // aborted: every workgroup drains
     tix = __builtin_amdgcn_readfirstlane(g_next_ticket);
   }
@@ -756,185 +1034,10 @@ __global__ void __launch_bounds__(256, 2) tile128_chol_kernel(TileCholArgs) {   
 #ifndef GPG_PAIR_KSYNC
 #define GPG_PAIR_KSYNC 8
 #endif
-__shared__ __attribute__((aligned(16))) double p128_U[2][4 * 16 * 80];    // per team: staging / transposition tile of the finalisation
-__shared__ __attribute__((aligned(16))) double p128_Ls[2][64][4][18];     // per team: diagonal-block image / potrf scratch
-__shared__ double p128_sdinv[2][64];
-__shared__ int p128_sh_ok;            // result of the joint flag waits: ONE word for both teams (a function-local __shared__ would be one per template instance)
-
-// Both flags up?  Thread 0 of the workgroup polls; 0 = timed out / aborted (both matrices are marked).
-__device__ __forceinline__ int wg_wait_flag2(int* fa, int* fb, int* abort_word, int* info_a, int* info_b, int* sh) {
-  if (threadIdx.x == 0) {
-    int ok = 1;
-    const unsigned long long t_wait = __builtin_amdgcn_s_memrealtime();
-    while (__hip_atomic_load(fa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 ||
-           __hip_atomic_load(fb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-      if (__builtin_amdgcn_s_memrealtime() - t_wait > GPG_TILE_WAIT_TICKS || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-        __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        atomicMax(info_a, GPG_INFO_INTERNAL);
-        atomicMax(info_b, GPG_INFO_INTERNAL);
-        ok = 0;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(8);
-    }
-    *sh = ok;
-  }
-  __syncthreads();
-  const int ok = *sh;
-  __syncthreads();
-  if (ok) GPG_ACQUIRE();
-  return ok;
-}
-
-// tile_solve_rows128 for the two teams of a pair: team-local row tile X against ITS matrix's diagonal tile L (the same tile for an
-// ordinary pair), every wait taken for both teams at once.  pa / pb / flag_c: [2] early-flag pointers of the two teams' matrices.
-__device__ __forceinline__ int pair_solve_rows128(const double* L, int ldl, const double* dinv, double* X, int ldx, double* U,
-                                                  double (*Ls)[4][18], double* sdinv, int* pa0, int* pa1, int* fc0, int* fc1, int* pb0,
-                                                  int* pb1, int* abort_word, int* info0, int* info1, int* sh, int tid) {
-  constexpr int SA = 80, BUF = 16 * SA;
-  const int lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l15 = lane & 15, l4 = lane >> 4;
-  const int q = tid & 3, rr = tid >> 2;
-  const int sp = tid & 31, sk = tid >> 5;
-  double x0[16], x1[16];
-  {
-    const double* Xr = X + rr + (size_t)q * ldx;
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-      x0[m] = Xr[(size_t)(4 * m) * ldx];
-      x1[m] = Xr[64 + (size_t)(4 * m) * ldx];
-    }
-  }
-#define GPG_P128_PIECE(FL, LP, DOFF, S)                                                      \
-  {                                                                                         \
-    if (!wg_wait_flag2(FL##0 + (S), FL##1 + (S), abort_word, info0, info1, sh)) return 0;    \
-    _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                          \
-      const int t = tid + 256 * u, jj = 16 * (S) + (t >> 6), k = t & 63;                     \
-      Ls[jj][k & 3][k >> 2] = (LP)[k + (size_t)jj * ldl];                                    \
-    }                                                                                       \
-    if (tid < 16) sdinv[16 * (S) + tid] = dinv[(DOFF) + 16 * (S) + tid];                     \
-    __syncthreads();                                                                        \
-    GPG_QUAD_SUBST2_PIECE(x0, x1, Ls, sdinv, q, S)                                           \
-    _Pragma("unroll") for (int m = 0; m < 16; ++m) { asm volatile("" : "+v"(x0[m])); asm volatile("" : "+v"(x1[m])); } \
-  }
-  GPG_P128_PIECE(pa, L, 0, 0)
-  GPG_P128_PIECE(pa, L, 0, 1)
-  GPG_P128_PIECE(pa, L, 0, 2)
-  GPG_P128_PIECE(pa, L, 0, 3)
-  {
-    double* Xr = X + rr + (size_t)q * ldx;
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-      GPG_ST(&Xr[(size_t)(4 * m) * ldx], x0[m]);
-      GPG_ST(&Xr[64 + (size_t)(4 * m) * ldx], x1[m]);
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // X1 of this team in memory before the barrier inside the wait
-  if (!wg_wait_flag2(fc0, fc1, abort_word, info0, info1, sh)) return 0;
-#pragma unroll
-  for (int hh = 0; hh < 2; ++hh) {
-    d4 acc[4];
-    const double* Cw = X + 64 * hh + 16 * w + l15 + (size_t)(64 + l4) * ldx;
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[ni][r] = Cw[(size_t)(ni * 16 + 4 * r) * ldx];
-    wave_tile_gemm(acc, X + 64 * hh + 2 * sp + (size_t)sk * ldx, ldx, L + 64 + 2 * sp + (size_t)sk * ldl, ldl, 4, U, U + 2 * BUF,
-                   w, l15, l4, sp, sk);
-    __syncthreads();
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) U[(ni * 16 + 4 * r + l4) * SA + 16 * w + l15] = acc[ni][r];
-    __syncthreads();
-    const double* Tr = U + q * SA + rr;
-    if (hh == 0) {
-#pragma unroll
-      for (int m = 0; m < 16; ++m) x0[m] = Tr[(4 * m) * SA];
-    } else {
-#pragma unroll
-      for (int m = 0; m < 16; ++m) x1[m] = Tr[(4 * m) * SA];
-    }
-    __syncthreads();
-  }
-  {
-    const double* L22 = L + 64 + (size_t)64 * ldl;
-    GPG_P128_PIECE(pb, L22, 64, 0)
-    GPG_P128_PIECE(pb, L22, 64, 1)
-    GPG_P128_PIECE(pb, L22, 64, 2)
-    GPG_P128_PIECE(pb, L22, 64, 3)
-  }
-#undef GPG_P128_PIECE
-  {
-    double* Xr = X + rr + (size_t)(64 + q) * ldx;
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-      GPG_ST(&Xr[(size_t)(4 * m) * ldx], x0[m]);
-      GPG_ST(&Xr[64 + (size_t)(4 * m) * ldx], x1[m]);
-    }
-  }
-  __syncthreads();
-  return 1;
-}
-
-// Finalisation of a pair whose updated tiles sit in memory (diagonal tiles: top-left block in the team's LDS tile), out of line like
-// tile128_finalize.  A / dinv: this thread's team; pa0 / pa1, ...: early flags and info words of the two teams' matrices (uniform).
-// One instance per team (H): the team's LDS arrays must be addressed statically -- through a pointer selected at run time the compiler
-// pre-loads the substitution's L image and spills it (2.3 KB of scratch against 0.4 KB) -- and both instances issue the same barriers.
-template <int H>
-__device__ __noinline__ int pair128_finalize(double* A, int ld, size_t r0, size_t cj, int is_diag, int* pa0, int* pa1, int* pb0, int* pb1,
-                                             int* fc0, int* fc1, int* abort_word, double* dinv, int* info0, int* info1, int N) {
-  constexpr int SA = 80;
-  constexpr int h = H;
-  const int tid = threadIdx.x & 255, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l15 = lane & 15, l4 = lane >> 4;
-  double* const U = p128_U[H];
-  double (*const Ls)[4][18] = p128_Ls[H];
-  double* const sdinv = p128_sdinv[H];
-  if (is_diag) {
-    double* blk = A + cj + cj * (size_t)ld;
-    double (*St)[64] = reinterpret_cast<double(*)[64]>(&Ls[0][0][0]);
-    __syncthreads();
-    {
-      const int bad = potrf64_wg(U, SA, St, blk, ld, dinv + cj, h ? pa1 : pa0, tid);
-      if (w == 0 && bad && lane == 0 && (int)cj + bad - 1 < N) atomicCAS(h ? info1 : info0, 0, (int)cj + bad);
-    }
-    __syncthreads();
-    panel_solve_rows64(blk, ld, dinv + cj, blk + 64, ld, 64, 64, U, Ls, sdinv, tid);
-    GPG_RELEASE();
-    __syncthreads();
-    if (tid == 0) GPG_FLAG_UP(h ? fc1 : fc0);
-    const int sp = tid & 31, sk = tid >> 5;
-    d4 a2[4];
-    const double* C2 = blk + 64 + 16 * w + l15 + (size_t)(64 + l4) * ld;
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) a2[ni][r] = C2[(size_t)(ni * 16 + 4 * r) * ld];
-    const double* g21 = blk + 64 + 2 * sp + (size_t)sk * ld;
-    wave_tile_gemm(a2, g21, ld, g21, ld, 4, U, U + 2 * 16 * SA, w, l15, l4, sp, sk);
-    __syncthreads();
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) U[(ni * 16 + 4 * r + l4) * SA + 16 * w + l15] = a2[ni][r];
-    __syncthreads();
-    {
-      const int bad = potrf64_wg(U, SA, St, blk + 64 + (size_t)64 * ld, ld, dinv + cj + 64, h ? pb1 : pb0, tid);
-      if (w == 0 && bad && lane == 0 && (int)cj + 64 + bad - 1 < N) atomicCAS(h ? info1 : info0, 0, (int)cj + 64 + bad);
-    }
-    return 1;
-  }
-  const double* Ljj = A + cj + cj * (size_t)ld;
-  double* X = A + r0 + cj * (size_t)ld;
-  return pair_solve_rows128(Ljj, ld, dinv + cj, X, ld, U, Ls, sdinv, pa0, pa1, fc0, fc1, pb0, pb1, abort_word, info0, info1, &p128_sh_ok, tid);
-}
-
 __device__ __forceinline__ bool
 pair128_chol_task(int tix, double* Abase, int ld, int Mt, const int* __restrict__ tasks, int* flags_base, int* early_base, int* abort_word,
                   int* ticket, double* __restrict__ dinv_base, int* __restrict__ info_base, int N, const int* __restrict__ batch_of,
-                  size_t a_stride, int d_stride, int f_stride) {
+                  size_t a_stride, int d_stride, int f_stride, unsigned long long kbits) {
   __shared__ int sh_kr;
   const int tid = threadIdx.x, h = __builtin_amdgcn_readfirstlane(tid >> 8), t = tid & 255, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -1016,35 +1119,54 @@ pair128_chol_task(int tix, double* Abase, int ld, int Mt, const int* __restrict_
     kdone = kr;
   }
 
-  // ---- (2) the updated tiles go back to memory (diagonal tiles: top-left block into the team's LDS tile) -------------------------
+  // ---- (2) diagonal tiles: top-left block into the team's LDS tile, the rest to memory; tiles below the diagonal: column block 0
+  //      into LDS for fin128_offdiag, column block 1 to memory -----------------------------------------------------------------------
   direct_tile_negate(acc);
-  if (ti == tj && w == 0) {
+  double* Cs = Cw;                                            // (see tile128_chol_task)
+  asm volatile("" : "+v"(Cs));
+  int l15s = l15, l4s = l4;
+  asm volatile("" : "+v"(l15s), "+v"(l4s));
+  if (ti0 == tj) {
+    if (w == 0) {
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
+      for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          (h ? p128_U[1] : p128_U[0])[(32 * (ni >> 1) + 8 * r + 2 * l4 + (ni & 1)) * 80 + 32 * (mi >> 1) + 2 * l15 + (mi & 1)] = acc[ni][mi][r];
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  } else if (!(ti == tj && wm == 0)) {
+          for (int r = 0; r < 4; ++r)
+            (h ? p128_U[1] : p128_U[0])[(32 * (ni >> 1) + 8 * r + 2 * l4s + (ni & 1)) * 80 + 32 * (mi >> 1) + 2 * l15s + (mi & 1)] = acc[ni][mi][r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    } else if (wm != 0) {
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
+      for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-      for (int g = 0; g < 2; ++g)
+        for (int g = 0; g < 2; ++g)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          double2 v;
-          v.x = acc[ni][2 * g][r];
-          v.y = acc[ni][2 * g + 1][r];
-          *reinterpret_cast<double2*>(Cw + 32 * g + (size_t)(32 * (ni >> 1) + 8 * r + (ni & 1)) * ld) = v;
-        }
+          for (int r = 0; r < 4; ++r) {
+            double2 v;
+            v.x = acc[ni][2 * g][r];
+            v.y = acc[ni][2 * g + 1][r];
+            *reinterpret_cast<double2*>(Cs + 32 * g + (size_t)(32 * (ni >> 1) + 8 * r + (ni & 1)) * ld) = v;
+          }
+    }
+  } else {
+    if (wn == 0) {
+      if (h) fin128_handoff_block0<1>(acc, wm, l15s, l4s); else fin128_handoff_block0<0>(acc, wm, l15s, l4s);
+    } else {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            double2 v;
+            v.x = acc[ni][2 * g][r];
+            v.y = acc[ni][2 * g + 1][r];
+            *reinterpret_cast<double2*>(Cs + 32 * g + (size_t)(32 * (ni >> 1) + 8 * r + (ni & 1)) * ld) = v;
+          }
+    }
   }
-  if (ti0 != tj) __syncthreads();
-  if ((h ? pair128_finalize<1>(A, ld, r0, cj, ti0 == tj, ea0 + 4 * tj, ea1 + 4 * tj, ea0 + 4 * Mt + 4 * tj, ea1 + 4 * Mt + 4 * tj, ea0 + 8 * Mt + tj,
-                                ea1 + 8 * Mt + tj, abort_word, dinv, info0, info1, N)
-         : pair128_finalize<0>(A, ld, r0, cj, ti0 == tj, ea0 + 4 * tj, ea1 + 4 * tj, ea0 + 4 * Mt + 4 * tj, ea1 + 4 * Mt + 4 * tj, ea0 + 8 * Mt + tj,
-                               ea1 + 8 * Mt + tj, abort_word, dinv, info0, info1, N)) == 0) return false;
+  if ((h ? fin128_task<1>(tix, kbits, ti0 == tj) : fin128_task<0>(tix, kbits, ti0 == tj)) == 0) return false;
   // ---- (3) publish both tiles (and fetch the next ticket) --------------------------------------------------------------------------
   {
     int nxt_ = 0;
@@ -1070,7 +1192,7 @@ __global__ void __launch_bounds__(512, 1) pair128_chol_kernel(TileCholArgs) {   
     GPG_KERNARGS(TileCholArgs, ap);
     if (tix >= ap->ntask) return;
     if (!pair128_chol_task(tix, ap->A, ap->ld, ap->Mt, ap->tasks, ap->flags, ap->pieces, ap->abort_word, ap->ticket, ap->dinv, ap->info,
-                           ap->N, ap->batch_of, ap->a_stride, ap->d_stride, ap->f_stride))
+                           ap->N, ap->batch_of, ap->a_stride, ap->d_stride, ap->f_stride, (unsigned long long)ap))
       return;
     tix = __builtin_amdgcn_readfirstlane(g_next_ticket);
   }
@@ -1984,7 +2106,14 @@ static void launch_tile_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a_st
 }
 
 // The whole matrix with the 128-tile dataflow kernel, on c->stream.
+static void launch_tile128_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a_stride, double* dinv_base, int d_stride, int* info_base);
+static bool pair128_wanted(const gpg_ctx* c, int B);
 static void launch_tile128_chol(gpg_ctx* c) {
+  c->last_launch_paired = false;
+  if (!c->chol_flags_override && pair128_wanted(c, 1)) {     // (the overlapped inverse reads this launch's flags: one tile per workgroup then)
+    launch_tile128_chol_batch(c, 1, c->A, 0, c->dinv, 0, c->info);
+    return;
+  }
   const int Mt = c->Npad / 128, Rt = c->ld / 128;
   const TileMap& tm = get_tile_tasks(c, Mt, Rt, false);
   if (!tm.dev) return;
@@ -2034,6 +2163,12 @@ static void build_pair_tasks(int Mt, int Rt, int B, std::vector<int>& list, std:
   }
 }
 
+static bool pair128_wanted(const gpg_ctx* c, int B) {
+  if (c->pair_mode == 1) return true;
+  if (c->pair_mode != 2) return false;
+  return B >= 2 ? c->Npad >= 16384 : c->Npad >= c->pair_single_cols;
+}
+
 // The same for B matrices at once (see launch_tile_chol_batch): at the two ends of a factorisation the dependency
 // chain leaves most of the chip idle, and a second matrix fills it.
 static void launch_tile128_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a_stride, double* dinv_base, int d_stride,
@@ -2042,7 +2177,9 @@ static void launch_tile128_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a
   // pair128_chol_kernel (512-thread workgroups, two tiles of a tile column each): same speed as tile128_chol_kernel from ~16k columns
   // on (ten cfg3 matrices 298.6 / 297.4 ms) with a quarter less memory traffic (87 against 120 GB per matrix), slower below (2560
   // columns x 64: 9.2 / 8.8 ms: the finalisations of a pair are not hidden behind another workgroup's MFMA loop)
-  const bool pair = B >= 2 && (c->pair_mode == 1 || (c->pair_mode == 2 && c->Npad >= 16384));
+  // One very large matrix per launch (cfg5: 532 tile columns): the rows of a tile column still pair up; only its diagonal tile has no
+  // partner and is given to both teams (532 of 142 000 tasks).
+  const bool pair = pair128_wanted(c, B);
   const unsigned long long key = (2ull << 62) | (1ull << 61) | ((unsigned long long)(c->task_order & 1) << 60) | ((unsigned long long)(pair ? 1 : 0) << 59) |
                                  ((unsigned long long)B << 40) | ((unsigned long long)Mt << 20) | (unsigned)Rt;
   auto it = c->tilemaps.find(key);
@@ -2067,6 +2204,7 @@ static void launch_tile128_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a
   int* abort_word = c->tile_flags + (size_t)Mt * Rt;
   const TileCholArgs args{Abase, c->ld, 0, Mt, tm.dev, tm.n, c->tile_flags, abort_word + 1, abort_word, c->tile_flags + (nflag - 8),
                           dinv_base, info_base, c->N, tm.dev + nlist, a_stride, d_stride, (int)per};
+  c->last_launch_paired = pair;
   if (pair)
     hipLaunchKernelGGL(pair128_chol_kernel, dim3(persistent_grid(c, pair128_chol_kernel, tm.n, 512)), dim3(512), 0, c->stream, args);
   else
@@ -2278,7 +2416,7 @@ void gpg_launch_tile_chol(gpg_ctx* c, int c0) {
 }
 void gpg_launch_tile128_chol(gpg_ctx* c) {
   launch_tile128_chol(c);
-  c->last_factor_kernel = 2; c->last_factor_batch = 1;
+  c->last_factor_kernel = c->last_launch_paired ? 3 : 2; c->last_factor_batch = 1;
 }
 // ---- value + gradient of ONE small matrix: W = L^-T overlapped with the factorisation ------------------------------------------------
 // The two chains (factorisation: one diagonal tile after the other; W = L^-T: one tile column after the other) are each latency-bound on
@@ -2418,6 +2556,6 @@ void gpg_launch_tile_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a_strid
   const bool use128 = batch_uses_tile128(c, B);
   if (use128) launch_tile128_chol_batch(c, B, Abase, a_stride, dinv_base, d_stride, info_base);
   else launch_tile_chol_batch(c, B, Abase, a_stride, dinv_base, d_stride, info_base);
-  c->last_factor_kernel = use128 ? 2 : 1;
+  c->last_factor_kernel = use128 ? (c->last_launch_paired ? 3 : 2) : 1;
   c->last_factor_batch = B;
 }

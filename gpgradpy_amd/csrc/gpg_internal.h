@@ -62,7 +62,8 @@ struct gpg_ctx {
   int nb_outer = 256;   // panel width
   bool launch_error = false;  // a launch helper could not allocate its scratch / task list: nothing was launched (checked by the API call)
   int factor_fallbacks = 0;   // times a dataflow launch timed out and the call was repeated with the blocked schedule
-  int last_factor_kernel = 0; // schedule of the most recent factorisation launch: 0 blocked, 1 64-tile, 2 128-tile dataflow
+  int last_factor_kernel = 0; // schedule of the most recent factorisation launch: 0 blocked, 1 64-tile, 2 128-tile dataflow, 3 128-tile pairs
+  bool last_launch_paired = false;
   int last_factor_batch = 0;  // matrices it factorised
   int chol_impl = 0;    // 1: whole factorisation by the 128-tile dataflow kernel
   int tail_cols = 0;    // trailing block of at most this many columns goes to the dataflow tile kernel (0: off)
@@ -92,6 +93,7 @@ struct gpg_ctx {
   int fuse_subdiag = 1;        // 64-tile factorisation: diagonal tasks own the sub-diagonal tile below the previous diagonal tile (tile_chol_task)
   int pair_mode = 2;           // batched 128-tile launches (B >= 2) by pair128_chol_kernel (two tiles of a tile column per 512-thread workgroup):
                                // 0 never, 1 always, 2 from 16384 padded columns on (env GPG_PAIR)
+  int pair_single_cols = 1 << 30;   // pair_mode 2: ONE matrix per launch goes to pair128_chol_kernel from this many padded columns on
   int task_order = 0;          // ticket order of the dataflow factorisation (for_each_chol_task in cholesky_dataflow.hip)
   double grad_eta = -1.0;      // >= 0: nugget the hyperparameter derivatives are formed with instead of hp->eta (gpg_set_gradient_nugget)
   int max_workgroups = 0;      // > 0: cap on the grid of every persistent launch (gpg_set_max_workgroups; 0 = co-resident capacity)

@@ -1458,11 +1458,11 @@ class GaussianProcess(HparaOptz):
         return cond, self._cond_grad_from_vectors(hp_struct, cond, lam_min, v_max, v_min)
 
     def last_factor(self):
-        """(schedule, matrices) of the most recent factorisation launch: 'blocked' | 'tile64' | 'tile128'."""
+        """(schedule, matrices) of the most recent factorisation launch: 'blocked' | 'tile64' | 'tile128' | 'pair128'."""
         import ctypes as C
         k, b = C.c_int(0), C.c_int(0)
         self._lib.gpg_last_factor(self._ctx, C.byref(k), C.byref(b))
-        return ('blocked', 'tile64', 'tile128')[k.value], b.value
+        return ('blocked', 'tile64', 'tile128', 'pair128')[k.value], b.value
 
     def download_chofac(self):
         """(P L, True) of the factor currently on the device (Kernel.py:252) as a SciPy cho_factor pair."""

@@ -305,8 +305,15 @@ int gpg_factor_fallbacks(gpg_ctx* ctx);
 int gpg_overlap_fallbacks(gpg_ctx* ctx);
 int gpg_solve_fallbacks(gpg_ctx* ctx);
 /* Schedule of the most recent factorisation launch (for logs / bench): *kernel = 0 blocked, 1 dataflow with 64 x 64
- * tiles, 2 dataflow with 128 x 128 tiles; *matrices = how many matrices that launch factorised.  Either may be NULL. */
+ * tiles, 2 dataflow with 128 x 128 tiles, 3 dataflow with pairs of 128 x 128 tiles per workgroup (batched launches of large
+ * matrices); *matrices = how many matrices that launch factorised.  Either may be NULL. */
 int gpg_last_factor(gpg_ctx* ctx, int* kernel, int* matrices);
+/* Batched launches of the 128 x 128-tile schedule (gpg_lkd_batch on large matrices) can give every 512-thread workgroup a PAIR of tiles of
+ * one tile column: both tiles then share the row panel they read as the second operand (a quarter less memory traffic), at the
+ * price of finalisations that are not hidden behind another workgroup's MFMA loop.  mode 0: never, 1: whenever a launch holds at
+ * least two matrices, 2 (default): from 16384 padded columns on, where the two schedules are equally fast.  Results are
+ * bit-identical in all three modes. */
+int gpg_set_pair_mode(gpg_ctx* ctx, int mode);
 
 /* Caps the number of persistent workgroups of every dataflow launch (0 = default: as many as the device holds at once).  The
  * launches are correct for ANY number >= 1 -- a workgroup only ever waits for tasks with smaller tickets, all of which are held

@@ -317,6 +317,41 @@ def test_batched_small_matrices_bitwise():
     assert np.isnan(ln[2]) and np.all(np.isfinite(np.delete(ln, 2)))
 
 
+def test_tile_pairs_bitwise_and_progress():
+    """pair128_chol_kernel (two tiles of a tile column per 512-thread workgroup; batched launches): forced on small matrices
+    (gpg_set_pair_mode 1) it must reproduce the one-tile-per-workgroup launch bit for bit -- odd and even numbers of matrices (a
+    diagonal tile without a partner is given to both teams), odd and even numbers of tile rows (left-over tiles pair across
+    matrices), a failing matrix inside the batch -- and finish with any number of resident workgroups."""
+    import gpgradpy_amd
+    from oracle import gp_oracle as orc
+    for n, d, kernel in ((70, 5, 'Ma5f2'), (60, 7, 'SqExp'), (140, 8, 'SqExp')):     # 4, 4 (N = 480 -> 512) and 10 tile rows of 128
+        X, f, g = orc.synthetic_design(n, d, seed=n)
+        for nrows in (2, 5, 8):
+            rows = np.random.default_rng(n + nrows).uniform(-2.5, -0.5, (nrows, d))
+            if nrows == 5:
+                rows[3] = -9.0                                  # all points alike: the factorisation of this row fails
+            res = {}
+            for mode, caps in ((0, (0,)), (1, (0, 1, 3))):
+                GP = gpgradpy_amd.GaussianProcess(d, True, kernel, 'precon')
+                GP.set_data(X, f, np.zeros(n), g, np.zeros((n, d)))
+                if nrows == 5:
+                    GP._etaK = GP._eta_Kgrad = 0.0
+                GP.set_factor_mode('tile128')
+                GP.set_batch(8)
+                assert GP._lib.gpg_set_pair_mode(GP._ctx, mode) == 0
+                for cap in caps:
+                    GP.set_max_workgroups(cap)
+                    out = GP.calc_lkd_batch(rows)
+                    assert GP.last_factor() == (('tile128', 'pair128')[mode], nrows) and GP.factor_fallbacks() == 0
+                    res[(mode, cap)] = out
+                GP.close()
+            ref = res[(0, 0)]
+            if nrows == 5:
+                assert np.isnan(ref[3]) and np.all(np.isfinite(np.delete(ref, 3)))
+            for key, out in res.items():
+                np.testing.assert_array_equal(out, ref, err_msg=str((n, d, nrows, key)))
+
+
 def test_random_small_shapes_against_oracle():
     """Seeded sweep over odd shapes (n = 1 .. 60, d = 1 .. 16, both kernels, three noise models, both schedules of the
     small-matrix regime): N not a multiple of any tile, one to ten tile columns, single-point data sets."""
@@ -522,8 +557,12 @@ def test_full_size_properties():
     hp_x0 = np.random.default_rng(1).uniform(-2.5, -0.5, (3, d))
     ln = GP.calc_lkd_batch(hp_x0)
     assert np.all(np.isfinite(ln))
+    assert GP.last_factor() == ('pair128', 3)                 # three matrices: one pair of diagonal tiles + one tile given to both teams
     one = GP.calc_lkd_all(GP.hp_vec2dataclass(GP.hp_info_optz_lkd, hp_x0[1]))[0].ln_lkd
-    assert one == ln[1]
+    assert one == ln[1] and GP.last_factor() == ('tile128', 1)
+    GP._lib.gpg_set_pair_mode(GP._ctx, 0)                     # the batched launch without pairs: same bits again
+    assert np.array_equal(GP.calc_lkd_batch(hp_x0), ln) and GP.last_factor() == ('tile128', 3)
+    GP._lib.gpg_set_pair_mode(GP._ctx, 2)
 
     perm = np.random.default_rng(2).permutation(n)
     GP2 = gpgradpy_amd.GaussianProcess(d, True, 'SqExp', 'precon')
@@ -564,7 +603,7 @@ def test_cfg5_size_properties():
     # several 37 GB workspaces fit in 288 GB: restart rows are factorised two / three per launch at this size too, bit for bit
     GP.set_batch(2)
     ln_b = GP.calc_lkd_batch(tab[:2])
-    assert GP.last_factor() == ('tile128', 2) and ln_b[0] == ln_df and np.isfinite(ln_b[1])
+    assert GP.last_factor() == ('pair128', 2) and ln_b[0] == ln_df and np.isfinite(ln_b[1])      # (batched, >= 16384 columns: tile pairs)
     GP.set_batch(-1)
     # the adjoint gradient at this size (W = L^-T and -(W W^T) of a 68096-column factor: 532 x 532 tiles, 111 GB of workspaces)
     # against a central difference of the device likelihood in its largest component

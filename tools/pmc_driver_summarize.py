@@ -73,7 +73,8 @@ def col(pass_name, counter, i):
 cmd = open(os.path.join(args.root, "command.txt")).read().strip() if os.path.exists(os.path.join(args.root, "command.txt")) else "?"
 print(f"# rocprofv3 over `{cmd}` (tools/profile_driver.sh): {args.kernel}, one line per dispatch")
 print(f"# FETCH_SIZE / WRITE_SIZE passes are separate runs of the same command; ms (trace) = un-instrumented kernel trace of that command")
-print(f"{'disp':>4s} {'mats':>4s} {'ms (trace)':>10s} {'FETCH GB raw':>12s} {'FETCH GB x2':>11s} {'WRITE GB':>9s} {'traffic GB':>10s} {'per matrix':>10s} {'L2 hit':>6s} {'MFMA busy':>9s} {'TB/s':>6s}")
+print(f"# MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); VALU busy = 4 x SQ_ACTIVE_INST_VALU / the same; GHz = GRBM_GUI_ACTIVE / 8 / duration of that pass")
+print(f"{'disp':>4s} {'mats':>4s} {'ms (trace)':>10s} {'FETCH GB raw':>12s} {'FETCH GB x2':>11s} {'WRITE GB':>9s} {'traffic GB':>10s} {'per matrix':>10s} {'L2 hit':>6s} {'MFMA busy':>9s} {'VALU busy':>9s} {'GHz':>5s} {'TB/s':>6s}")
 entries = []
 for i in range(ndisp):
     fetch = col("pmc_FETCH_SIZE", "FETCH_SIZE", i) * 1024
@@ -81,13 +82,16 @@ for i in range(ndisp):
     hit, miss = col("pmc_TCC_HIT_sum", "TCC_HIT_sum", i), col("pmc_TCC_HIT_sum", "TCC_MISS_sum", i)
     cyc = col("pmc_GRBM_GUI_ACTIVE", "GRBM_GUI_ACTIVE", i) / 8.0
     busy = col("pmc_GRBM_GUI_ACTIVE", "SQ_VALU_MFMA_BUSY_CYCLES", i) / (1024.0 * cyc) if cyc and cyc == cyc else float("nan")
+    ns_pass = col("pmc_GRBM_GUI_ACTIVE", "_ns", i)
+    ghz = cyc / ns_pass if ns_pass and ns_pass == ns_pass and cyc == cyc else float("nan")
+    valu = 4.0 * col("pmc_SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_VALU", i) / (1024.0 * cyc) if cyc and cyc == cyc else float("nan")
     ms = durs[i] if i < len(durs) else float("nan")
     m = mats[i] if i < len(mats) else 1
     traffic = 2 * fetch + write
     print(f"{i:4d} {m:4d} {ms:10.3f} {fetch / 1e9:12.2f} {2 * fetch / 1e9:11.2f} {write / 1e9:9.2f} {traffic / 1e9:10.2f} {traffic / m / 1e9:10.2f} "
-          f"{hit / max(1.0, hit + miss):6.2f} {busy:9.2f} {traffic / (ms * 1e-3) / 1e12 if ms == ms and ms > 0 else float('nan'):6.2f}")
+          f"{hit / max(1.0, hit + miss):6.2f} {busy:9.2f} {valu:9.2f} {ghz:5.2f} {traffic / (ms * 1e-3) / 1e12 if ms == ms and ms > 0 else float('nan'):6.2f}")
     entries.append(dict(config=args.config, kernel=args.kernel, matrices_per_launch=m, fetch_bytes_raw=fetch, write_bytes=write,
-                        traffic_bytes_per_launch=traffic, l2_hit=hit / max(1.0, hit + miss), mfma_busy=busy, launch_ms_trace=ms,
+                        traffic_bytes_per_launch=traffic, l2_hit=hit / max(1.0, hit + miss), mfma_busy=busy, valu_busy=valu, clock_ghz=ghz, launch_ms_trace=ms,
                         source=args.source or f"rocprofv3 --pmc over `{cmd}` (FETCH_SIZE x 2 + WRITE_SIZE)"))
 if args.update:
     try:

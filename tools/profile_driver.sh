@@ -16,7 +16,7 @@ timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/s
 tail -1 $OUT/bench_stats.log > $R/gpurun_out/${TAG}_bench.json
 cp $(find $OUT/stats -name "*kernel_stats.csv" | head -1) $R/gpurun_out/${TAG}_kernel_stats.csv
 cp $(find $OUT/stats -name "*kernel_trace.csv" | head -1) $R/gpurun_out/${TAG}_kernel_trace.csv
-for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY"; do
+for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY" "SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_INSTS_LDS"; do
   tag=$(echo $set | awk '{print $1}')
   timeout -k 10 600 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pmc_$tag -- python3 $R/bench.py $ARGS > $OUT/pmc_$tag.log 2>&1 || { echo "pass $tag failed"; exit 1; }
   echo "pass $tag done"
