@@ -517,11 +517,13 @@ __shared__ __attribute__((aligned(16))) double t128_U[4 * 16 * 80];   // staging
 __shared__ __attribute__((aligned(16))) double t128_Ls[64][4][18];    // diagonal-block image / potrf scratch
 __shared__ double t128_sdinv[64];
 __shared__ int t128_sh_ok;
+__shared__ int t128_sh2[2];           // verdict on the NEXT 16-column piece (fin128_offdiag; two words used alternately: a barrier lies between two uses of one)
 
 // LDS of pair128_chol_kernel (512 threads = two teams; defined here because fin128_offdiag serves both 128-tile kernels)
 __shared__ __attribute__((aligned(16))) double p128_U[2][4 * 16 * 80];    // per team: staging / transposition tile of the finalisation
 __shared__ __attribute__((aligned(16))) double p128_Ls[2][64][4][18];     // per team: diagonal-block image / potrf scratch
 __shared__ double p128_sdinv[2][64];
+__shared__ int p128_sh2[2];
 __shared__ int p128_sh_ok;            // result of the joint flag waits: ONE word for both teams (a function-local __shared__ would be one per template instance)
 
 // Both flags up?  Thread 0 of the workgroup polls; 0 = timed out / aborted (both matrices are marked).
@@ -570,6 +572,7 @@ template <int SET> __device__ __forceinline__ double* fin128_U() { if constexpr 
 template <int SET> __device__ __forceinline__ double (*fin128_Ls())[4][18] { if constexpr (SET == 2) return t128_Ls; else return p128_Ls[SET]; }
 template <int SET> __device__ __forceinline__ double* fin128_sdinv() { if constexpr (SET == 2) return t128_sdinv; else return p128_sdinv[SET]; }
 template <int SET> __device__ __forceinline__ int* fin128_sh() { if constexpr (SET == 2) return &t128_sh_ok; else return &p128_sh_ok; }
+template <int SET> __device__ __forceinline__ int* fin128_sh2() { if constexpr (SET == 2) return t128_sh2; else return p128_sh2; }
 // the caller's side of the LDS hand-over (inlined into the task: the accumulators are in its registers)
 template <int SET>
 __device__ __forceinline__ void fin128_handoff_block0(const d4 (&acc)[4][4], int wm, int l15, int l4) {
@@ -624,6 +627,7 @@ __device__ __noinline__ int fin128_offdiag(int tix_v, unsigned long long kernarg
   double (*const Ls)[4][18] = fin128_Ls<SET>();
   double* const sdinv = fin128_sdinv<SET>();
   int* const sh = fin128_sh<SET>();
+  int* const sh2 = fin128_sh2<SET>();
   const int tid = SET == 2 ? (int)threadIdx.x : (int)(threadIdx.x & 255), lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, l4 = lane >> 4;
@@ -723,15 +727,36 @@ __device__ __noinline__ int fin128_offdiag(int tix_v, unsigned long long kernarg
   }
   __syncthreads();                                             // x1 is out of the image region, *sh may be rewritten
   // piecewise: L11 / L22 arrive in four 16-column pieces each while the diagonal task is still at work
+  // A piece whose flag is already up while the previous piece is being substituted is fetched into registers behind that
+  // substitution (pf = 1): its turn then starts with the LDS write instead of a flag poll, two barriers and a dependent load.
+  double lp4[4];
+  int pf = 0;
 #define GPG_F128_PIECE(FL, LP, DOFF, S)                                                      \
   {                                                                                         \
-    if (!wg_wait_flag2(FL##0 + (S), FL##1 + (S), abort_word, info0, info1, sh)) return 0;    \
+    if (!pf) {                                                                              \
+      if (!wg_wait_flag2(FL##0 + (S), FL##1 + (S), abort_word, info0, info1, sh)) return 0;  \
+      _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                        \
+        const int t = tid + 256 * u, jj = 16 * (S) + (t >> 6), k = t & 63;                   \
+        lp4[u] = (LP)[k + (size_t)jj * ldl];                                                 \
+      }                                                                                     \
+    }                                                                                       \
     _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                          \
       const int t = tid + 256 * u, jj = 16 * (S) + (t >> 6), k = t & 63;                     \
-      Ls[jj][k & 3][k >> 2] = (LP)[k + (size_t)jj * ldl];                                    \
+      Ls[jj][k & 3][k >> 2] = lp4[u];                                                        \
     }                                                                                       \
     if (tid < 16) sdinv[16 * (S) + tid] = dinv[(DOFF) + 16 * (S) + tid];                     \
+    if ((S) < 3 && threadIdx.x == 0)                                                         \
+      sh2[(S) & 1] = __hip_atomic_load(FL##0 + (S) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 && \
+             __hip_atomic_load(FL##1 + (S) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;  \
     __syncthreads();                                                                        \
+    pf = (S) < 3 ? sh2[(S) & 1] : 0;                                                        \
+    if (pf) {                                                                               \
+      GPG_ACQUIRE();                                                                        \
+      _Pragma("unroll") for (int u = 0; u < 4; ++u) {                                        \
+        const int t = tid + 256 * u, jj = 16 * ((S) + 1) + (t >> 6), k = t & 63;             \
+        lp4[u] = (LP)[k + (size_t)jj * ldl];                                                 \
+      }                                                                                     \
+    }                                                                                       \
     GPG_QUAD_SUBST2_PIECE(x0, x1, Ls, sdinv, q, S)                                           \
     _Pragma("unroll") for (int m = 0; m < 16; ++m) { asm volatile("" : "+v"(x0[m])); asm volatile("" : "+v"(x1[m])); } \
   }
@@ -1980,14 +2005,24 @@ static void for_each_chol_task(int Mt, int Rt, int B, int order, F emit /* (b, i
   }
 }
 
+// Ticket order of a launch (gpg_ctx::task_order: 0 column-major, 1 critical path first, -1 = measured choice).  With the round-3
+// finalisation (a tile whose diagonal tile is complete on arrival takes the one-piece path) it pays to have the diagonal tiles done
+// early: order 1 gains 3.7 % on 64 matrices of 2560 columns, 3 % on 16 of 4608, 2.5 % on the 64-tile batches, 1-3 % on one matrix
+// of 9216 columns, and loses 1 % on one matrix of 18048 (tools/tile_probe, GPG_PROBE_ORDER, same box, twice).
+static int chol_task_order(const gpg_ctx* c, int B) {
+  if (c->task_order >= 0) return c->task_order & 1;
+  return (B >= 2 || c->Npad < 16384) ? 1 : 0;
+}
+
 // Task list of the dataflow factorisation of one matrix, cached per shape and order.
 const TileMap& get_tile_tasks(gpg_ctx* c, int Mt, int Rt, bool fuse) {
-  const unsigned long long key = (1ull << 63) | ((unsigned long long)(c->task_order & 1) << 60) | ((unsigned long long)(fuse ? 1 : 0) << 59) |
+  const int order = chol_task_order(c, 1);
+  const unsigned long long key = (1ull << 63) | ((unsigned long long)order << 60) | ((unsigned long long)(fuse ? 1 : 0) << 59) |
                                  ((unsigned long long)Mt << 20) | (unsigned)Rt;
   auto it = c->tilemaps.find(key);
   if (it != c->tilemaps.end()) return it->second;
   std::vector<int> list;
-  for_each_chol_task(Mt, Rt, 1, c->task_order, [&](int, int i, int j) { list.push_back(i | (j << 16)); }, fuse);
+  for_each_chol_task(Mt, Rt, 1, order, [&](int, int i, int j) { list.push_back(i | (j << 16)); }, fuse);
   TileMap tm;
   tm.n = (int)list.size();
   tm.dev = nullptr;
@@ -2072,12 +2107,13 @@ static void launch_tile_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a_st
   const int Mt = c->Npad / 64, Rt = c->ld / 64;
   // batched launches are throughput-bound, not chain-bound: the fused task's doubled loop costs +27 % there (tile_probe, 64 x 1280 columns)
   const bool fuse = c->fuse_subdiag != 0 && B == 1 && Mt <= c->fuse_subdiag_max_tiles;
-  const unsigned long long key = (2ull << 62) | ((unsigned long long)(c->task_order & 1) << 60) | ((unsigned long long)(fuse ? 1 : 0) << 59) |
+  const int order = chol_task_order(c, B);
+  const unsigned long long key = (2ull << 62) | ((unsigned long long)order << 60) | ((unsigned long long)(fuse ? 1 : 0) << 59) |
                                  ((unsigned long long)B << 40) | ((unsigned long long)Mt << 20) | (unsigned)Rt;
   auto it = c->tilemaps.find(key);
   if (it == c->tilemaps.end()) {
     std::vector<int> list, bof;
-    for_each_chol_task(Mt, Rt, B, c->task_order, [&](int b, int i, int j) { list.push_back(i | (j << 16)); bof.push_back(b); }, fuse);
+    for_each_chol_task(Mt, Rt, B, order, [&](int b, int i, int j) { list.push_back(i | (j << 16)); bof.push_back(b); }, fuse);
     TileMap tm;
     tm.n = (int)list.size();
     if (!gpg_dev_alloc(c, &tm.dev, sizeof(int) * 2 * list.size())) return;
@@ -2180,13 +2216,14 @@ static void launch_tile128_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a
   // One very large matrix per launch (cfg5: 532 tile columns): the rows of a tile column still pair up; only its diagonal tile has no
   // partner and is given to both teams (532 of 142 000 tasks).
   const bool pair = pair128_wanted(c, B);
-  const unsigned long long key = (2ull << 62) | (1ull << 61) | ((unsigned long long)(c->task_order & 1) << 60) | ((unsigned long long)(pair ? 1 : 0) << 59) |
+  const int order = chol_task_order(c, B);
+  const unsigned long long key = (2ull << 62) | (1ull << 61) | ((unsigned long long)order << 60) | ((unsigned long long)(pair ? 1 : 0) << 59) |
                                  ((unsigned long long)B << 40) | ((unsigned long long)Mt << 20) | (unsigned)Rt;
   auto it = c->tilemaps.find(key);
   if (it == c->tilemaps.end()) {
     std::vector<int> list, bof;
     if (pair) build_pair_tasks(Mt, Rt, B, list, bof);
-    else for_each_chol_task(Mt, Rt, B, c->task_order, [&](int b, int i, int j) { list.push_back(i | (j << 16)); bof.push_back(b); });
+    else for_each_chol_task(Mt, Rt, B, order, [&](int b, int i, int j) { list.push_back(i | (j << 16)); bof.push_back(b); });
     TileMap tm;
     tm.n = (int)(pair ? list.size() / 2 : list.size());
     if (!gpg_dev_alloc(c, &tm.dev, sizeof(int) * 2 * list.size())) return;

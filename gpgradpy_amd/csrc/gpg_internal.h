@@ -94,7 +94,7 @@ struct gpg_ctx {
   int pair_mode = 2;           // batched 128-tile launches (B >= 2) by pair128_chol_kernel (two tiles of a tile column per 512-thread workgroup):
                                // 0 never, 1 always, 2 from 16384 padded columns on (env GPG_PAIR)
   int pair_single_cols = 1 << 30;   // pair_mode 2: ONE matrix per launch goes to pair128_chol_kernel from this many padded columns on
-  int task_order = 0;          // ticket order of the dataflow factorisation (for_each_chol_task in cholesky_dataflow.hip)
+  int task_order = -1;         // ticket order of the dataflow factorisation: 0 column-major, 1 critical path first, -1 measured choice (chol_task_order)
   double grad_eta = -1.0;      // >= 0: nugget the hyperparameter derivatives are formed with instead of hp->eta (gpg_set_gradient_nugget)
   int max_workgroups = 0;      // > 0: cap on the grid of every persistent launch (gpg_set_max_workgroups; 0 = co-resident capacity)
   std::map<const void*, int> occupancy;   // workgroups per compute unit of each persistent kernel (occupancy query, cached)
