@@ -660,6 +660,31 @@ __device__ __forceinline__ int wg_wait_flag(int* flag, int* abort_word, int* inf
   return ok;
 }
 
+// How far do the completion flags of NR flag rows reach from tile column kdone on (exclusive end kend)?  Called by ONE whole wave: lane l
+// looks at tile column base + l of every row -- a handful of independent loads per 64 tile columns instead of NR dependent loads per
+// tile column from one thread (round 3: with the flags all up, as they are for 85 % of the tasks of a batched launch, that serial scan
+// was the whole "flag wait": ~50 tile columns x 2-4 L2 round trips = 25-65 us per task).  Returns the first column whose flags are not
+// all up (kdone if none is up yet), identical in every lane.
+template <int NR>
+__device__ __forceinline__ int wave_scan_flags(int* const (&rows)[NR], int kdone, int kend) {
+  const int lane = threadIdx.x & 63;
+  for (int base = kdone; base < kend; base += 64) {
+    const int k = base + lane;
+    int up = 0;
+    if (k < kend) {
+      up = 1;
+#pragma unroll
+      for (int r = 0; r < NR; ++r) up &= __hip_atomic_load(rows[r] + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    }
+    const unsigned long long have = __ballot(up);
+    const int valid = kend - base < 64 ? kend - base : 64;
+    const unsigned long long need = valid == 64 ? ~0ull : ((1ull << valid) - 1ull);
+    const unsigned long long miss = ~have & need;
+    if (miss) return base + (int)__builtin_ctzll(miss);
+  }
+  return kend;
+}
+
 // X (128 rows x 128 columns, in place) <- X L^-T against a factorised 128 x 128 diagonal tile, whole workgroup.
 // Each lane quad carries TWO matrix rows (r and r + 64) through the substitution, so the 128 rows cost two
 // substitution sweeps instead of four and half the L-image traffic.  Column block 0 is read from memory

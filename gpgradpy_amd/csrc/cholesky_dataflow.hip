@@ -906,23 +906,24 @@ tile128_chol_task(int tix, double* A, int ld, int Mt, const int* __restrict__ ta
   int kdone = 0;
   while (kdone < tj) {
     GPG_TR(q0)
-    if (tid == 0) {
-      int kr = kdone;
+    if (w == 0) {                                           // wave 0 scans the two flag rows, 64 tile columns per pass
+      int* const frows[2] = {frow_i, frow_j};
+      int kr;
       const unsigned long long t_wait = __builtin_amdgcn_s_memrealtime();
       for (;;) {
-        while (kr < tj && __hip_atomic_load(frow_i + kr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 &&
-               __hip_atomic_load(frow_j + kr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
-          ++kr;
+        kr = wave_scan_flags<2>(frows, kdone, tj);
         if (kr > kdone) break;
         if (__builtin_amdgcn_s_memrealtime() - t_wait > GPG_TILE_WAIT_TICKS || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-          __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          atomicMax(info, GPG_INFO_INTERNAL);
+          if (lane == 0) {
+            __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicMax(info, GPG_INFO_INTERNAL);
+          }
           kr = -1;
           break;
         }
         __builtin_amdgcn_s_sleep(8);
       }
-      sh_kr = kr;
+      if (lane == 0) sh_kr = kr;
     }
     __syncthreads();
     const int kr = __builtin_amdgcn_readfirstlane(sh_kr);
@@ -1059,6 +1060,9 @@ __global__ void __launch_bounds__(256, 2) tile128_chol_kernel(TileCholArgs) {   
 #ifndef GPG_PAIR_KSYNC
 #define GPG_PAIR_KSYNC 8
 #endif
+#ifndef GPG_PAIR_PF
+#define GPG_PAIR_PF GPG_MFMA_PF   // k-steps of operand prefetch in the pair kernel's MFMA loop (its eight waves run in lock step: nobody covers a late load)
+#endif
 __device__ __forceinline__ bool
 pair128_chol_task(int tix, double* Abase, int ld, int Mt, const int* __restrict__ tasks, int* flags_base, int* early_base, int* abort_word,
                   int* ticket, double* __restrict__ dinv_base, int* __restrict__ info_base, int N, const int* __restrict__ batch_of,
@@ -1097,52 +1101,62 @@ pair128_chol_task(int tix, double* Abase, int ld, int Mt, const int* __restrict_
         acc[ni][2 * g + 1][r] = v.y;
       }
 
+#ifdef GPG_STAMP
+  const unsigned long long tk_start = __builtin_amdgcn_s_memrealtime();
+  unsigned long long tk_spin = 0, tk_gemm = 0, tk_runs = 0;
+#endif
   // ---- (1) left-looking accumulation: runs as far as the flags of BOTH tiles' rows (and of tile row j of both matrices) allow ----
   direct_tile_negate(acc);                                   // the loop adds the products to -A_ij; sign restored below
   const unsigned lane_off = (unsigned)(2 * l15 + l4 * ld) * 8u;
   int kdone = 0;
   while (kdone < tj) {
-    if (tid == 0) {
-      int kr = kdone;
-      int* const fi0 = fl0 + (size_t)ti0 * Mt; int* const fj0 = fl0 + (size_t)tj * Mt;
-      int* const fi1 = fl1 + (size_t)ti1 * Mt; int* const fj1 = fl1 + (size_t)tj * Mt;
+    GPG_TR(q0)
+    if (tid < 64) {                                         // wave 0 of team 0 scans the four flag rows, 64 tile columns per pass
+      int* const frows[4] = {fl0 + (size_t)ti0 * Mt, fl0 + (size_t)tj * Mt, fl1 + (size_t)ti1 * Mt, fl1 + (size_t)tj * Mt};
+      int kr;
       const unsigned long long t_wait = __builtin_amdgcn_s_memrealtime();
       for (;;) {
-        while (kr < tj && __hip_atomic_load(fi0 + kr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 &&
-               __hip_atomic_load(fj0 + kr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 &&
-               __hip_atomic_load(fi1 + kr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 &&
-               __hip_atomic_load(fj1 + kr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)
-          ++kr;
+        kr = wave_scan_flags<4>(frows, kdone, tj);
         if (kr > kdone) break;
         if (__builtin_amdgcn_s_memrealtime() - t_wait > GPG_TILE_WAIT_TICKS || __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-          __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          atomicMax(info0, GPG_INFO_INTERNAL);
-          atomicMax(info1, GPG_INFO_INTERNAL);
+          if (tid == 0) {
+            __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicMax(info0, GPG_INFO_INTERNAL);
+            atomicMax(info1, GPG_INFO_INTERNAL);
+          }
           kr = -1;
           break;
         }
         __builtin_amdgcn_s_sleep(8);
       }
-      sh_kr = kr;
+      if (tid == 0) sh_kr = kr;
     }
     __syncthreads();
     const int kr = __builtin_amdgcn_readfirstlane(sh_kr);
     if (kr < 0) return false;
     GPG_ACQUIRE();
+    GPG_TR(q1)
     const size_t ck = 128 * (size_t)kdone;
     const int nstep = 32 * (kr - kdone);
     if (ti < Mt) {
       if (!(ti == tj && wm == 0 && wn == 1))
-        direct_tile_gemm_acc<GPG_MFMA_PF, 4, GPG_PAIR_KSYNC>(acc, A + r0 + wm * 64 + ck * (size_t)ld, lane_off, ld,
+        direct_tile_gemm_acc<GPG_PAIR_PF, 4, GPG_PAIR_KSYNC>(acc, A + r0 + wm * 64 + ck * (size_t)ld, lane_off, ld,
                                                             A + cj + wn * 64 + ck * (size_t)ld, lane_off, ld, nstep);
-      else direct_tile_sync_only<GPG_MFMA_PF, GPG_PAIR_KSYNC>(nstep);
+      else direct_tile_sync_only<GPG_PAIR_PF, GPG_PAIR_KSYNC>(nstep);
     } else if (wm == 0)
-      direct_tile_gemm_acc<GPG_MFMA_PF, 2, GPG_PAIR_KSYNC>(acc, A + r0 + ck * (size_t)ld, lane_off, ld,
+      direct_tile_gemm_acc<GPG_PAIR_PF, 2, GPG_PAIR_KSYNC>(acc, A + r0 + ck * (size_t)ld, lane_off, ld,
                                                           A + cj + wn * 64 + ck * (size_t)ld, lane_off, ld, nstep);
-    else direct_tile_sync_only<GPG_MFMA_PF, GPG_PAIR_KSYNC>(nstep);
+    else direct_tile_sync_only<GPG_PAIR_PF, GPG_PAIR_KSYNC>(nstep);
     __syncthreads();
+    GPG_TR(q2)
+#ifdef GPG_STAMP
+    tk_spin += q1 - q0; tk_gemm += q2 - q1; ++tk_runs;
+#endif
     kdone = kr;
   }
+#ifdef GPG_STAMP
+  const unsigned long long tk_fin0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   // ---- (2) diagonal tiles: top-left block into the team's LDS tile, the rest to memory; tiles below the diagonal: column block 0
   //      into LDS for fin128_offdiag, column block 1 to memory -----------------------------------------------------------------------
@@ -1204,6 +1218,13 @@ pair128_chol_task(int tix, double* Abase, int ld, int Mt, const int* __restrict_
       GPG_FLAG_UP(fl1 + (size_t)ti1 * Mt + tj);
     }
   }
+#ifdef GPG_STAMP
+  if (tid == 0 && g_stamp_buf != nullptr && tix < GPG_STAMP_MAX) {
+    unsigned long long* o = g_stamp_buf + (size_t)tix * 8;
+    o[0] = tk_start; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = tk_spin; o[3] = tk_gemm; o[4] = tk_runs;
+    o[5] = tk_fin0; o[6] = (unsigned long long)task0; o[7] = (unsigned long long)blockIdx.x;
+  }
+#endif
   return true;
 }
 
