@@ -1046,9 +1046,11 @@ __global__ void __launch_bounds__(256, 2) tile128_chol_kernel(TileCholArgs) {   
 // pair128_chol_kernel (round 3): the same dataflow factorisation for BATCHED launches, 512 threads = two 256-thread teams per
 // workgroup, ONE workgroup per compute unit.  A task is a PAIR of 128 x 128 tiles of one tile column j that go through the same
 // control flow: team h owns tile (i_h, j) of matrix b_h.  Ordinary pairs are two consecutive rows of one matrix: both teams then
-// read the SAME row panel L_j,0:j as their B operand, k-step by k-step in lock step (the workgroup barrier of the MFMA loop,
-// GPG_PAIR_KSYNC k-steps apart), so it crosses the L2 -> L1 path once per pair: the operand stream of a 256 x 128 footprint, 25 %
-// fewer bytes than two independent 128 x 128 tiles.  Diagonal tiles pair with the diagonal tile of the NEXT matrix of the batch
+// read the SAME row panel L_j,0:j as their B operand, k-step by k-step at the same pace -- eight waves that start a run together and
+// execute the same instruction stream stay together by themselves: a workgroup barrier in the loop (GPG_PAIR_KSYNC k-steps apart;
+// 0 = none, the default) only adds its skew: 283.4 ms and 3.90e8 KiB FETCH_SIZE without, 289.0 ms and 4.08e8 with one every 8 k-steps
+// -- so it crosses the L2 -> L1 path once per pair: the operand stream of a 256 x 128 footprint, 25 % fewer bytes than two independent
+// 128 x 128 tiles.  Diagonal tiles pair with the diagonal tile of the NEXT matrix of the batch
 // (same j, same barrier sequence, different data); what is left over in a tile column pairs with the next matrix's leftover,
 // and a tile without any partner is simply given to both teams (identical instruction streams on identical data: the duplicate
 // stores write identical values).  Every barrier is a full-workgroup barrier: the two teams never diverge in control flow, and
@@ -1058,7 +1060,7 @@ __global__ void __launch_bounds__(256, 2) tile128_chol_kernel(TileCholArgs) {   
 // What it gives up: with one workgroup per CU the finalisation of a pair is not overlapped with another workgroup's MFMA loop.
 // ------------------------------------------------------------------------------------------------
 #ifndef GPG_PAIR_KSYNC
-#define GPG_PAIR_KSYNC 8
+#define GPG_PAIR_KSYNC 0
 #endif
 #ifndef GPG_PAIR_PF
 #define GPG_PAIR_PF GPG_MFMA_PF   // k-steps of operand prefetch in the pair kernel's MFMA loop (its eight waves run in lock step: nobody covers a late load)
@@ -1312,22 +1314,25 @@ tile128_trinv_task(int tix, const double* __restrict__ A, int ld, const double* 
   const unsigned lane_off_w = (unsigned)(2 * l15 + l4 * ldw) * 8u, lane_off_l = (unsigned)(2 * l15 + l4 * ld) * 8u;
   int kdone = tj;
   while (kdone < ti) {
-    if (tid == 0) {
-      int kr = kdone;
+    if (w == 0) {                                           // wave 0 scans the flag row, 64 tile columns per pass
+      int* const frows[1] = {frow};
+      int kr;
       const unsigned long long t_wait = __builtin_amdgcn_s_memrealtime();
       for (;;) {
-        while (kr < ti && __hip_atomic_load(frow + kr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) ++kr;
+        kr = wave_scan_flags<1>(frows, kdone, ti);
         if (kr > kdone) break;
         if (__builtin_amdgcn_s_memrealtime() - t_wait > GPG_TILE_WAIT_TICKS ||
             __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-          __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          atomicMax(info, GPG_INFO_INTERNAL);
+          if (lane == 0) {
+            __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicMax(info, GPG_INFO_INTERNAL);
+          }
           kr = -1;
           break;
         }
         __builtin_amdgcn_s_sleep(8);
       }
-      sh_kr = kr;
+      if (lane == 0) sh_kr = kr;
     }
     __syncthreads();
     const int kr = __builtin_amdgcn_readfirstlane(sh_kr);
@@ -2197,18 +2202,35 @@ static void launch_tile128_chol(gpg_ctx* c) {
 // matrix's tiles below the diagonal in pairs of consecutive rows, then what was left over (at most one ordinary tile per matrix, paired
 // over the matrices) and the right-hand-side tile rows (light tasks: paired with each other).  A tile without a partner is listed
 // twice (both teams do it).  Every task waits only for tasks of earlier tile columns and for the diagonal tiles of its own column.
-static void build_pair_tasks(int Mt, int Rt, int B, std::vector<int>& list, std::vector<int>& bof) {
+static void build_pair_tasks(int Mt, int Rt, int B, std::vector<int>& list, std::vector<int>& bof, int order) {
   auto emit = [&](int ba, int ia, int bb, int ib, int j) {
     list.push_back(ia | (j << 16)); list.push_back(ib | (j << 16));
     bof.push_back(ba); bof.push_back(bb);
   };
+  auto emit_diag = [&](int j) { for (int b = 0; b < B; b += 2) emit(b, j, b + 1 < B ? b + 1 : b, j, j); };
+  // order 1 (critical path first, as for_each_chol_task): the first pair below the diagonal of tile column j and then the diagonal
+  // tiles of column j + 1 go ahead of the rest of column j
+  if (order == 1) emit_diag(0);
   for (int j = 0; j < Mt; ++j) {
-    for (int b = 0; b < B; b += 2) emit(b, j, b + 1 < B ? b + 1 : b, j, j);
+    if (order != 1) emit_diag(j);
     std::vector<std::pair<int, int>> left;
-    for (int b = 0; b < B; ++b) {
-      int i = j + 1;
-      for (; i + 1 < Mt; i += 2) emit(b, i, b, i + 1, j);
-      if (i < Mt) left.emplace_back(b, i);
+    const bool ahead = order == 1 && j + 1 < Mt;
+    for (int pass = ahead ? 0 : 1; pass < 2; ++pass) {          // pass 0: only the pair that holds row j + 1; pass 1: the others
+      for (int b = 0; b < B; ++b) {
+        int i = j + 1;
+        for (; i + 1 < Mt; i += 2)
+          if (!ahead || (pass == 0) == (i == j + 1)) emit(b, i, b, i + 1, j);
+        if (i < Mt && (!ahead || (pass == 0) == (i == j + 1))) left.emplace_back(b, i);
+      }
+      if (pass == 0) {                                          // (a lone row j + 1 -- the last column pair -- pairs over the matrices right away)
+        for (size_t k = 0; k < left.size(); k += 2) {
+          const auto& a = left[k];
+          const auto& bb = k + 1 < left.size() ? left[k + 1] : left[k];
+          emit(a.first, a.second, bb.first, bb.second, j);
+        }
+        left.clear();
+        emit_diag(j + 1);
+      }
     }
     for (size_t k = 0; k < left.size(); k += 2) {
       const auto& a = left[k];
@@ -2223,7 +2245,10 @@ static void build_pair_tasks(int Mt, int Rt, int B, std::vector<int>& list, std:
 static bool pair128_wanted(const gpg_ctx* c, int B) {
   if (c->pair_mode == 1) return true;
   if (c->pair_mode != 2) return false;
-  return B >= 2 ? c->Npad >= 16384 : c->Npad >= c->pair_single_cols;
+  // measured (tools/tile_probe, same box, twice; pair kernel without a barrier in its MFMA loop): ahead of tile128_chol_kernel at every
+  // batched size -- 64 x 2560 columns +1.3 %, 16 x 4608 +1.7 %, 8 x 9216 +2.6 %, 8 x 12288 +2.7 %, 2 / 5 / 10 x 18048 +2.2 / +1.3 / +2.3 % --
+  // and 1-2 % behind it for ONE matrix per launch (9216 ... 68096 columns)
+  return B >= 2 || c->Npad >= c->pair_single_cols;
 }
 
 // The same for B matrices at once (see launch_tile_chol_batch): at the two ends of a factorisation the dependency
@@ -2231,9 +2256,8 @@ static bool pair128_wanted(const gpg_ctx* c, int B) {
 static void launch_tile128_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a_stride, double* dinv_base, int d_stride,
                                       int* info_base) {
   const int Mt = c->Npad / 128, Rt = c->ld / 128;
-  // pair128_chol_kernel (512-thread workgroups, two tiles of a tile column each): same speed as tile128_chol_kernel from ~16k columns
-  // on (ten cfg3 matrices 298.6 / 297.4 ms) with a quarter less memory traffic (87 against 120 GB per matrix), slower below (2560
-  // columns x 64: 9.2 / 8.8 ms: the finalisations of a pair are not hidden behind another workgroup's MFMA loop)
+  // pair128_chol_kernel (512-thread workgroups, two tiles of a tile column each): a quarter less memory traffic than tile128_chol_kernel
+  // (87 against 120 GB per cfg3 matrix) and, since its finalisation lost its spill reloads and its MFMA loop its barrier, 1-3 % faster
   // One very large matrix per launch (cfg5: 532 tile columns): the rows of a tile column still pair up; only its diagonal tile has no
   // partner and is given to both teams (532 of 142 000 tasks).
   const bool pair = pair128_wanted(c, B);
@@ -2243,7 +2267,7 @@ static void launch_tile128_chol_batch(gpg_ctx* c, int B, double* Abase, size_t a
   auto it = c->tilemaps.find(key);
   if (it == c->tilemaps.end()) {
     std::vector<int> list, bof;
-    if (pair) build_pair_tasks(Mt, Rt, B, list, bof);
+    if (pair) build_pair_tasks(Mt, Rt, B, list, bof, order);
     else for_each_chol_task(Mt, Rt, B, order, [&](int b, int i, int j) { list.push_back(i | (j << 16)); bof.push_back(b); });
     TileMap tm;
     tm.n = (int)(pair ? list.size() / 2 : list.size());

@@ -92,7 +92,7 @@ struct gpg_ctx {
   int fuse_subdiag_max_tiles = 48;   // ... up to this many 64-column tile columns (3072 matrix columns)
   int fuse_subdiag = 1;        // 64-tile factorisation: diagonal tasks own the sub-diagonal tile below the previous diagonal tile (tile_chol_task)
   int pair_mode = 2;           // batched 128-tile launches (B >= 2) by pair128_chol_kernel (two tiles of a tile column per 512-thread workgroup):
-                               // 0 never, 1 always, 2 from 16384 padded columns on (env GPG_PAIR)
+                               // 0 never, 1 always, 2 whenever a launch holds two or more matrices (env GPG_PAIR)
   int pair_single_cols = 1 << 30;   // pair_mode 2: ONE matrix per launch goes to pair128_chol_kernel from this many padded columns on
   int task_order = -1;         // ticket order of the dataflow factorisation: 0 column-major, 1 critical path first, -1 measured choice (chol_task_order)
   double grad_eta = -1.0;      // >= 0: nugget the hyperparameter derivatives are formed with instead of hp->eta (gpg_set_gradient_nugget)

@@ -310,9 +310,9 @@ int gpg_solve_fallbacks(gpg_ctx* ctx);
 int gpg_last_factor(gpg_ctx* ctx, int* kernel, int* matrices);
 /* Batched launches of the 128 x 128-tile schedule (gpg_lkd_batch on large matrices) can give every 512-thread workgroup a PAIR of tiles of
  * one tile column: both tiles then share the row panel they read as the second operand (a quarter less memory traffic), at the
- * price of finalisations that are not hidden behind another workgroup's MFMA loop.  mode 0: never, 1: whenever a launch holds at
- * least two matrices, 2 (default): from 16384 padded columns on, where the two schedules are equally fast.  Results are
- * bit-identical in all three modes. */
+ * price of finalisations that are not hidden behind another workgroup's MFMA loop; measured 1-3 % faster for every batched size.
+ * mode 0: never, 1: always (also for one matrix per launch, where it is 1-2 % slower), 2 (default): whenever a launch holds at
+ * least two matrices.  Results are bit-identical in all three modes. */
 int gpg_set_pair_mode(gpg_ctx* ctx, int mode);
 
 /* Caps the number of persistent workgroups of every dataflow launch (0 = default: as many as the device holds at once).  The

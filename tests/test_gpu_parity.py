@@ -603,7 +603,7 @@ def test_cfg5_size_properties():
     # several 37 GB workspaces fit in 288 GB: restart rows are factorised two / three per launch at this size too, bit for bit
     GP.set_batch(2)
     ln_b = GP.calc_lkd_batch(tab[:2])
-    assert GP.last_factor() == ('pair128', 2) and ln_b[0] == ln_df and np.isfinite(ln_b[1])      # (batched, >= 16384 columns: tile pairs)
+    assert GP.last_factor() == ('pair128', 2) and ln_b[0] == ln_df and np.isfinite(ln_b[1])      # (batched launch: tile pairs)
     GP.set_batch(-1)
     # the adjoint gradient at this size (W = L^-T and -(W W^T) of a 68096-column factor: 532 x 532 tiles, 111 GB of workspaces)
     # against a central difference of the device likelihood in its largest component

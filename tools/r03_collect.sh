@@ -17,6 +17,6 @@ run() {   # name, kernel, config, mats, bench arguments...
   cut -c1-600 gpurun_out/${TAG}_${name}_bench.json
 }
 run drv pair128_chol_kernel cfg3 5,10,10 --gpus 1 --steps 20 --warmup 5
-run cfg2 tile128_chol_kernel cfg2 64,64 --config cfg2 --steps 64 --warmup 64 --no-cpu-baseline
+run cfg2 pair128_chol_kernel cfg2 64,64 --config cfg2 --steps 64 --warmup 64 --no-cpu-baseline
 run cfg2one tile_chol_kernel cfg2 1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1 --config cfg2 --steps 16 --warmup 4 --batch 0 --no-cpu-baseline
 run cfg5 tile128_chol_kernel cfg5 1,1,1,1,1 --config cfg5 --steps 4 --warmup 1 --no-cpu-baseline
