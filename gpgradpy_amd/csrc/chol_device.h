@@ -727,6 +727,17 @@ __device__ __forceinline__ void direct_tile_negate(d4 (&acc)[4][4]) {
 #ifndef GPG_UNROLL_KSTEPS
 #define GPG_UNROLL_KSTEPS 32
 #endif
+typedef double gpg_d2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 gpg_dx_nt(const char* p) {
+  const gpg_d2v v = __builtin_nontemporal_load(reinterpret_cast<const gpg_d2v*>(p));
+  double2 r; r.x = v.x; r.y = v.y; return r;
+}
+__device__ __forceinline__ double2 gpg_dx_x2(const char* p, unsigned l0, unsigned l8) {   // two 8-byte loads (l8 = l0 + 8, opaque to the compiler)
+  double2 r;
+  r.x = *reinterpret_cast<const double*>(p + (size_t)l0);
+  r.y = *reinterpret_cast<const double*>(p + (size_t)l8);
+  return r;
+}
 template <int PF, int MI = 4, int KS = GPG_KSYNC, int UN = GPG_UNROLL_KSTEPS>
 __device__ __forceinline__ void direct_tile_gemm_acc(d4 (&acc)[4][4], const double* ua_d, unsigned la, int lda, const double* ub_d,
                                                      unsigned lb, int ldb, int nstep) {
@@ -734,7 +745,17 @@ __device__ __forceinline__ void direct_tile_gemm_acc(d4 (&acc)[4][4], const doub
   const char* ua = reinterpret_cast<const char*>(ua_d);
   const char* ub = reinterpret_cast<const char*>(ub_d);
   double2 fa0[PF + 1], fa1[PF + 1], fb0[PF + 1], fb1[PF + 1];
+#if defined(GPG_DX_X2)
+  unsigned la8 = la + 8u, lb8 = lb + 8u;
+  asm volatile("" : "+v"(la8), "+v"(lb8));
+#endif
+#if defined(GPG_DX_NT)        // diagnostic builds of tools/subst_probe.hip only: other flavours of the operand loads
+#define GPG_DX_LD(u, l, x) gpg_dx_nt((u) + (size_t)(l) + (x))
+#elif defined(GPG_DX_X2)
+#define GPG_DX_LD(u, l, x) gpg_dx_x2((u) + (x), (l), (l##8))
+#else
 #define GPG_DX_LD(u, l, x) (reinterpret_cast<const double2*>((u) + (size_t)(l))[(x) / 16])
+#endif
 #define GPG_DX_LOAD(set)                                                              \
   {                                                                                   \
     fa0[set] = GPG_DX_LD(ua, la, 0);                                                  \
