@@ -105,7 +105,7 @@ def test_cfg3_full_size_against_oracle():
     tp[k] += h
     tm[k] -= h
     fd = (GP.calc_lkd_all(GP.make_hp_class(theta=tp))[0].ln_lkd - GP.calc_lkd_all(GP.make_hp_class(theta=tm))[0].ln_lkd) / (2 * h)
-    assert abs(fd - info_g.ln_lkd_grad[k]) <= 2e-3 * abs(fd), (fd, info_g.ln_lkd_grad[k])
+    assert abs(fd - info_g.ln_lkd_grad[k]) <= 1e-6 * abs(fd), (fd, info_g.ln_lkd_grad[k])   # measured 3e-8 (tools/grad_time.py)
 
 
 def test_cfg5_combination_at_tile_scale_against_oracle():

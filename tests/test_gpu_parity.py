@@ -617,7 +617,7 @@ def test_cfg5_size_properties():
     tm[k] -= h
     mk = lambda t: GP.make_hp_class(theta=t, varK=hp.varK)
     fd = (GP.calc_lkd_all(mk(tp))[0].ln_lkd - GP.calc_lkd_all(mk(tm))[0].ln_lkd) / (2 * h)
-    assert abs(fd - info_g.ln_lkd_grad[k]) <= 5e-3 * abs(fd), (fd, info_g.ln_lkd_grad[k])
+    assert abs(fd - info_g.ln_lkd_grad[k]) <= 1e-6 * abs(fd), (fd, info_g.ln_lkd_grad[k])   # measured 9e-9 at this step (tools/fd_cfg5.py: 1e-6 / 9e-9 / 5e-9 at h = 1e-3 / 1e-4 / 1e-5 theta)
     GP.set_factor_mode('blocked')
     ln_bl = GP.calc_lkd_all(hp)[0].ln_lkd
     assert GP.last_factor()[0] == 'blocked'
