@@ -383,6 +383,24 @@ __device__ __forceinline__ void wave_tile_gemm(d4 (&acc)[4], const double* ga, i
       GPG_QS2_STEP(x0, x1, Ls, sdinv, q, 3)                                                  \
     }                                                                                       \
   }
+// GPG_QUAD_SUBST2 with a hook after the four steps of every column group mj (x0[mj], x1[mj] are final then): the dataflow kernels
+// put the two stores of the finished columns there, so that the 32 stores of a block trickle out behind the column steps instead of
+// being issued -- 4 us -- and acknowledged after them
+#define GPG_QUAD_SUBST2_HOOK(x0, x1, Ls, sdinv, q, HOOK)                                      \
+  {                                                                                         \
+    double lv[2][16];                                                                       \
+    _Pragma("unroll") for (int m = 0; m < 16; ++m) lv[0][m] = Ls[0][q][m];                   \
+    _Pragma("unroll") for (int mj = 0; mj < 16; ++mj) {                                      \
+      GPG_QS2_STEP(x0, x1, Ls, sdinv, q, 0)                                                  \
+      GPG_QS2_STEP(x0, x1, Ls, sdinv, q, 1)                                                  \
+      GPG_QS2_STEP(x0, x1, Ls, sdinv, q, 2)                                                  \
+      GPG_QS2_STEP(x0, x1, Ls, sdinv, q, 3)                                                  \
+      HOOK(mj)                                                                              \
+    }                                                                                       \
+  }
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for the wave's outstanding global stores (vmcnt(0) --
+// microseconds for write-through stores), which the LDS hand-overs inside a finalisation do not need
+#define GPG_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 // one 16-column piece of GPG_QUAD_SUBST2 (see GPG_QUAD_SUBST_PIECE)
 #define GPG_QUAD_SUBST2_PIECE(x0, x1, Ls, sdinv, q, s)                                       \
   {                                                                                         \
@@ -626,7 +644,7 @@ __device__ __forceinline__ void panel_solve_rows64(const double* __restrict__ L,
 #endif
   }
 #undef GPG_PS_PREFETCH
-#ifdef GPG_STAMP
+#if defined(GPG_STAMP) && defined(GPG_STAMP_PANEL)   // (the panel kernel's own record: would overwrite the dataflow kernels' task records)
   if (lane == 0 && blockIdx.x < 4096 && g_stamp_buf != nullptr) {
     unsigned long long* o = g_stamp_buf + ((size_t)blockIdx.x * 4 + w) * 8;
     o[0] = ps_pre; o[1] = ps_gemm; o[2] = ps_tr; o[3] = ps_sub; o[4] = ps_st;

@@ -406,6 +406,7 @@ __global__ void __launch_bounds__(256, 2) tile_chol_kernel(TileCholArgs) {
 // second potrf64.
 #ifdef GPG_STAMP
 __shared__ unsigned long long* t128_fo;      // finalisation record of the running task (thread 0 writes and reads it)
+__shared__ unsigned long long t128_wait_acc; // ticks thread 0 spent polling piece flags in this task's finalisation (wg_wait_flag2)
 #define GPG_FS2(k) if (threadIdx.x == 0 && t128_fo) t128_fo[k] = __builtin_amdgcn_s_memrealtime();
 // piece-level record (third region of the stamp buffer, 16 words per task): per piece S of column block 0 -- after the flag wait,
 // after the image is in LDS (barrier), after the 16 column steps
@@ -543,6 +544,9 @@ __device__ __forceinline__ int wg_wait_flag2(int* fa, int* fb, int* abort_word, 
       __builtin_amdgcn_s_sleep(8);
     }
     *sh = ok;
+#ifdef GPG_STAMP
+    t128_wait_acc += __builtin_amdgcn_s_memrealtime() - t_wait;
+#endif
   }
   __syncthreads();
   const int ok = *sh;
@@ -593,8 +597,16 @@ __device__ __forceinline__ void fin128_handoff_block0(const d4 (&acc)[4][4], int
 // Called with the ticket and the kernel's argument segment only: everything else is re-derived here by scalar loads.  What a task
 // keeps alive across its MFMA loop is spilled, and every spill reload after the loop is a memory round trip under full load (the
 // timeline of the first version of this function showed ~35 us of them in front of the call).
+#ifndef GPG_FIN_INLINE
+#define GPG_FIN_INLINE 1
+#endif
+#if GPG_FIN_INLINE
+#define GPG_FIN_FN __device__ __forceinline__
+#else
+#define GPG_FIN_FN __device__ __noinline__
+#endif
 template <int SET>
-__device__ __noinline__ int fin128_offdiag(int tix_v, unsigned long long kernarg_bits) {
+GPG_FIN_FN int fin128_offdiag(int tix_v, unsigned long long kernarg_bits) {
   constexpr int SA = 80, S2 = 72, BUF = 16 * SA;
   GPG_KERNARGS_FROM(TileCholArgs, ap, kernarg_bits);
   const int tix = __builtin_amdgcn_readfirstlane(tix_v);
@@ -628,7 +640,9 @@ __device__ __noinline__ int fin128_offdiag(int tix_v, unsigned long long kernarg
   double* const sdinv = fin128_sdinv<SET>();
   int* const sh = fin128_sh<SET>();
   int* const sh2 = fin128_sh2<SET>();
-  const int tid = SET == 2 ? (int)threadIdx.x : (int)(threadIdx.x & 255), lane = tid & 63;
+  int tid_raw = (int)threadIdx.x;
+  asm volatile("" : "+v"(tid_raw));                            // (inlined: nothing derived from the lane index may be hoisted above the task's MFMA loop)
+  const int tid = SET == 2 ? tid_raw : (tid_raw & 255), lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, l4 = lane >> 4;
   const int q = tid & 3, rr = tid >> 2;
@@ -638,7 +652,7 @@ __device__ __noinline__ int fin128_offdiag(int tix_v, unsigned long long kernarg
   double* const X = A + r0 + cj * (size_t)ld;
   const int ldl = ld, ldx = ld;
 #ifdef GPG_STAMP
-#define GPG_FS4(k) if (SET == 2 && threadIdx.x == 0 && t128_fo) t128_fo[k] = __builtin_amdgcn_s_memrealtime();
+#define GPG_FS4(k) if (SET != 1 && threadIdx.x == 0 && t128_fo) t128_fo[k] = __builtin_amdgcn_s_memrealtime();
 #else
 #define GPG_FS4(k)
 #endif
@@ -650,17 +664,21 @@ __device__ __noinline__ int fin128_offdiag(int tix_v, unsigned long long kernarg
   const int fast = *sh;
   GPG_FS4(1)
 #ifdef GPG_STAMP
-  if (SET == 2 && threadIdx.x == 0 && t128_fo) t128_fo[7] = fast ? 2 : 1;
+  if (SET != 1 && threadIdx.x == 0 && t128_fo) t128_fo[7] = fast ? 2 : 1;
 #endif
   double x0[16], x1[16];
-  {
-    const double* T0 = U + q * SA + rr;
-    const double* T1 = &fin128_Ls<SET>()[0][0][0] + q * S2 + rr;
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-      x0[m] = T0[(4 * m) * SA];
-      x1[m] = T1[(4 * m) * S2];
-    }
+  // (taken out of the hand-over tiles separately on each path, through an opaque copy of the thread index: loaded once ahead of the
+  // branch, the initial values stayed live -- in scratch -- through the whole one-piece path)
+#define GPG_F128_TAKE_X()                                                                    \
+  {                                                                                         \
+    int tq = tid;                                                                           \
+    asm volatile("" : "+v"(tq));                                                            \
+    const double* T0 = U + (tq & 3) * SA + (tq >> 2);                                        \
+    const double* T1 = &fin128_Ls<SET>()[0][0][0] + (tq & 3) * S2 + (tq >> 2);               \
+    _Pragma("unroll") for (int m = 0; m < 16; ++m) {                                         \
+      x0[m] = T0[(4 * m) * SA];                                                             \
+      x1[m] = T1[(4 * m) * S2];                                                             \
+    }                                                                                       \
   }
   // column block 1 after its update: T2 -= X1 L21^T for the two row halves, each transposed through the LDS tile into x0 / x1
 #define GPG_F128_UPDATE()                                                                    \
@@ -689,12 +707,22 @@ __device__ __noinline__ int fin128_offdiag(int tix_v, unsigned long long kernarg
     }                                                                                       \
   }
   if (fast) {
+    // One-piece path (the diagonal tile was complete on entry).  Round 3, second half: the update of column block 1 no longer goes
+    // through memory.  Before: X1 stored, s_waitcnt vmcnt(0) + barrier (5.5 us of store acknowledgements), then wave_tile_gemm staging
+    // X1 and L21 from memory through LDS with three barriers per 16-deep chunk (14.8 us) -- for 128 MFMAs per wave.  Now L21 is brought
+    // in with L11 (one round trip) and parked k-major in the staging tile, the A operand -X1 comes straight out of the substitution's
+    // registers by a lane permutation (quad layout: lane 4 r + q holds row r, columns 4 m + q; MFMA layout: lane 16 k + r holds row r,
+    // column 4 s + k: source lane 4 l15 + l4, register m = s), the X1 store is left in flight until the task publishes, and the
+    // transposition back into the quad layout is wave-private (wave w owns rows 16 w .. 16 w + 15 in both layouts).  Two barriers
+    // instead of fourteen.  Same MFMA operands in the same order as GPG_F128_UPDATE (fn = L21 fragment, fm = -X1 fragment, accumulator
+    // preloaded with T2, k ascending): bit-identical with the piecewise path.
     GPG_ACQUIRE();
-    double li[16];                                             // raw 64 x 64 block of L, 16 entries per thread
-#define GPG_F128_RAW(LP)                                                                     \
+    GPG_F128_TAKE_X()
+    double li[16], lj[16];                                     // raw 64 x 64 blocks of L, 16 entries per thread
+#define GPG_F128_RAW(dst, LP)                                                                \
     _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                         \
       const int t = tid + 256 * i;                                                          \
-      li[i] = (LP)[(t & 63) + (size_t)(t >> 6) * ldl];                                       \
+      dst[i] = (LP)[(t & 63) + (size_t)(t >> 6) * ldl];                                      \
     }
 #define GPG_F128_IMAGE(DOFF)                                                                 \
     _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                         \
@@ -702,29 +730,104 @@ __device__ __noinline__ int fin128_offdiag(int tix_v, unsigned long long kernarg
       Ls[jj][k & 3][k >> 2] = li[i];                                                        \
     }                                                                                       \
     if (tid < 64) sdinv[tid] = dinv[(DOFF) + tid];
-    GPG_F128_RAW(L)
-    __syncthreads();                                           // every thread has taken its x1 out of the image region
+    GPG_F128_RAW(li, L)
+    GPG_F128_RAW(lj, L + 64)                                   // L21[n][k] = L[64 + n + k ldl]
+    GPG_LDS_BARRIER();                                         // every thread has taken x0 / x1 out of the staging tile and the image region
     GPG_F128_IMAGE(0)
-    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {                             // L21 k-major: U[k][n], row stride SA
+      const int t = tid + 256 * i;
+      U[(t >> 6) * SA + (t & 63)] = lj[i];
+    }
+    GPG_F128_RAW(li, L + 64 + (size_t)64 * ldl)                // L22: in flight through the column steps of block 0
+    GPG_LDS_BARRIER();
     GPG_FS4(2)
-    GPG_QUAD_SUBST2(x0, x1, Ls, sdinv, q)
+    {
+      double* const Xs = X + rr + (size_t)q * ldx;             // the finished columns of X1 leave behind the steps (no wait before the task publishes)
+#define GPG_F128_HOOK(mj) GPG_ST(&Xs[(size_t)(4 * (mj)) * ldx], x0[mj]); GPG_ST(&Xs[64 + (size_t)(4 * (mj)) * ldx], x1[mj]);
+      GPG_QUAD_SUBST2_HOOK(x0, x1, Ls, sdinv, q, GPG_F128_HOOK)
+    }
     GPG_FS4(3)
-    GPG_F128_STORE(0)
-    GPG_F128_RAW(L + 64 + (size_t)64 * ldl)                    // L22, in flight through the update of block 1
-    __syncthreads();                                           // X1 in memory (vmcnt(0) of every wave precedes the barrier); image of L11 no longer read
+    // (addresses used from here on are re-derived from an opaque copy of the thread index: computed ahead of the column steps -- they are
+    // pure functions of it -- they were kept in ~50 registers across the steps and spilled around them)
+    int tid2 = tid;
+    asm volatile("" : "+v"(tid2));
+#define GPG_F128_RELANE(t)  const int lane_ = (t) & 63, l15 = lane_ & 15, l4 = lane_ >> 4, q = (t) & 3, rr = (t) >> 2, tid = (t); (void)l15; (void)l4; (void)q; (void)rr; (void)tid;
+    d4 c0[4], c1[4];                                           // T2 in the MFMA layout: rows 16 w + l15 (c0) and 64 + 16 w + l15 (c1), column 64 + 16 ni + 4 r + l4
+    {
+      GPG_F128_RELANE(tid2)
+      const double* Cw = X + 16 * w + l15 + (size_t)(64 + l4) * ldx;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          c0[ni][r] = Cw[(size_t)(ni * 16 + 4 * r) * ldx];
+          c1[ni][r] = Cw[64 + (size_t)(ni * 16 + 4 * r) * ldx];
+        }
+    }
+    double a0[16], a1[16];
+    {
+      GPG_F128_RELANE(tid2)
+      const int src = 4 * (4 * l15 + l4);
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const int lo0 = __builtin_amdgcn_ds_bpermute(src, __double2loint(x0[m])), hi0 = __builtin_amdgcn_ds_bpermute(src, __double2hiint(x0[m]));
+        const int lo1 = __builtin_amdgcn_ds_bpermute(src, __double2loint(x1[m])), hi1 = __builtin_amdgcn_ds_bpermute(src, __double2hiint(x1[m]));
+        a0[m] = -__hiloint2double(hi0, lo0);
+        a1[m] = -__hiloint2double(hi1, lo1);
+      }
+    }
+    GPG_FS3(6)
+    GPG_LDS_BARRIER();                                         // (1) every wave is through the column steps of block 0: the image region is free
     GPG_FS4(4)
-    GPG_F128_UPDATE()
+    {
+      GPG_F128_RELANE(tid2)
+      GPG_F128_IMAGE(64)
+#pragma unroll
+      for (int s4 = 0; s4 < 16; ++s4) {
+        double fn[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) fn[ni] = U[(4 * s4 + l4) * SA + ni * 16 + l15];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          c0[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(fn[ni], a0[s4], c0[ni], 0, 0, 0);
+          c1[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(fn[ni], a1[s4], c1[ni], 0, 0, 0);
+        }
+      }
+    }
+    GPG_LDS_BARRIER();                                         // (2) L21 is no longer read from the staging tile; the image of L22 is complete
+    {
+      GPG_F128_RELANE(tid2)
+      const double* Tr = U + q * SA + rr;                      // rows 16 w .. 16 w + 15 are written and read by wave w only: no barrier
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) U[(ni * 16 + 4 * r + l4) * SA + 16 * w + l15] = c0[ni][r];
+#pragma unroll
+      for (int m = 0; m < 16; ++m) x0[m] = Tr[(4 * m) * SA];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) U[(ni * 16 + 4 * r + l4) * SA + 16 * w + l15] = c1[ni][r];
+#pragma unroll
+      for (int m = 0; m < 16; ++m) x1[m] = Tr[(4 * m) * SA];
+    }
     GPG_FS4(5)
-    GPG_F128_IMAGE(64)
-    __syncthreads();
-    GPG_QUAD_SUBST2(x0, x1, Ls, sdinv, q)
+    {
+      GPG_F128_RELANE(tid2)
+      double* const Xs = X + rr + (size_t)(64 + q) * ldx;
+      GPG_QUAD_SUBST2_HOOK(x0, x1, Ls, sdinv, q, GPG_F128_HOOK)
+#undef GPG_F128_HOOK
+    }
     GPG_FS4(6)
-    GPG_F128_STORE(64)
-    __syncthreads();
-    return 1;
+    GPG_FS3(0)
+    GPG_FS3(1)
+    return 1;                                                  // (the caller's publish step waits for the stores and synchronises the workgroup)
+#undef GPG_F128_RELANE
 #undef GPG_F128_RAW
 #undef GPG_F128_IMAGE
   }
+  GPG_F128_TAKE_X()
   __syncthreads();                                             // x1 is out of the image region, *sh may be rewritten
   // piecewise: L11 / L22 arrive in four 16-column pieces each while the diagonal task is still at work
   // A piece whose flag is already up while the previous piece is being substituted is fetched into registers behind that
@@ -764,9 +867,12 @@ __device__ __noinline__ int fin128_offdiag(int tix_v, unsigned long long kernarg
   GPG_F128_PIECE(pa, L, 0, 1)
   GPG_F128_PIECE(pa, L, 0, 2)
   GPG_F128_PIECE(pa, L, 0, 3)
+  GPG_FS4(2)
   GPG_F128_STORE(0)
   if (!wg_wait_flag2(fc0, fc1, abort_word, info0, info1, sh)) return 0;   // barrier inside: X1 in memory, L21 final
+  GPG_FS4(3)
   GPG_F128_UPDATE()
+  GPG_FS4(4)
   {
     const double* L22 = L + 64 + (size_t)64 * ldl;
     GPG_F128_PIECE(pb, L22, 64, 0)
@@ -774,12 +880,15 @@ __device__ __noinline__ int fin128_offdiag(int tix_v, unsigned long long kernarg
     GPG_F128_PIECE(pb, L22, 64, 2)
     GPG_F128_PIECE(pb, L22, 64, 3)
   }
+  GPG_FS4(5)
   GPG_F128_STORE(64)
   __syncthreads();
+  GPG_FS4(6)
   return 1;
 #undef GPG_F128_PIECE
 #undef GPG_F128_UPDATE
 #undef GPG_F128_STORE
+#undef GPG_F128_TAKE_X
 }
 
 
@@ -789,7 +898,7 @@ __device__ __noinline__ int fin128_offdiag(int tix_v, unsigned long long kernarg
 //     A22 -= L21 L21^T on MFMA, L22 = chol(A22) (pieces pb).
 // Arguments as for fin128_offdiag: the ticket and the kernel's argument segment.
 template <int SET>
-__device__ __noinline__ int fin128_diag(int tix_v, unsigned long long kernarg_bits) {
+GPG_FIN_FN int fin128_diag(int tix_v, unsigned long long kernarg_bits) {
   constexpr int SA = 80;
   GPG_KERNARGS_FROM(TileCholArgs, ap, kernarg_bits);
   const int tix = __builtin_amdgcn_readfirstlane(tix_v);
@@ -814,21 +923,26 @@ __device__ __noinline__ int fin128_diag(int tix_v, unsigned long long kernarg_bi
   double* const U = fin128_U<SET>();
   double (*const Ls)[4][18] = fin128_Ls<SET>();
   double* const sdinv = fin128_sdinv<SET>();
-  const int tid = SET == 2 ? (int)threadIdx.x : (int)(threadIdx.x & 255), lane = tid & 63;
+  int tid_raw = (int)threadIdx.x;
+  asm volatile("" : "+v"(tid_raw));
+  const int tid = SET == 2 ? tid_raw : (tid_raw & 255), lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, l4 = lane >> 4;
   double* blk = A + cj + cj * (size_t)ld;
   double (*St)[64] = reinterpret_cast<double(*)[64]>(&Ls[0][0][0]);   // potrf scratch over the image region
   __syncthreads();   // A11 was left in the LDS tile by wave 0; the other waves' stores of A21 / A22 are drained below
+  GPG_FS4(0)
   {
     const int bad = potrf64_wg(U, SA, St, blk, ld, dinv + cj, pa, tid);   // L11 published in 16-column pieces pa[0..3]
     if (w == 0 && bad && lane == 0 && (int)cj + bad - 1 < N) atomicCAS(info, 0, (int)cj + bad);
   }
   __syncthreads();   // also drains the other waves' stores of A21 / A22
+  GPG_FS4(1)
   panel_solve_rows64(blk, ld, dinv + cj, blk + 64, ld, 64, 64, U, Ls, sdinv, tid);   // L21 = A21 L11^-T
   GPG_RELEASE();     // L21 is final (every thread stored part of it; the solve ended with a barrier)
   __syncthreads();
   if (tid == 0) GPG_FLAG_UP(flag_c);
+  GPG_FS4(2)
   const int sp = tid & 31, sk = tid >> 5;
   d4 a2[4];
   const double* C2 = blk + 64 + 16 * w + l15 + (size_t)(64 + l4) * ld;
@@ -844,10 +958,12 @@ __device__ __noinline__ int fin128_diag(int tix_v, unsigned long long kernarg_bi
 #pragma unroll
     for (int r = 0; r < 4; ++r) U[(ni * 16 + 4 * r + l4) * SA + 16 * w + l15] = a2[ni][r];
   __syncthreads();
+  GPG_FS4(3)
   {
     const int bad = potrf64_wg(U, SA, St, blk + 64 + (size_t)64 * ld, ld, dinv + cj + 64, pb, tid);   // L22: pb[0..3]
     if (w == 0 && bad && lane == 0 && (int)cj + 64 + bad - 1 < N) atomicCAS(info, 0, (int)cj + 64 + bad);
   }
+  GPG_FS4(4)
   return 1;
 }
 
@@ -855,7 +971,7 @@ __device__ __noinline__ int fin128_diag(int tix_v, unsigned long long kernarg_bi
 // branches out one after the other, the accumulators of the second stay live across the call of the first, and all 240 live VGPRs
 // are saved to scratch and reloaded around it (seen in the ISA, round 3).
 template <int SET>
-__device__ __noinline__ int fin128_task(int tix_v, unsigned long long kernarg_bits, int is_diag) {
+GPG_FIN_FN int fin128_task(int tix_v, unsigned long long kernarg_bits, int is_diag) {
   return __builtin_amdgcn_readfirstlane(is_diag) ? fin128_diag<SET>(tix_v, kernarg_bits) : fin128_offdiag<SET>(tix_v, kernarg_bits);
 }
 
@@ -864,7 +980,9 @@ tile128_chol_task(int tix, double* A, int ld, int Mt, const int* __restrict__ ta
                   int* ticket, double* __restrict__ dinv, int* __restrict__ info, int N, const int* __restrict__ batch_of, size_t a_stride,
                   int d_stride, int f_stride, unsigned long long kbits) {
   __shared__ int sh_kr;
-  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int tid_task = threadIdx.x;
+  asm volatile("" : "+v"(tid_task));   // per task: nothing derived from the lane index is kept alive from one task to the next (across its MFMA loop and finalisation)
+  const int tid = tid_task, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = w & 1, wn = w >> 1;
   const int l15 = lane & 15, l4 = lane >> 4;
   const int task = tasks[tix];
@@ -1070,7 +1188,9 @@ pair128_chol_task(int tix, double* Abase, int ld, int Mt, const int* __restrict_
                   int* ticket, double* __restrict__ dinv_base, int* __restrict__ info_base, int N, const int* __restrict__ batch_of,
                   size_t a_stride, int d_stride, int f_stride, unsigned long long kbits) {
   __shared__ int sh_kr;
-  const int tid = threadIdx.x, h = __builtin_amdgcn_readfirstlane(tid >> 8), t = tid & 255, lane = tid & 63;
+  int tid_task = threadIdx.x;
+  asm volatile("" : "+v"(tid_task));   // (see tile128_chol_task)
+  const int tid = tid_task, h = __builtin_amdgcn_readfirstlane(tid >> 8), t = tid & 255, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = w & 1, wn = w >> 1;
   const int l15 = lane & 15, l4 = lane >> 4;
@@ -1207,14 +1327,28 @@ pair128_chol_task(int tix, double* Abase, int ld, int Mt, const int* __restrict_
           }
     }
   }
+#ifdef GPG_STAMP
+  if (tid == 0) {
+    t128_fo = (g_stamp_buf != nullptr && tix < GPG_STAMP_MAX) ? g_stamp_buf + (size_t)GPG_STAMP_MAX * 8 + (size_t)tix * 8 : nullptr;
+    t128_wait_acc = 0;
+    if (t128_fo) for (int k = 0; k < 8; ++k) t128_fo[k] = 0;
+  }
+  GPG_FS3(5)
+#endif
   if ((h ? fin128_task<1>(tix, kbits, ti0 == tj) : fin128_task<0>(tix, kbits, ti0 == tj)) == 0) return false;
+#ifdef GPG_STAMP
+  if (tid == 0 && t128_fo) (g_stamp_buf + (size_t)GPG_STAMP_MAX * 16 + (size_t)tix * 16)[15] = t128_wait_acc;
+  GPG_FS3(2)
+#endif
   // ---- (3) publish both tiles (and fetch the next ticket) --------------------------------------------------------------------------
   {
     int nxt_ = 0;
     if (tid == 0) nxt_ = GPG_TICKET_FETCH(ticket);
     GPG_RELEASE();
+    GPG_FS3(3)
     if (tid == 0) g_next_ticket = nxt_;
     __syncthreads();
+    GPG_FS3(4)
     if (tid == 0) {
       GPG_FLAG_UP(fl0 + (size_t)ti0 * Mt + tj);
       GPG_FLAG_UP(fl1 + (size_t)ti1 * Mt + tj);

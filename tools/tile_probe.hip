@@ -75,17 +75,18 @@ int main(int argc, char** argv) {
     hipMemcpy(hb.data(), dbuf, hb.size() * 8, hipMemcpyDeviceToHost);
     FILE* f = fopen(argc > 4 ? argv[4] : "../gpurun_out/tile_timeline.csv", "w");
     if (f) {
-      fprintf(f, "block,ti,tj,start,end,spin_cyc,gemm_cyc,runs,fin0,f0,f1,f2,f3,f4,wg,f5,f6,f7,p0w,p0i,p0s,p1w,p1i,p1s,p2w,p2i,p2s,p3w,p3i,p3s\n");
+      fprintf(f, "block,ti,tj,start,end,spin_cyc,gemm_cyc,runs,fin0,f0,f1,f2,f3,f4,wg,f5,f6,f7,p0w,p0i,p0s,p1w,p1i,p1s,p2w,p2i,p2s,p3w,p3i,p3s,x12,x13,x14,finwait\n");
       unsigned long long t0 = ~0ull;
       for (int b = 0; b < GPG_STAMP_MAX; ++b) if (hb[b * 8 + 1] && hb[b * 8] < t0) t0 = hb[b * 8];
       for (int b = 0; b < GPG_STAMP_MAX; ++b) {
         const unsigned long long* o = &hb[(size_t)b * 8];
         if (o[1] == 0) continue;
         const unsigned long long* g = &hb[(size_t)GPG_STAMP_MAX * 8 + (size_t)b * 8];
-        fprintf(f, "%d,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu\n", b, o[6] & 0xffff, o[6] >> 16, o[0] - t0, o[1] - t0, o[2], o[3], o[4], o[5] - t0, g[0] - t0, g[1] - t0, g[2] - t0, g[3] - t0, g[4] ? g[4] - t0 : 0ull, o[7], g[5] ? g[5] - t0 : 0ull, g[6] ? g[6] - t0 : 0ull, g[7] ? g[7] - t0 : 0ull);
+        fprintf(f, "%d,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu,%llu\n", b, o[6] & 0xffff, o[6] >> 16, o[0] - t0, o[1] - t0, o[2], o[3], o[4], o[5] - t0, g[0] - t0, g[1] - t0, g[2] - t0, g[3] - t0, g[4] ? g[4] - t0 : 0ull, o[7], g[5] ? g[5] - t0 : 0ull, g[6] ? g[6] - t0 : 0ull, g[7] > 16 ? g[7] - t0 : g[7]);
         const unsigned long long* pz = &hb[(size_t)GPG_STAMP_MAX * 16 + (size_t)b * 16];
         fseek(f, -1, SEEK_CUR);
         for (int k = 0; k < 12; ++k) fprintf(f, ",%llu", pz[k] ? pz[k] - t0 : 0ull);
+        for (int k = 12; k < 16; ++k) fprintf(f, ",%llu", pz[k]);
         fprintf(f, "\n");
       }
       fclose(f);
