@@ -594,9 +594,161 @@ __device__ __forceinline__ void fin128_handoff_block0(const d4 (&acc)[4][4], int
   if (wm == 0) { GPG_F128_HAND(U, 80) } else { GPG_F128_HAND(L2, 72) }
 #undef GPG_F128_HAND
 }
-// Called with the ticket and the kernel's argument segment only: everything else is re-derived here by scalar loads.  What a task
-// keeps alive across its MFMA loop is spilled, and every spill reload after the loop is a memory round trip under full load (the
-// timeline of the first version of this function showed ~35 us of them in front of the call).
+#ifdef GPG_STAMP
+#define GPG_FS4(k) if (SET != 1 && threadIdx.x == 0 && t128_fo) t128_fo[k] = __builtin_amdgcn_s_memrealtime();
+#else
+#define GPG_FS4(k)
+#endif
+// fin128_onepiece: X <- X L^-T for a 128 x 128 tile whose column block 0 has been handed over in LDS (fin128_handoff_block0) and whose
+// column block 1 sits in memory, against a COMPLETE diagonal tile L (reciprocal pivots dinv) -- the one-piece path of fin128_offdiag, also
+// the finalisation of tile128_trinv_kernel (whose diagonal tiles are always complete).  The caller has synchronised the workgroup after
+// the hand-over (and the stores of block 1); on return the stores of X are in flight: the caller's publish step waits for them.
+// One-piece path (the diagonal tile was complete on entry).  Round 3, second half: the update of column block 1 no longer goes
+// through memory.  Before: X1 stored, s_waitcnt vmcnt(0) + barrier (5.5 us of store acknowledgements), then wave_tile_gemm staging
+// X1 and L21 from memory through LDS with three barriers per 16-deep chunk (14.8 us) -- for 128 MFMAs per wave.  Now L21 is brought
+// in with L11 (one round trip) and parked k-major in the staging tile, the A operand -X1 comes straight out of the substitution's
+// registers by a lane permutation (quad layout: lane 4 r + q holds row r, columns 4 m + q; MFMA layout: lane 16 k + r holds row r,
+// column 4 s + k: source lane 4 l15 + l4, register m = s), the X1 store is left in flight until the task publishes, and the
+// transposition back into the quad layout is wave-private (wave w owns rows 16 w .. 16 w + 15 in both layouts).  Two barriers
+// instead of fourteen.  Same MFMA operands in the same order as GPG_F128_UPDATE (fn = L21 fragment, fm = -X1 fragment, accumulator
+// preloaded with T2, k ascending): bit-identical with the piecewise path.
+template <int SET>
+__device__ __forceinline__ void fin128_onepiece(double* X, int ldx, const double* L, int ldl, const double* dinv) {
+  constexpr int SA = 80, S2 = 72;
+  double* const U = fin128_U<SET>();
+  double (*const Ls)[4][18] = fin128_Ls<SET>();
+  double* const sdinv = fin128_sdinv<SET>();
+  int tid_raw = (int)threadIdx.x;
+  asm volatile("" : "+v"(tid_raw));
+  const int tid = SET == 2 ? tid_raw : (tid_raw & 255), lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, l4 = lane >> 4;
+  const int q = tid & 3, rr = tid >> 2;
+  (void)l15; (void)l4;
+  double x0[16], x1[16];
+#define GPG_F128_TAKE_X()                                                                    \
+  {                                                                                         \
+    int tq = tid;                                                                           \
+    asm volatile("" : "+v"(tq));                                                            \
+    const double* T0 = U + (tq & 3) * SA + (tq >> 2);                                        \
+    const double* T1 = &fin128_Ls<SET>()[0][0][0] + (tq & 3) * S2 + (tq >> 2);               \
+    _Pragma("unroll") for (int m = 0; m < 16; ++m) {                                         \
+      x0[m] = T0[(4 * m) * SA];                                                             \
+      x1[m] = T1[(4 * m) * S2];                                                             \
+    }                                                                                       \
+  }
+  GPG_ACQUIRE();
+  GPG_F128_TAKE_X()
+  double li[16], lj[16];                                     // raw 64 x 64 blocks of L, 16 entries per thread
+#define GPG_F128_RAW(dst, LP)                                                                \
+  _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                         \
+    const int t = tid + 256 * i;                                                          \
+    dst[i] = (LP)[(t & 63) + (size_t)(t >> 6) * ldl];                                      \
+  }
+#define GPG_F128_IMAGE(DOFF)                                                                 \
+  _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                         \
+    const int t = tid + 256 * i, jj = t >> 6, k = t & 63;                                  \
+    Ls[jj][k & 3][k >> 2] = li[i];                                                        \
+  }                                                                                       \
+  if (tid < 64) sdinv[tid] = dinv[(DOFF) + tid];
+  GPG_F128_RAW(li, L)
+  GPG_F128_RAW(lj, L + 64)                                   // L21[n][k] = L[64 + n + k ldl]
+  GPG_LDS_BARRIER();                                         // every thread has taken x0 / x1 out of the staging tile and the image region
+  GPG_F128_IMAGE(0)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {                             // L21 k-major: U[k][n], row stride SA
+    const int t = tid + 256 * i;
+    U[(t >> 6) * SA + (t & 63)] = lj[i];
+  }
+  GPG_F128_RAW(li, L + 64 + (size_t)64 * ldl)                // L22: in flight through the column steps of block 0
+  GPG_LDS_BARRIER();
+  GPG_FS4(2)
+  {
+    double* const Xs = X + rr + (size_t)q * ldx;             // the finished columns of X1 leave behind the steps (no wait before the task publishes)
+#define GPG_F128_HOOK(mj) GPG_ST(&Xs[(size_t)(4 * (mj)) * ldx], x0[mj]); GPG_ST(&Xs[64 + (size_t)(4 * (mj)) * ldx], x1[mj]);
+    GPG_QUAD_SUBST2_HOOK(x0, x1, Ls, sdinv, q, GPG_F128_HOOK)
+  }
+  GPG_FS4(3)
+  // (addresses used from here on are re-derived from an opaque copy of the thread index: computed ahead of the column steps -- they are
+  // pure functions of it -- they were kept in ~50 registers across the steps and spilled around them)
+  int tid2 = tid;
+  asm volatile("" : "+v"(tid2));
+#define GPG_F128_RELANE(t)  const int lane_ = (t) & 63, l15 = lane_ & 15, l4 = lane_ >> 4, q = (t) & 3, rr = (t) >> 2, tid = (t); (void)l15; (void)l4; (void)q; (void)rr; (void)tid;
+  d4 c0[4], c1[4];                                           // T2 in the MFMA layout: rows 16 w + l15 (c0) and 64 + 16 w + l15 (c1), column 64 + 16 ni + 4 r + l4
+  {
+    GPG_F128_RELANE(tid2)
+    const double* Cw = X + 16 * w + l15 + (size_t)(64 + l4) * ldx;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        c0[ni][r] = Cw[(size_t)(ni * 16 + 4 * r) * ldx];
+        c1[ni][r] = Cw[64 + (size_t)(ni * 16 + 4 * r) * ldx];
+      }
+  }
+  double a0[16], a1[16];
+  {
+    GPG_F128_RELANE(tid2)
+    const int src = 4 * (4 * l15 + l4);
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const int lo0 = __builtin_amdgcn_ds_bpermute(src, __double2loint(x0[m])), hi0 = __builtin_amdgcn_ds_bpermute(src, __double2hiint(x0[m]));
+      const int lo1 = __builtin_amdgcn_ds_bpermute(src, __double2loint(x1[m])), hi1 = __builtin_amdgcn_ds_bpermute(src, __double2hiint(x1[m]));
+      a0[m] = -__hiloint2double(hi0, lo0);
+      a1[m] = -__hiloint2double(hi1, lo1);
+    }
+  }
+  GPG_FS3(6)
+  GPG_LDS_BARRIER();                                         // (1) every wave is through the column steps of block 0: the image region is free
+  GPG_FS4(4)
+  {
+    GPG_F128_RELANE(tid2)
+    GPG_F128_IMAGE(64)
+#pragma unroll
+    for (int s4 = 0; s4 < 16; ++s4) {
+      double fn[4];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) fn[ni] = U[(4 * s4 + l4) * SA + ni * 16 + l15];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        c0[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(fn[ni], a0[s4], c0[ni], 0, 0, 0);
+        c1[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(fn[ni], a1[s4], c1[ni], 0, 0, 0);
+      }
+    }
+  }
+  GPG_LDS_BARRIER();                                         // (2) L21 is no longer read from the staging tile; the image of L22 is complete
+  {
+    GPG_F128_RELANE(tid2)
+    const double* Tr = U + q * SA + rr;                      // rows 16 w .. 16 w + 15 are written and read by wave w only: no barrier
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) U[(ni * 16 + 4 * r + l4) * SA + 16 * w + l15] = c0[ni][r];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) x0[m] = Tr[(4 * m) * SA];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) U[(ni * 16 + 4 * r + l4) * SA + 16 * w + l15] = c1[ni][r];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) x1[m] = Tr[(4 * m) * SA];
+  }
+  GPG_FS4(5)
+  {
+    GPG_F128_RELANE(tid2)
+    double* const Xs = X + rr + (size_t)(64 + q) * ldx;
+    GPG_QUAD_SUBST2_HOOK(x0, x1, Ls, sdinv, q, GPG_F128_HOOK)
+#undef GPG_F128_HOOK
+  }
+  GPG_FS4(6)
+  GPG_FS3(0)
+  GPG_FS3(1)
+#undef GPG_F128_RELANE
+#undef GPG_F128_RAW
+#undef GPG_F128_IMAGE
+#undef GPG_F128_TAKE_X
+}
+
 #ifndef GPG_FIN_INLINE
 #define GPG_FIN_INLINE 1
 #endif
@@ -605,6 +757,9 @@ __device__ __forceinline__ void fin128_handoff_block0(const d4 (&acc)[4][4], int
 #else
 #define GPG_FIN_FN __device__ __noinline__
 #endif
+// Called with the ticket and the kernel's argument segment only: everything else is re-derived here by scalar loads.  What a task
+// keeps alive across its MFMA loop is spilled, and every spill reload after the loop is a memory round trip under full load (the
+// timeline of the first version of this function showed ~35 us of them in front of the call).
 template <int SET>
 GPG_FIN_FN int fin128_offdiag(int tix_v, unsigned long long kernarg_bits) {
   constexpr int SA = 80, S2 = 72, BUF = 16 * SA;
@@ -651,11 +806,6 @@ GPG_FIN_FN int fin128_offdiag(int tix_v, unsigned long long kernarg_bits) {
   const double* const dinv = dinv_m + cj;
   double* const X = A + r0 + cj * (size_t)ld;
   const int ldl = ld, ldx = ld;
-#ifdef GPG_STAMP
-#define GPG_FS4(k) if (SET != 1 && threadIdx.x == 0 && t128_fo) t128_fo[k] = __builtin_amdgcn_s_memrealtime();
-#else
-#define GPG_FS4(k)
-#endif
   GPG_FS4(0)
   if (threadIdx.x == 0)
     *sh = __hip_atomic_load(done0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 &&
@@ -707,125 +857,8 @@ GPG_FIN_FN int fin128_offdiag(int tix_v, unsigned long long kernarg_bits) {
     }                                                                                       \
   }
   if (fast) {
-    // One-piece path (the diagonal tile was complete on entry).  Round 3, second half: the update of column block 1 no longer goes
-    // through memory.  Before: X1 stored, s_waitcnt vmcnt(0) + barrier (5.5 us of store acknowledgements), then wave_tile_gemm staging
-    // X1 and L21 from memory through LDS with three barriers per 16-deep chunk (14.8 us) -- for 128 MFMAs per wave.  Now L21 is brought
-    // in with L11 (one round trip) and parked k-major in the staging tile, the A operand -X1 comes straight out of the substitution's
-    // registers by a lane permutation (quad layout: lane 4 r + q holds row r, columns 4 m + q; MFMA layout: lane 16 k + r holds row r,
-    // column 4 s + k: source lane 4 l15 + l4, register m = s), the X1 store is left in flight until the task publishes, and the
-    // transposition back into the quad layout is wave-private (wave w owns rows 16 w .. 16 w + 15 in both layouts).  Two barriers
-    // instead of fourteen.  Same MFMA operands in the same order as GPG_F128_UPDATE (fn = L21 fragment, fm = -X1 fragment, accumulator
-    // preloaded with T2, k ascending): bit-identical with the piecewise path.
-    GPG_ACQUIRE();
-    GPG_F128_TAKE_X()
-    double li[16], lj[16];                                     // raw 64 x 64 blocks of L, 16 entries per thread
-#define GPG_F128_RAW(dst, LP)                                                                \
-    _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                         \
-      const int t = tid + 256 * i;                                                          \
-      dst[i] = (LP)[(t & 63) + (size_t)(t >> 6) * ldl];                                      \
-    }
-#define GPG_F128_IMAGE(DOFF)                                                                 \
-    _Pragma("unroll") for (int i = 0; i < 16; ++i) {                                         \
-      const int t = tid + 256 * i, jj = t >> 6, k = t & 63;                                  \
-      Ls[jj][k & 3][k >> 2] = li[i];                                                        \
-    }                                                                                       \
-    if (tid < 64) sdinv[tid] = dinv[(DOFF) + tid];
-    GPG_F128_RAW(li, L)
-    GPG_F128_RAW(lj, L + 64)                                   // L21[n][k] = L[64 + n + k ldl]
-    GPG_LDS_BARRIER();                                         // every thread has taken x0 / x1 out of the staging tile and the image region
-    GPG_F128_IMAGE(0)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {                             // L21 k-major: U[k][n], row stride SA
-      const int t = tid + 256 * i;
-      U[(t >> 6) * SA + (t & 63)] = lj[i];
-    }
-    GPG_F128_RAW(li, L + 64 + (size_t)64 * ldl)                // L22: in flight through the column steps of block 0
-    GPG_LDS_BARRIER();
-    GPG_FS4(2)
-    {
-      double* const Xs = X + rr + (size_t)q * ldx;             // the finished columns of X1 leave behind the steps (no wait before the task publishes)
-#define GPG_F128_HOOK(mj) GPG_ST(&Xs[(size_t)(4 * (mj)) * ldx], x0[mj]); GPG_ST(&Xs[64 + (size_t)(4 * (mj)) * ldx], x1[mj]);
-      GPG_QUAD_SUBST2_HOOK(x0, x1, Ls, sdinv, q, GPG_F128_HOOK)
-    }
-    GPG_FS4(3)
-    // (addresses used from here on are re-derived from an opaque copy of the thread index: computed ahead of the column steps -- they are
-    // pure functions of it -- they were kept in ~50 registers across the steps and spilled around them)
-    int tid2 = tid;
-    asm volatile("" : "+v"(tid2));
-#define GPG_F128_RELANE(t)  const int lane_ = (t) & 63, l15 = lane_ & 15, l4 = lane_ >> 4, q = (t) & 3, rr = (t) >> 2, tid = (t); (void)l15; (void)l4; (void)q; (void)rr; (void)tid;
-    d4 c0[4], c1[4];                                           // T2 in the MFMA layout: rows 16 w + l15 (c0) and 64 + 16 w + l15 (c1), column 64 + 16 ni + 4 r + l4
-    {
-      GPG_F128_RELANE(tid2)
-      const double* Cw = X + 16 * w + l15 + (size_t)(64 + l4) * ldx;
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          c0[ni][r] = Cw[(size_t)(ni * 16 + 4 * r) * ldx];
-          c1[ni][r] = Cw[64 + (size_t)(ni * 16 + 4 * r) * ldx];
-        }
-    }
-    double a0[16], a1[16];
-    {
-      GPG_F128_RELANE(tid2)
-      const int src = 4 * (4 * l15 + l4);
-#pragma unroll
-      for (int m = 0; m < 16; ++m) {
-        const int lo0 = __builtin_amdgcn_ds_bpermute(src, __double2loint(x0[m])), hi0 = __builtin_amdgcn_ds_bpermute(src, __double2hiint(x0[m]));
-        const int lo1 = __builtin_amdgcn_ds_bpermute(src, __double2loint(x1[m])), hi1 = __builtin_amdgcn_ds_bpermute(src, __double2hiint(x1[m]));
-        a0[m] = -__hiloint2double(hi0, lo0);
-        a1[m] = -__hiloint2double(hi1, lo1);
-      }
-    }
-    GPG_FS3(6)
-    GPG_LDS_BARRIER();                                         // (1) every wave is through the column steps of block 0: the image region is free
-    GPG_FS4(4)
-    {
-      GPG_F128_RELANE(tid2)
-      GPG_F128_IMAGE(64)
-#pragma unroll
-      for (int s4 = 0; s4 < 16; ++s4) {
-        double fn[4];
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) fn[ni] = U[(4 * s4 + l4) * SA + ni * 16 + l15];
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-          c0[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(fn[ni], a0[s4], c0[ni], 0, 0, 0);
-          c1[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(fn[ni], a1[s4], c1[ni], 0, 0, 0);
-        }
-      }
-    }
-    GPG_LDS_BARRIER();                                         // (2) L21 is no longer read from the staging tile; the image of L22 is complete
-    {
-      GPG_F128_RELANE(tid2)
-      const double* Tr = U + q * SA + rr;                      // rows 16 w .. 16 w + 15 are written and read by wave w only: no barrier
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) U[(ni * 16 + 4 * r + l4) * SA + 16 * w + l15] = c0[ni][r];
-#pragma unroll
-      for (int m = 0; m < 16; ++m) x0[m] = Tr[(4 * m) * SA];
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) U[(ni * 16 + 4 * r + l4) * SA + 16 * w + l15] = c1[ni][r];
-#pragma unroll
-      for (int m = 0; m < 16; ++m) x1[m] = Tr[(4 * m) * SA];
-    }
-    GPG_FS4(5)
-    {
-      GPG_F128_RELANE(tid2)
-      double* const Xs = X + rr + (size_t)(64 + q) * ldx;
-      GPG_QUAD_SUBST2_HOOK(x0, x1, Ls, sdinv, q, GPG_F128_HOOK)
-#undef GPG_F128_HOOK
-    }
-    GPG_FS4(6)
-    GPG_FS3(0)
-    GPG_FS3(1)
+    fin128_onepiece<SET>(X, ldx, L, ldl, dinv);
     return 1;                                                  // (the caller's publish step waits for the stores and synchronises the workgroup)
-#undef GPG_F128_RELANE
-#undef GPG_F128_RAW
-#undef GPG_F128_IMAGE
   }
   GPG_F128_TAKE_X()
   __syncthreads();                                             // x1 is out of the image region, *sh may be rewritten
@@ -1479,6 +1512,36 @@ tile128_trinv_task(int tix, const double* __restrict__ A, int ld, const double* 
     kdone = kr;
   }
   direct_tile_negate(acc);
+#ifndef GPG_TRINV_OLDFIN
+  // (r03) the factorisation's one-piece finalisation: column block 0 handed over through LDS, column block 1 through memory; the diagonal
+  // tile of L is final, so there is nothing to wait for
+  {
+    double* Cs = Cw;                                          // (store addresses formed here, see tile128_chol_task)
+    asm volatile("" : "+v"(Cs));
+    int l15s = l15, l4s = l4;
+    asm volatile("" : "+v"(l15s), "+v"(l4s));
+    if (wn == 0) fin128_handoff_block0<2>(acc, wm, l15s, l4s);
+    else {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            double2 v;
+            v.x = acc[ni][2 * g][r];
+            v.y = acc[ni][2 * g + 1][r];
+            *reinterpret_cast<double2*>(Cs + 32 * g + (size_t)(32 * (ni >> 1) + 8 * r + (ni & 1)) * ldw) = v;
+          }
+    }
+  }
+  __syncthreads();
+  GPG_PRIO(2);
+#ifdef GPG_STAMP
+  if (tid == 0) t128_fo = nullptr;
+#endif
+  fin128_onepiece<2>(W + r0 + ci * (size_t)ldw, ldw, A + ci + ci * (size_t)ld, ld, dinv + ci);
+#else
 #pragma unroll
   for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
@@ -1499,6 +1562,7 @@ tile128_trinv_task(int tix, const double* __restrict__ A, int ld, const double* 
   if (!tile_solve_rows128(A + ci + ci * (size_t)ld, ld, dinv + ci, W + r0 + ci * (size_t)ldw, ldw, t128_U, t128_Ls, t128_sdinv, ones,
                           ones + 4, ones, abort_word, info, &sh_ok))
     return false;
+#endif
   GPG_PUBLISH_AND_NEXT(ticket, frow + ti)
   return true;
 }
