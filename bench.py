@@ -207,7 +207,12 @@ def self_launch(nranks):
         time.sleep(0.05)
     reader.join(timeout=10.0)
     out0 = buf[0] if buf else b""
-    sys.stdout.write(out0.decode())
+    for ln in out0.decode(errors="replace").splitlines():        # ONE JSON line on our stdout; whatever else rank 0 (or a library in it,
+        ln_s = ln.strip()                                        # e.g. gloo's connection notice) wrote there goes to stderr
+        if ln_s.startswith("{") and ln_s.endswith("}"):
+            sys.stdout.write(ln_s + "\n")
+        elif ln_s:
+            print(ln, file=sys.stderr)
     sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(rcs) if c != 0]
     if bad:
