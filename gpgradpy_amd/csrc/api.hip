@@ -495,14 +495,16 @@ static int batch_plan(gpg_ctx* c, int m) {
       // ~1280 tasks of the 128-tile kernel per tile-column round (measured, tools/tile_probe 5: 2560 columns 32 / 37 /
       // 41 TF with 16 / 32 / 64 matrices, 4608: 42 / 51 / 52 with 8 / 32 / 64, 9216: 59 / 60 with 8 / 16, 18048: +0.3 %
       // from 8 to 16); none at 68k columns
-      bmax = (1280 + c->Npad / 128 - 1) / (c->Npad / 128);
+      // (r03, pair kernel with the cheaper finalisation: twice as many still pay -- 2560 columns 48.5 -> 51.6 TF from 64 to 128
+      // matrices, 9216: 64.9 -> 65.6 from 16 to 32, 18048: 68.6 -> 69.1 from 10 to 20 -- the two ends of a launch are shared by more work)
+      bmax = (2816 + c->Npad / 128 - 1) / (c->Npad / 128);
     } else {
       // very large matrices (cfg5: 68096 padded columns, 37 GB per workspace): the chain-bound ends are ~3 % of one
       // factorisation there and several matrices per launch gain nothing (measured: 65.7 TF with three per launch against
       // 66.0 one at a time, profiles/r02b_bench_cfg5_3perlaunch.json); gpg_set_batch(2..3) still works (288 GB hold them)
       bmax = 1;
     }
-    if (bmax > 1) bmax = bmax < 8 ? 8 : (bmax > 64 ? 64 : bmax);
+    if (bmax > 1) bmax = bmax < 8 ? 8 : (bmax > 128 ? 128 : bmax);
   }
   if (c->batch_max > 1 && c->Npad > 32768 && bmax > 3) bmax = 3;
   if (!(small || large_df) || bmax <= 1 || m <= 1) return 1;
