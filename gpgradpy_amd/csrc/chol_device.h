@@ -41,6 +41,10 @@ __device__ __forceinline__ void gpg_store_through(double* p, double v) {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for the wave's outstanding global stores (vmcnt(0) --
+// microseconds for write-through stores), which the LDS hand-overs inside a finalisation do not need
+#define GPG_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -163,6 +167,14 @@ __device__ __forceinline__ int potrf64_wave(const double* src, int sld, double (
 // value is that of wave 0 (other waves return 0).
 // tid_in: index of the calling thread inside its 256-thread team (default: threadIdx.x; the pair kernel runs two teams per workgroup,
 // whose barriers -- __syncthreads, all 512 threads -- coincide because both teams execute the same sequence).
+#ifndef GPG_POTRF_DEFER
+#define GPG_POTRF_DEFER 3        // pivot of the next sub-block at which the previous piece is published (0: right behind its stores, as in rounds 1 / 2)
+#endif
+#if GPG_POTRF_DEFER
+#define GPG_POTRF_BARRIER() GPG_LDS_BARRIER()   // the barriers inside order the LDS image only (src is an LDS tile at every call site); no wait for the stores
+#else
+#define GPG_POTRF_BARRIER() __syncthreads()
+#endif
 __device__ __forceinline__ int potrf64_wg(const double* src, int sld, double (*St)[64], double* __restrict__ blk, int ld,
                                           double* __restrict__ dinv, int* piece_flags = nullptr, int tid_in = -1) {
   const int tid_team = tid_in < 0 ? (int)threadIdx.x : tid_in;
@@ -192,7 +204,7 @@ __device__ __forceinline__ int potrf64_wg(const double* src, int sld, double (*S
 #pragma unroll
         for (int r = 0; r < 4; ++r) St[16 * s + 4 * r + l4][16 * w + l15] = pre[r];
       }
-      __syncthreads();                                     // the updated panel is in St[16 s .. 16 s + 15][.]
+      GPG_POTRF_BARRIER();                                 // the updated panel is in St[16 s .. 16 s + 15][.]
       if (w == 0) {
 #pragma unroll
         for (int c = 0; c < 16; ++c) a[c] = St[16 * s + c][i];
@@ -203,6 +215,15 @@ __device__ __forceinline__ int potrf64_wg(const double* src, int sld, double (*S
       double ajj = readlane_d(a[0], 16 * s);
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
+#if GPG_POTRF_DEFER
+        // the PREVIOUS sub-block's columns went to memory ~1000 cycles ago: their acknowledgements are in (or nearly), the wait costs
+        // nothing now -- right behind the stores it cost ~800 cycles of the pivot chain per sub-block (tools/potrf_probe: 28.4 k cycles
+        // with the pieces published against 25.1 k without)
+        if (s > 0 && c == GPG_POTRF_DEFER && piece_flags) {
+          GPG_RELEASE();
+          if (i == 0) GPG_FLAG_UP(piece_flags + s - 1);
+        }
+#endif
         bad = (bad == 0 && !(ajj > 0.0)) ? 16 * s + c + 1 : bad;
         const double y0 = __builtin_amdgcn_rsq(ajj);
         double g = ajj * y0, h = 0.5 * y0;
@@ -230,7 +251,7 @@ __device__ __forceinline__ int potrf64_wg(const double* src, int sld, double (*S
         if (i >= 16 * s + c) GPG_ST(&blk[i + (size_t)(16 * s + c) * ld], a[c]);
       }
       if (i >= 16 * s && i < 16 * s + 16) GPG_ST(&dinv[i], myinv);
-      if (piece_flags) {
+      if (piece_flags && (!GPG_POTRF_DEFER || s == 3)) {   // pieces 0 .. 2: published from inside the next sub-block's pivot phase
         GPG_RELEASE();
         if (i == 0) GPG_FLAG_UP(piece_flags + s);
       }
@@ -247,7 +268,7 @@ __device__ __forceinline__ int potrf64_wg(const double* src, int sld, double (*S
       }
     }
     GPG_PS(2 * s + 1)
-    if (s < 3) __syncthreads();                            // columns 16 s .. 16 s + 15 of St are final for the next update
+    if (s < 3) GPG_POTRF_BARRIER();                        // columns 16 s .. 16 s + 15 of St are final for the next update
   }
   return bad;
 }
@@ -398,9 +419,6 @@ __device__ __forceinline__ void wave_tile_gemm(d4 (&acc)[4], const double* ga, i
       HOOK(mj)                                                                              \
     }                                                                                       \
   }
-// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for the wave's outstanding global stores (vmcnt(0) --
-// microseconds for write-through stores), which the LDS hand-overs inside a finalisation do not need
-#define GPG_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 // one 16-column piece of GPG_QUAD_SUBST2 (see GPG_QUAD_SUBST_PIECE)
 #define GPG_QUAD_SUBST2_PIECE(x0, x1, Ls, sdinv, q, s)                                       \
   {                                                                                         \
