@@ -283,9 +283,16 @@ tile_chol_task(int tix, double* A, int ld, int c0, int Mt, const int* __restrict
       for (int m = 0; m < 16; ++m) x[m] = Tr[(4 * m) * SA];
     }
     GPG_TC_PIECE(0, tj - 1, cjm)
+    GPG_TR(tq_p0)
     GPG_TC_PIECE(1, tj - 1, cjm)
     GPG_TC_PIECE(2, tj - 1, cjm)
+    GPG_TR(tq_p2)
+#ifdef GPG_STAMP
+    if (!wg_wait_flag(pieces + 4 * (tj - 1) + 3, abort_word, info, &sh_kr)) return false;   // (diagnostic: when piece 3 is SEEN; the wait inside the piece macro then falls through)
+#endif
+    GPG_TR(tq_seen3)
     GPG_TC_PIECE(3, tj - 1, cjm)
+    GPG_TR(tq_sub3)
     {
       double* Xr = A + r0 + (tid >> 2) + (cjm + q) * (size_t)ld;
       double* Tw = U + q * SA + (tid >> 2);
@@ -308,6 +315,13 @@ tile_chol_task(int tix, double* A, int ld, int c0, int Mt, const int* __restrict
     GPG_RELEASE();                                        // the stores of X have had the whole update to complete
     __syncthreads();                                      // ... and the LDS tile is free again
     if (tid == 0) GPG_FLAG_UP(frow_i + (tj - 1));          // tile (tj, tj-1) is final for everybody else
+    GPG_TR(tq_upd)
+#ifdef GPG_STAMP   // tools/timeline_chain64.py: the chain of the fused diagonal tasks, split at these stamps
+    if (tid == 0 && g_stamp_buf != nullptr && tix < GPG_STAMP_MAX) {
+      unsigned long long* pz = g_stamp_buf + (size_t)GPG_STAMP_MAX * 16 + (size_t)tix * 16;
+      pz[0] = tq_p0; pz[1] = tq_p2; pz[2] = tq_seen3; pz[3] = tq_sub3; pz[4] = tq_upd;
+    }
+#endif
   }
   // ---- (2) accumulators -> LDS tile Ts[col][row] --------------------------------------------------------------
   {
@@ -321,7 +335,13 @@ tile_chol_task(int tix, double* A, int ld, int c0, int Mt, const int* __restrict
     __syncthreads();
     {   // diagonal tile: factor it (pivots on wave 0, the MFMA updates on all four; entries above the diagonal are garbage nobody reads)
       double* blk = A + r0 + cj * (size_t)ld;
+#ifdef GPG_STAMP
+      if (tid == 0 && g_stamp_buf != nullptr && tix < GPG_STAMP_MAX) (g_stamp_buf + (size_t)GPG_STAMP_MAX * 16 + (size_t)tix * 16)[5] = __builtin_amdgcn_s_memrealtime();
+#endif
       const int bad = potrf64_wg(U, SA, reinterpret_cast<double(*)[64]>(&Ls[0][0][0]), blk, ld, dinv + cj, pieces + 4 * tj);
+#ifdef GPG_STAMP
+      if (tid == 0 && g_stamp_buf != nullptr && tix < GPG_STAMP_MAX) (g_stamp_buf + (size_t)GPG_STAMP_MAX * 16 + (size_t)tix * 16)[6] = __builtin_amdgcn_s_memrealtime();
+#endif
       if (w == 0 && bad && lane == 0 && (int)cj + bad - 1 < N) atomicCAS(info, 0, (int)cj + bad);
     }
   } else {
