@@ -7,7 +7,7 @@ to its durations from the kernel trace of the same command.
 --mats: matrices factorised by each dispatch of the dominant kernel, in dispatch order (bench.py: one warm-up launch with
 `warmup` rows, then the timed launches).  FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB; on gfx950 FETCH_SIZE
 counts a wide streamed read at half its bytes (MI355X_MICROARCH.md, HBM section): traffic = 2 x FETCH + WRITE.
-Prints a text table (redirect into profiles/) and, with --update, rewrites the entries of that configuration in the
+Prints a text table (redirect into profiles/) and, with --update, rewrites the entries of that configuration, kernel and launch size in the
 JSON table bench.py reads `roofline.traffic` from."""
 import argparse
 import collections
@@ -98,10 +98,12 @@ if args.update:
         table = json.load(open(args.update))
     except (OSError, ValueError):
         table = {"entries": []}
-    keep = [e for e in table.get("entries", []) if not (e.get("config") == args.config and e.get("kernel") == args.kernel)]
     best = {}
     for e in entries:                     # one entry per matrices_per_launch: the LAST dispatch of that size (timed region)
         best[e["matrices_per_launch"]] = e
+    # entries of this configuration and kernel with OTHER launch sizes stay (bench.py looks one up by matrices per launch)
+    keep = [e for e in table.get("entries", [])
+            if not (e.get("config") == args.config and e.get("kernel") == args.kernel and e.get("matrices_per_launch") in best)]
     table["entries"] = keep + [best[k] for k in sorted(best)]
     table["note"] = "per-launch HBM traffic of the dominant kernel from rocprofv3 PMC passes; written by tools/pmc_driver_summarize.py, read by bench.py"
     json.dump(table, open(args.update, "w"), indent=1)
