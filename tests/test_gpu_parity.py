@@ -317,6 +317,28 @@ def test_batched_small_matrices_bitwise():
     assert np.isnan(ln[2]) and np.all(np.isfinite(np.delete(ln, 2)))
 
 
+def test_many_rows_per_launch_bitwise():
+    """Round 3 doubled the number of restart rows a dataflow launch takes (batch_plan: up to 128 of a 2560-column shape).  130 rows
+    of a 2176-column problem go through two launches of 65; every row must equal its one-at-a-time evaluation bit for bit, and
+    the factorisation must have been the paired 128-tile kernel without a fallback."""
+    import gpgradpy_amd
+    from oracle import gp_oracle as orc
+    n, d = 410, 4                                                          # N = 2050 -> 17 tile rows of 128
+    X, f, g = orc.synthetic_design(n, d, seed=3)
+    rows = np.random.default_rng(4).uniform(-2.3, -0.6, (130, d))
+    GP = gpgradpy_amd.GaussianProcess(d, True, 'SqExp', 'precon')
+    GP.set_data(X, f, np.zeros(n), g, np.zeros((n, d)))
+    ln = GP.calc_lkd_batch(rows)
+    assert np.all(np.isfinite(ln))
+    assert GP.last_factor()[0] == 'pair128' and GP.factor_fallbacks() == 0
+    GP1 = gpgradpy_amd.GaussianProcess(d, True, 'SqExp', 'precon')
+    GP1.set_data(X, f, np.zeros(n), g, np.zeros((n, d)))
+    GP1.set_batch(0)
+    for i in (0, 64, 65, 100, 129):
+        one = GP1.calc_lkd_all(GP1.hp_vec2dataclass(GP1.hp_info_optz_lkd, rows[i]))[0].ln_lkd
+        assert one == ln[i], (i, one, ln[i])
+
+
 def test_tile_pairs_bitwise_and_progress():
     """pair128_chol_kernel (two tiles of a tile column per 512-thread workgroup; batched launches): forced on small matrices
     (gpg_set_pair_mode 1) it must reproduce the one-tile-per-workgroup launch bit for bit -- odd and even numbers of matrices (a
